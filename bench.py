@@ -1,0 +1,216 @@
+#!/usr/bin/env python
+"""bench.py -- VB EM iterations/s of the MI355X VBx hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (config.workload): every GPU holds a batch of ``--batch`` independent synthetic
+recordings of the headline shape T=10 000 x-vectors, R=128, S=30 (vbx_amd.synth, kappa=0.05,
+random gamma init); BASELINE.json config 4 ("64 recordings over 8 GPUs") gives the default
+of 8 per GPU.  One *step* = one VB EM iteration (M-step, log-likelihoods, forward-backward,
+ELBO, pi update: VBx.py:94-105) of every recording in the batch.  ``value`` counts
+recording-iterations per second over all ranks; inputs are resident in HBM before the timed
+region.  Weak scaling: per-GPU work is fixed, recordings never talk to each other, RCCL is
+used only for the barrier / max-over-ranks of the timings.
+
+Also reported on the same JSON line:
+  single_recording  latency-bound rate of ONE recording (batch=1) on one GPU
+  roofline          dominant kernel: algorithmic bytes / HIP-event time vs the 8 TB/s HBM peak
+  cpu_baseline      the NumPy/SciPy restatement of the reference (oracle/vbx_oracle.py) on the
+                    host cores, bounded sample (rank 0, N=1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+# algorithmic HBM bytes per recording per launch (8*T*R + 28*T*S per iteration,
+# split over the kernels that own each pass; fp32 storage = 4 bytes, fp64 = 8)
+ALGO_PASSES = {            # kernel -> (passes over T x R, passes over T x S)
+    'mstep_acc': (1, 1),   # rho read, gamma read
+    'loglik': (1, 1),      # rho read, b write
+    'fb': (0, 3),          # b read by forward and by backward, ahat write
+    'post': (0, 2),        # ahat read, gamma write
+}
+
+
+def algo_bytes(kernel, T, R, S, esize):
+    pr, ps = ALGO_PASSES[kernel]
+    return esize * (pr * T * R + ps * T * S)
+
+
+def make_batch(ctx, n_rec, T, S, D, precision, seed0, max_iters):
+    from vbx_amd import _capi
+    from vbx_amd.synth import make_recording
+    batch = _capi.Batch(ctx, [T] * n_rec, [S] * n_rec, D, precision=precision, max_iters=max_iters)
+    for b in range(n_rec):
+        X, Phi, _ = make_recording(T, S, D=D, seed=seed0 + b, kappa=0.05, dtype=np.float32)
+        g = np.random.default_rng(10_000 + seed0 + b).gamma(1.0, size=(T, S))
+        g /= g.sum(1, keepdims=True)
+        batch.set_recording(b, X, Phi, np.ones(S) / S, g, 0.99, 0.3, 17.0)
+    return batch
+
+
+def cpu_baseline(T, S, D, iters):
+    """oracle (kind="port"): same algorithm and third-party calls as the reference's VBx.py."""
+    from oracle import vbx_oracle
+    from vbx_amd.synth import make_recording
+    X, Phi, _ = make_recording(T, S, D=D, seed=0, kappa=0.05)
+    g = np.random.default_rng(10_000).gamma(1.0, size=(T, S))
+    g /= g.sum(1, keepdims=True)
+    t0 = time.perf_counter()
+    vbx_oracle.VBx(X, Phi, loopProb=0.99, Fa=0.3, Fb=17.0, pi=S, gamma=g, maxIters=iters, epsilon=-1e300)
+    dt = time.perf_counter() - t0
+    return {'value': iters / dt, 'unit': 'EM iterations/s', 'cores': 1, 'kind': 'port',
+            'sample': f'{iters} iterations of one recording T={T} S={S} R={D} (float64, NumPy+SciPy logsumexp, '
+                      f'{dt:.1f} s on {os.cpu_count()} visible cores; the path is single-threaded)'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=8, help='recordings per GPU')
+    ap.add_argument('--T', type=int, default=10000)
+    ap.add_argument('--S', type=int, default=30)
+    ap.add_argument('--D', type=int, default=128)
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'fp64'])
+    ap.add_argument('--cpu-iters', type=int, default=6, help='oracle iterations for cpu_baseline (0 = skip)')
+    ap.add_argument('--no-single', action='store_true', help='skip the batch=1 latency measurement')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+
+    import torch
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+
+    from vbx_amd import _capi
+    ctx = _capi.Context(local_rank)
+    info = ctx.device_info()
+    esize = 4 if args.precision == 'fp32' else 8
+    K, W = args.steps, args.warmup
+
+    batch = make_batch(ctx, args.batch, args.T, args.S, args.D, args.precision, seed0=rank * args.batch,
+                       max_iters=K + W)
+    batch.set_option(_capi.OPT_PROFILE, 1)        # HIP events around every launch of the timed region
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    batch.run(W, -np.inf)
+    barrier()
+    t0 = time.perf_counter()
+    batch.run(K, -np.inf)                          # returns after the stream has drained
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    dev_ms, launched = batch.last_run_ms()
+    ktimes = batch.kernel_times()
+    assert launched == K
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # the same K steps without per-kernel events (reported beside the contract number)
+    batch.close()
+    batch2 = make_batch(ctx, args.batch, args.T, args.S, args.D, args.precision, seed0=rank * args.batch,
+                        max_iters=K + W)
+    batch2.run(W, -np.inf)
+    barrier()
+    t0 = time.perf_counter()
+    batch2.run(K, -np.inf)
+    torch.cuda.synchronize()
+    elapsed_plain = time.perf_counter() - t0
+    barrier()
+    res0 = batch2.result(0, want_model=False)
+    batch2.close()
+
+    single = None
+    if not args.no_single and rank == 0:
+        b1 = make_batch(ctx, 1, args.T, args.S, args.D, args.precision, seed0=0, max_iters=K + W)
+        b1.run(W, -np.inf)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        b1.run(K, -np.inf)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        single = {'value': K / dt, 'unit': 'EM iterations/s', 'ms_per_iteration': 1e3 * dt / K, 'batch': 1}
+        b1.close()
+
+    if rank == 0:
+        total_units = world * args.batch * K
+        per_kernel = {k: {'avg_us': 1e3 * ms / n, 'launches': n} for k, (ms, n) in ktimes.items() if n}
+        dom = max((k for k in per_kernel if k in ALGO_PASSES), key=lambda k: per_kernel[k]['avg_us'])
+        dom_bytes = args.batch * algo_bytes(dom, args.T, args.D, args.S, esize)
+        achieved = dom_bytes / (per_kernel[dom]['avg_us'] * 1e-6) / 1e9
+        out = {
+            'metric': 'VB EM iterations/sec (T=10k xvecs, R=128, S=30)',
+            'value': total_units / elapsed,
+            'unit': 'recording-EM-iterations/s',
+            'n_gpus': world,
+            'steps': K,
+            'warmup': W,
+            'ms_per_step': 1e3 * elapsed / K,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32' if args.precision == 'fp32' else 'f64',
+            'data': 'synthetic',
+            'config': {'workload': f'batch of {args.batch} recordings per GPU, each T={args.T} x-vectors, '
+                                   f'R={args.D}, S={args.S} (BASELINE configs[3] shard; headline shape), '
+                                   'random gamma init, Fa=0.3 Fb=17 loopProb=0.99',
+                       'recordings_per_gpu': args.batch, 'T': args.T, 'R': args.D, 'S': args.S,
+                       'parallelism': f'recordings sharded over {world} rank(s), no data-path collective'},
+            'value_without_kernel_events': world * args.batch * K / elapsed_plain,
+            'device_ms_per_step': dev_ms / K,
+            'device': info['name'],
+            'kernels_avg_us': {k: round(v['avg_us'], 2) for k, v in per_kernel.items()},
+            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'algorithmic_bytes_per_launch': dom_bytes,
+                         'avg_launch_us': per_kernel[dom]['avg_us']},
+            'gamma_checks': {'row_sum_max_dev': float(np.abs(res0['gamma'].sum(1) - 1).max()),
+                             'elbo_last': float(res0['Li'][-1])},
+        }
+        whole = args.batch * (8 * args.T * args.D + 28 * args.T * args.S) * (esize / 4)
+        out['roofline_whole_iteration'] = {'algorithmic_bytes_per_step': whole,
+                                           'achieved_GBs': whole / (dev_ms / K * 1e-3) / 1e9,
+                                           'frac_of_hbm_peak': whole / (dev_ms / K * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if single:
+            out['single_recording'] = single
+        if world == 1 and args.cpu_iters > 0:
+            cb = cpu_baseline(args.T, args.S, args.D, args.cpu_iters)
+            out['cpu_baseline'] = cb
+            if single:
+                out['single_recording']['speedup_vs_cpu_baseline'] = single['value'] / cb['value']
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

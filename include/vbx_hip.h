@@ -1,0 +1,180 @@
+/*
+ * vbx_hip.h -- C ABI of libvbx_hip.so, the MI355X (gfx950) implementation of the VBx
+ * variational-Bayes HMM E/M loop.
+ *
+ * The reference has no FFI: the path is the pure-Python function
+ *     VBx(X, Phi, loopProb, Fa, Fb, pi, gamma, maxIters, epsilon, alphaQInit, ref, plot,
+ *         return_model, alpha, invL) -> (gamma, pi, Li[, alpha, invL])
+ * at /root/reference/VBx/VBx.py:27-126, called from /root/reference/VBx/vbhmm.py:154-158.
+ * The entry points below are what a ctypes binding for that function binds; the Python
+ * mirror of the reference interface (vbx_amd/VBx.py) is a thin marshalling layer on top.
+ * INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns 0 on success or a negative
+ *     VBX_ERR_* code and never throws; vbx_last_error() gives the message.
+ *   - the caller owns every host buffer; inputs are read-only; outputs are written
+ *     into caller-allocated arrays.  Device memory is owned by the ctx / batch objects.
+ *   - matrices are C-contiguous row-major, exactly as NumPy hands them over:
+ *     X[T][D], gamma[T][S] (frames x speakers, VBx.py:82,85), alpha/invL[S][D].
+ *   - a ctx is bound to one device and one HIP stream; not thread-safe per ctx.
+ *   - "recording" = one x-vector sequence = one VBx() call in the reference.
+ */
+#ifndef VBX_HIP_H
+#define VBX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VBX_ABI_VERSION 1
+
+/* error codes */
+#define VBX_OK 0
+#define VBX_ERR_INVALID (-1)     /* bad argument (shape, NULL, range)                      */
+#define VBX_ERR_UNSUPPORTED (-2) /* e.g. S > VBX_MAX_SPEAKERS                              */
+#define VBX_ERR_HIP (-3)         /* a HIP runtime call failed; see vbx_last_error          */
+#define VBX_ERR_NO_DEVICE (-4)   /* no gfx950-class GPU visible                            */
+#define VBX_ERR_STATE (-5)       /* call order violated (run before every recording is set) */
+
+#define VBX_MAX_SPEAKERS 256
+
+/* element types of caller buffers */
+#define VBX_F32 0
+#define VBX_F64 1
+
+/* arithmetic of the device path (bench.py "dtype") */
+#define VBX_PREC_FP32 0 /* f32 storage + f32 MFMA; f64 for every reduction over T and the ELBO */
+#define VBX_PREC_FP64 1 /* f64 storage + f64 MFMA; matches the reference's iteration count   */
+
+/* forward-backward algorithm selector (vbx_batch_set_option VBX_OPT_FB_ALGO) */
+#define VBX_FB_AUTO 0
+#define VBX_FB_SEQUENTIAL 1 /* one wavefront per direction walks all T frames           */
+#define VBX_FB_CHUNKED 2    /* exact chunked parallel scan over T (transfer operators)   */
+
+/* options for vbx_batch_set_option */
+#define VBX_OPT_FB_ALGO 1
+#define VBX_OPT_CHECK_EVERY 2   /* iterations launched between two convergence polls (default 4) */
+#define VBX_OPT_PROFILE 3       /* 1: bracket every kernel launch with HIP events              */
+#define VBX_OPT_CHUNK_FRAMES 4  /* frames per scan chunk for VBX_FB_CHUNKED (0 = auto)         */
+
+typedef struct vbx_ctx vbx_ctx;
+typedef struct vbx_batch vbx_batch;
+
+/* kernel classes reported by vbx_batch_kernel_times (one slot per HIP kernel) */
+enum {
+    VBX_K_PREP = 0,       /* rho = X*sqrt(Phi), sum_t G_t            VBx.py:87-89  */
+    VBX_K_MSTEP_ACC = 1,  /* gamma^T rho partial sums (MFMA)         VBx.py:96     */
+    VBX_K_MSTEP_FIN = 2,  /* invL, alpha, per-speaker bias           VBx.py:95-97  */
+    VBX_K_LOGLIK = 3,     /* rho alpha^T + bias, row max, exp (MFMA) VBx.py:97     */
+    VBX_K_FB = 4,         /* forward-backward recursion              VBx.py:146-175 */
+    VBX_K_FB_AUX = 5,     /* chunk-boundary propagation (chunked scan only)         */
+    VBX_K_POST = 6,       /* gamma, pi statistics                    VBx.py:101-103,174 */
+    VBX_K_ITER_FIN = 7,   /* ELBO, pi update, convergence test       VBx.py:100-105,122-125 */
+    VBX_K_COUNT = 8
+};
+
+int vbx_abi_version(void);
+
+/* ---- context -------------------------------------------------------------------- */
+int vbx_create(vbx_ctx** out, int device);
+int vbx_destroy(vbx_ctx* ctx);
+/* message of the last failure on this ctx (ctx == NULL: last failure of vbx_create). */
+const char* vbx_last_error(const vbx_ctx* ctx);
+/* device name (NUL-terminated, truncated to cap), compute units, HBM bytes. */
+int vbx_device_info(vbx_ctx* ctx, char* name, int cap, int* compute_units, int64_t* hbm_bytes);
+
+/* ---- batch of recordings resident in HBM -------------------------------------------
+ * T[b] frames, S[b] speakers (HMM states) per recording, common feature dim D.
+ * max_iters bounds the ELBO history kept on the device. */
+int vbx_batch_create(vbx_ctx* ctx, int n_rec, const int64_t* T, const int32_t* S, int32_t D,
+                     int precision, int max_iters, vbx_batch** out);
+int vbx_batch_destroy(vbx_batch* batch);
+int vbx_batch_set_option(vbx_batch* batch, int option, int64_t value);
+
+/* Upload one recording and its hyper-parameters; computes rho and sum_t G_t on the device.
+ *   X      [T][D]  x_dtype            (VBx.py:27 "X")
+ *   Phi    [D]     f64                (VBx.py:27 "Phi")
+ *   pi0    [S]     f64                (VBx.py:76-77; the caller expands an int pi to ones/pi)
+ *   gamma0 [T][S]  g_dtype            (VBx.py:79-85; the caller draws the RNG init)
+ *   alpha0, invL0 [S][D] f64 or both NULL (VBx.py:94: skip the first M-step when given)  */
+int vbx_batch_set_recording(vbx_batch* batch, int b, const void* X, int x_dtype, const double* Phi,
+                            const double* pi0, const void* gamma0, int g_dtype,
+                            const double* alpha0, const double* invL0, double loopProb, double Fa,
+                            double Fb);
+
+/* Run up to max_iters VB iterations on every recording (VBx.py:91-125).  A recording
+ * stops on its own when ii > 0 and ELBO - previous < epsilon (VBx.py:122-125); its state
+ * is frozen from then on.  Returns after the device work has completed. */
+int vbx_batch_run(vbx_batch* batch, int max_iters, double epsilon);
+
+/* Results of recording b.  Any pointer may be NULL to skip that output.
+ *   gamma [T][S] f64, pi [S] f64, Li [n_iters] f64 (ELBO per iteration, VBx.py:105),
+ *   n_iters, warned (1 iff the last ELBO step was negative: the reference prints
+ *   'WARNING: Value of auxiliary function has decreased!', VBx.py:123-124),
+ *   alpha/invL [S][D] f64 (VBx.py:126 return_model). */
+int vbx_batch_get_result(vbx_batch* batch, int b, double* gamma, double* pi, double* Li, int li_cap,
+                         int* n_iters, int* warned, double* alpha, double* invL);
+
+/* Wall time of the last vbx_batch_run measured with HIP events on the batch's stream
+ * (ms), and the number of iterations that were launched. */
+int vbx_batch_last_run_ms(vbx_batch* batch, double* total_ms, int* iters_launched);
+/* With VBX_OPT_PROFILE=1: summed HIP-event time (ms) and launch count per kernel class
+ * for the last run; arrays of VBX_K_COUNT entries. */
+int vbx_batch_kernel_times(vbx_batch* batch, double* ms, int64_t* launches);
+
+/* ---- one-shot: a single recording, host buffers in / out (= one reference VBx call) ---- */
+typedef struct {
+    int64_t T;
+    int32_t D, S;
+    const void* X;        /* [T][D] */
+    int32_t x_dtype;      /* VBX_F32 / VBX_F64 */
+    const double* Phi;    /* [D] */
+    const double* pi0;    /* [S] */
+    const void* gamma0;   /* [T][S] */
+    int32_t g_dtype;
+    const double* alpha0; /* [S][D] or NULL */
+    const double* invL0;  /* [S][D] or NULL */
+    double loopProb, Fa, Fb;
+    int32_t max_iters;
+    double epsilon;
+    int32_t precision;    /* VBX_PREC_* */
+    int32_t fb_algo;      /* VBX_FB_* */
+} vbx_problem;
+
+typedef struct {
+    double* gamma;   /* [T][S] */
+    double* pi;      /* [S] */
+    double* Li;      /* [max_iters] */
+    double* alpha;   /* [S][D] or NULL */
+    double* invL;    /* [S][D] or NULL */
+    int32_t n_iters;
+    int32_t warned;
+    double run_ms;   /* device time of the iteration loop */
+} vbx_result;
+
+int vbx_run(vbx_ctx* ctx, const vbx_problem* problem, vbx_result* result);
+
+/* ---- step-level entry points (used by the parity tests) ------------------------------
+ * forward_backward (VBx.py:146-175) for transition matrices of the form VBx.py:98 builds,
+ *   tr = I*loopProb + (1-loopProb)*pi      (every column j constant off the diagonal),
+ * and initial-state probabilities ip (NULL: ip = pi, as VBx.py:99 passes them).
+ *   lls [T][S] f64, pi [S], ip [S]  ->  gamma [T][S], tll, entered [S], lfw [T][S], lbw [T][S]
+ * entered[j] = sum_{t>=1} exp(LSE_i lfw[t-1,i] + lls[t,j] + lbw[t,j] - tll) is the statistic
+ * of VBx.py:101-103.  Any output pointer may be NULL. */
+int vbx_forward_backward(vbx_ctx* ctx, int64_t T, int32_t S, const double* lls, const double* pi,
+                         const double* ip, double loopProb, int precision, int fb_algo, double* gamma,
+                         double* tll, double* entered, double* lfw, double* lbw);
+/* M-step (VBx.py:95-96): gamma [T][S], X [T][D], Phi [D] -> alpha, invL [S][D]. */
+int vbx_mstep(vbx_ctx* ctx, int64_t T, int32_t S, int32_t D, const double* X, const double* Phi,
+              const double* gamma, double Fa, double Fb, int precision, double* alpha, double* invL);
+/* per-frame log-likelihoods (VBx.py:97): X, Phi, alpha, invL -> log_p [T][S] (G included). */
+int vbx_loglik(vbx_ctx* ctx, int64_t T, int32_t S, int32_t D, const double* X, const double* Phi,
+               const double* alpha, const double* invL, double Fa, int precision, double* log_p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VBX_HIP_H */

@@ -1,0 +1,294 @@
+"""GPU parity tests: the HIP path (through the C ABI / ctypes) against the CPU oracle and the
+golden fixtures generated from the reference.  Tolerances: fp64 device path ~1e-7; fp32 device
+path 1e-4 (BASELINE.json north_star: "within 1e-4 relative on fp32")."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+from golden_util import case_inputs
+
+pytestmark = pytest.mark.gpu
+
+FP32_TOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from vbx_amd import _capi
+    return _capi.default_context(0)
+
+
+def _orc():
+    from oracle import vbx_oracle
+    return vbx_oracle
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) / (np.abs(b) + 1e-300))) if a.size else 0.0
+
+
+# ------------------------------------------------------------------------------------ steps
+@pytest.mark.parametrize('precision,tol', [('fp64', 1e-11), ('fp32', 2e-5)])
+@pytest.mark.parametrize('T,S,D', [(300, 7, 128), (1000, 30, 128), (257, 50, 128), (130, 70, 64), (40, 3, 100)])
+def test_mstep_matches_oracle(ctx, precision, tol, T, S, D):
+    rng = np.random.default_rng(T + S)
+    X = rng.standard_normal((T, D))
+    Phi = np.sort(rng.uniform(0.5, 6.0, D))[::-1].copy()
+    gamma = rng.gamma(1.0, size=(T, S))
+    gamma /= gamma.sum(1, keepdims=True)
+    alpha, invL = ctx.mstep(X, Phi, gamma, 0.3, 17.0, precision=precision)
+    G, rho = _orc().frame_constants(X, Phi)
+    a_ref, i_ref = _orc().speaker_model(gamma, rho, Phi, 0.3, 17.0)
+    np.testing.assert_allclose(invL, i_ref, rtol=max(tol, 1e-7 if precision == 'fp32' else 0))
+    np.testing.assert_allclose(alpha, a_ref, rtol=0, atol=tol * np.abs(a_ref).max())
+
+
+@pytest.mark.parametrize('precision,tol', [('fp64', 1e-10), ('fp32', 3e-5)])
+@pytest.mark.parametrize('T,S,D', [(300, 7, 128), (1000, 30, 128), (257, 50, 128), (130, 70, 64), (40, 3, 100)])
+def test_loglik_matches_oracle(ctx, precision, tol, T, S, D):
+    rng = np.random.default_rng(T * 3 + S)
+    X = rng.standard_normal((T, D))
+    Phi = np.sort(rng.uniform(0.5, 6.0, D))[::-1].copy()
+    gamma = rng.gamma(0.3, size=(T, S)) + 1e-3
+    gamma /= gamma.sum(1, keepdims=True)
+    G, rho = _orc().frame_constants(X, Phi)
+    alpha, invL = _orc().speaker_model(gamma, rho, Phi, 0.3, 17.0)
+    got = ctx.loglik(X, Phi, alpha, invL, 0.3, precision=precision)
+    want = _orc().frame_loglik(rho, alpha, invL, Phi, G, 0.3)
+    # asymmetric check: a transposed or row/column-permuted tile would fail this
+    scale = np.abs(want - want.mean()).max()
+    np.testing.assert_allclose(got, want, rtol=0, atol=tol * max(scale, 1.0))
+
+
+@pytest.mark.parametrize('precision', ['fp64', 'fp32'])
+def test_forward_backward_known_answers(ctx, fb_cases, precision):
+    tol = 1e-9 if precision == 'fp64' else 2e-5
+    for name, c in fb_cases.items():
+        lp = float(c['loopProb'])
+        gamma, tll, entered, lfw, lbw = ctx.forward_backward(c['lls'], c['pi'], lp, precision=precision,
+                                                             want_logs=True)
+        np.testing.assert_allclose(gamma, c['post'], rtol=0, atol=tol, err_msg=name)
+        np.testing.assert_allclose(tll, c['tll'], rtol=1e-11 if precision == 'fp64' else 2e-6, err_msg=name)
+        _, _, ent_ref = _orc().fb_linear(c['lls'], c['pi'], lp)
+        np.testing.assert_allclose(entered, ent_ref, rtol=tol * 100, atol=tol * 10, err_msg=name)
+        ltol = 1e-8 if precision == 'fp64' else 2e-3
+        fin = np.isfinite(c['lfw']) & (c['post'] > 1e-30)
+        np.testing.assert_allclose(lfw[fin], c['lfw'][fin], rtol=0, atol=ltol * 10, err_msg=name)
+        np.testing.assert_allclose(lbw[fin], c['lbw'][fin], rtol=0, atol=ltol * 10, err_msg=name)
+
+
+def test_module_level_forward_backward(fb_cases):
+    import vbx_amd
+    c = fb_cases['fb_T257_S31']
+    lp, S = float(c['loopProb']), len(c['pi'])
+    tr = np.eye(S) * lp + (1 - lp) * c['pi']
+    post, tll, lfw, lbw = vbx_amd.forward_backward(c['lls'], tr, c['pi'])
+    np.testing.assert_allclose(post, c['post'], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(tll, c['tll'], rtol=1e-11)
+    with pytest.raises(NotImplementedError):
+        vbx_amd.forward_backward(c['lls'], np.random.default_rng(0).random((S, S)), c['pi'])
+
+
+# ------------------------------------------------------------------------------------ VBx()
+def run_case(c, precision):
+    import vbx_amd
+    X, Phi, kw = case_inputs(c)
+    Xc, Pc = X.copy(), Phi.copy()
+    gc = None if kw['gamma'] is None else kw['gamma'].copy()
+    if 'np_seed' in c:
+        np.random.seed(int(c['np_seed']))
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        out = vbx_amd.VBx(X, Phi, return_model=True, precision=precision, **kw)
+    assert np.array_equal(X, Xc) and np.array_equal(Phi, Pc), 'inputs were mutated'
+    if gc is not None:
+        assert np.array_equal(kw['gamma'], gc), 'gamma input was mutated'
+    return out, 'WARNING' in buf.getvalue()
+
+
+def test_vbx_fp64_matches_reference_on_every_golden_case(synth_cases):
+    for name, c in synth_cases.items():
+        (gamma, pi, Li, alpha, invL), warned = run_case(c, 'fp64')
+        assert len(Li) == len(c['Li']), (name, len(Li), len(c['Li']))
+        assert gamma.dtype == np.float64 and gamma.shape == c['gamma'].shape
+        np.testing.assert_allclose(gamma, c['gamma'], rtol=0, atol=2e-7, err_msg=name)
+        np.testing.assert_allclose(pi, c['pi'], rtol=0, atol=2e-8, err_msg=name)
+        if len(Li):
+            np.testing.assert_allclose([r[0] for r in Li], c['Li'], rtol=1e-10, err_msg=name)
+            np.testing.assert_allclose(alpha, c['alpha'], rtol=0, atol=1e-7 * np.abs(c['alpha']).max(), err_msg=name)
+            np.testing.assert_allclose(invL, c['invL'], rtol=1e-7, err_msg=name)
+        assert warned == bool(c['warned']), name
+
+
+def test_vbx_fp32_within_1e4_on_fixed_iteration_cases(synth_cases):
+    checked = 0
+    for name, c in synth_cases.items():
+        if float(c.get('kw_epsilon', 0)) > -1e299 or 'kw_maxIters' not in c or int(c['kw_maxIters']) == 0:
+            continue                      # early-stopping cases are covered by the fp64 path
+        (gamma, pi, Li, alpha, invL), _ = run_case(c, 'fp32')
+        assert len(Li) == len(c['Li']), name
+        assert np.abs(gamma - c['gamma']).max() <= FP32_TOL, (name, np.abs(gamma - c['gamma']).max())
+        assert np.abs(pi - c['pi']).max() <= FP32_TOL, name
+        assert rel_err([r[0] for r in Li], c['Li']) <= FP32_TOL, name
+        assert np.abs(alpha - c['alpha']).max() <= FP32_TOL * max(1.0, np.abs(c['alpha']).max()), name
+        assert rel_err(invL, c['invL']) <= FP32_TOL, name
+        checked += 1
+    assert checked >= 9
+
+
+def _segments(labels, seg_times):
+    """argmax labels -> merged segments, as vbhmm.py:160-172 + diarization_lib.merge_adjacent_labels do."""
+    starts, ends = seg_times[:, 0].copy(), seg_times[:, 1].copy()
+    adjacent = np.logical_or(np.isclose(ends[:-1], starts[1:]), ends[:-1] > starts[1:])
+    split = np.nonzero(np.logical_or(~adjacent, labels[1:] != labels[:-1]))[0]
+    s = starts[np.r_[0, split + 1]]
+    e = ends[np.r_[split, -1]]
+    lab = labels[np.r_[0, split + 1]]
+    ov = np.nonzero(s[1:] < e[:-1])[0]
+    e[ov] = s[ov + 1] = (e[ov] + s[ov + 1]) / 2.0
+    return s, e, lab
+
+
+@pytest.mark.parametrize('precision', ['fp64', 'fp32'])
+def test_es2005a_end_to_end(es2005a, precision):
+    """The reference's only end-to-end example: same call as vbhmm.py:154-158."""
+    import vbx_amd
+    g = es2005a
+    X = g['fea'] if precision == 'fp64' else g['fea'].astype(np.float32)
+    q, sp, L = vbx_amd.VBx(X, g['Phi'], pi=int(g['qinit'].shape[1]), gamma=g['qinit'], maxIters=40, epsilon=1e-6,
+                           loopProb=float(g['loopProb']), Fa=float(g['Fa']), Fb=float(g['Fb']), precision=precision)
+    assert q.dtype == np.float64 and q.shape == g['gamma40'].shape
+    if precision == 'fp64':
+        assert len(L) == 13
+        np.testing.assert_allclose([r[0] for r in L], g['Li40'], rtol=1e-11)
+        np.testing.assert_allclose(q, g['gamma40'], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(sp, g['pi40'], rtol=0, atol=1e-8)
+    else:
+        n = min(len(L), len(g['Li40']))
+        assert rel_err([r[0] for r in L][:n], g['Li40'][:n]) < 1e-6
+        assert np.abs(q - g['gamma40']).max() <= FP32_TOL
+        assert np.abs(sp - g['pi40']).max() <= FP32_TOL
+    labels = np.argsort(-q, axis=1)[:, 0]                                # vbhmm.py:160
+    s, e, lab = _segments(labels, g['seg_times'])
+    want = g['rttm_committed']                                           # exp/ES2005a.rttm
+    assert len(s) == len(want) == 50
+    np.testing.assert_allclose(s, want[:, 0], atol=1e-5)
+    np.testing.assert_allclose(e - s, want[:, 1], atol=1e-5)
+    mapping = {}
+    for mine, theirs in zip(lab + 1, want[:, 2].astype(int)):            # labels up to a bijection
+        assert mapping.setdefault(int(mine), int(theirs)) == int(theirs)
+    assert len(set(mapping.values())) == len(mapping) == 5
+
+
+def test_reference_error_behaviour():
+    import vbx_amd
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((20, 128))
+    Phi = np.ones(128)
+    with pytest.raises(AssertionError):                                  # VBx.py:85
+        vbx_amd.VBx(X, Phi, pi=4, gamma=np.full((20, 5), 0.2))
+    with pytest.raises(TypeError):                                       # VBx.py:76 -> len(np.int64)
+        vbx_amd.VBx(X, Phi, pi=np.int64(4))
+    g0 = np.full((20, 4), 0.25)
+    gamma, pi, Li = vbx_amd.VBx(X, Phi, pi=4, gamma=g0, maxIters=0)
+    assert gamma is g0 and Li == [] and np.allclose(pi, 0.25)
+    out = vbx_amd.VBx(X.astype(np.float32), Phi, pi=4, gamma=g0, maxIters=2)
+    assert out[0].dtype == np.float64 and out[1].dtype == np.float64     # float64 out, as under NumPy 2
+    from vbx_amd import _capi
+    with pytest.raises(_capi.VbxError):
+        vbx_amd.VBx(rng.standard_normal((10, 16)), np.ones(16), pi=300, gamma=np.full((10, 300), 1 / 300))
+
+
+def test_ref_labels_give_der_columns(synth_cases):
+    import vbx_amd
+    c = synth_cases['soft_T600_S12']
+    X, Phi, kw = case_inputs(c)
+    from vbx_amd.synth import make_recording
+    _, _, labels = make_recording(600, 12, seed=3, kappa=0.05)
+    kw['maxIters'] = 4
+    gamma, pi, Li = vbx_amd.VBx(X, Phi, ref=labels, **kw)
+    gr, pr, Lr = _orc().VBx(X, Phi, ref=labels, **kw)
+    assert len(Li) == len(Lr) == 4 and all(len(r) == 3 for r in Li)
+    np.testing.assert_allclose(np.array(Li), np.array(Lr), rtol=1e-7, atol=1e-9)
+
+
+# ------------------------------------------------------------------------------------ batches
+def test_ragged_batch_equals_individual_runs(ctx):
+    from vbx_amd import _capi
+    from vbx_amd.synth import make_recording
+    shapes = [(700, 9), (129, 4), (1, 3), (1500, 14), (128, 16)]
+    recs = []
+    for k, (T, S) in enumerate(shapes):
+        X, Phi, _ = make_recording(T, S, seed=40 + k, kappa=0.1)
+        r = np.random.default_rng(k)
+        g = r.gamma(1.0, size=(T, S))
+        recs.append((X, Phi, g / g.sum(1, keepdims=True)))
+    for precision, tol in (('fp64', 1e-9), ('fp32', 2e-5)):
+        batch = _capi.Batch(ctx, [s[0] for s in shapes], [s[1] for s in shapes], 128, precision=precision, max_iters=6)
+        for k, (X, Phi, g) in enumerate(recs):
+            batch.set_recording(k, X, Phi, np.ones(shapes[k][1]) / shapes[k][1], g, 0.9, 0.3, 17.0)
+        batch.run(6, -np.inf)
+        for k, (X, Phi, g) in enumerate(recs):
+            res = batch.result(k)
+            gr, pr, Lr = _orc().VBx(X, Phi, loopProb=0.9, Fa=0.3, Fb=17.0, pi=shapes[k][1], gamma=g, maxIters=6,
+                                    epsilon=-1e300)
+            assert np.abs(res['gamma'] - gr).max() < max(tol, 1e-8) * 5, (precision, k)
+            assert rel_err(res['Li'], [r[0] for r in Lr]) < max(tol, 1e-10), (precision, k)
+        batch.close()
+
+
+def test_early_stop_is_per_recording(ctx):
+    """One recording converges early, the other keeps iterating; the converged one is frozen."""
+    from vbx_amd import _capi
+    from vbx_amd.synth import make_recording
+    Xa, Phi, _ = make_recording(450, 9, seed=14, kappa=0.3)
+    Xb, _, _ = make_recording(600, 12, seed=3, kappa=0.05)
+    r = np.random.default_rng(20)
+    ga = r.gamma(1.0, size=(450, 9)); ga /= ga.sum(1, keepdims=True)
+    gb = np.random.default_rng(11).gamma(1.0, size=(600, 12)); gb /= gb.sum(1, keepdims=True)
+    batch = _capi.Batch(ctx, [450, 600], [9, 12], 128, precision='fp64', max_iters=30)
+    batch.set_recording(0, Xa, Phi, np.ones(9) / 9, ga, 0.9, 0.3, 17.0)
+    batch.set_recording(1, Xb, Phi, np.ones(12) / 12, gb, 0.9, 0.3, 17.0)
+    batch.run(30, 1e-4)
+    for k, (X, g, S) in enumerate(((Xa, ga, 9), (Xb, gb, 12))):
+        gr, pr, Lr = _orc().VBx(X, Phi, loopProb=0.9, Fa=0.3, Fb=17.0, pi=S, gamma=g, maxIters=30, epsilon=1e-4)
+        res = batch.result(k)
+        assert res['n_iters'] == len(Lr), (k, res['n_iters'], len(Lr))
+        np.testing.assert_allclose(res['gamma'], gr, rtol=0, atol=1e-7)
+    batch.close()
+
+
+# ------------------------------------------------------------------------------------ full size
+def test_headline_size_properties_and_oracle_agreement(ctx):
+    """T=10 000, R=128, S=30 (BASELINE.json metric): oracle agreement for the first iterations and
+    size-independent invariants (rows of gamma and pi sum to one, ELBO never decreases)."""
+    from vbx_amd import _capi
+    from vbx_amd.synth import make_recording
+    T, S = 10000, 30
+    X, Phi, _ = make_recording(T, S, seed=0, kappa=0.05)
+    g0 = np.random.default_rng(1).gamma(1.0, size=(T, S))
+    g0 /= g0.sum(1, keepdims=True)
+    gr, pr, Lr = _orc().VBx(X, Phi, loopProb=0.99, Fa=0.3, Fb=17.0, pi=S, gamma=g0, maxIters=2, epsilon=-1e300)
+    outs = {}
+    for precision in ('fp64', 'fp32'):
+        batch = _capi.Batch(ctx, [T], [S], 128, precision=precision, max_iters=12)
+        batch.set_recording(0, X, Phi, np.ones(S) / S, g0, 0.99, 0.3, 17.0)
+        batch.run(2, -np.inf)
+        res = batch.result(0)
+        tol = 1e-7 if precision == 'fp64' else FP32_TOL
+        assert np.abs(res['gamma'] - gr).max() <= tol, precision
+        assert rel_err(res['Li'], [r[0] for r in Lr]) <= (1e-10 if precision == 'fp64' else 1e-6)
+        batch.run(10, -np.inf)
+        res = batch.result(0)
+        outs[precision] = res
+        np.testing.assert_allclose(res['gamma'].sum(1), 1.0, atol=1e-5)
+        np.testing.assert_allclose(res['pi'].sum(), 1.0, atol=1e-9)
+        assert res['gamma'].min() >= 0.0
+        d = np.diff(res['Li'])
+        assert np.all(d > (-1e-6 if precision == 'fp64' else -0.5)), (precision, d)
+        batch.close()
+    assert np.abs(outs['fp32']['gamma'] - outs['fp64']['gamma']).max() <= FP32_TOL
+    assert rel_err(outs['fp32']['Li'], outs['fp64']['Li']) <= 1e-6

@@ -1,0 +1,126 @@
+"""CPU-only checks: the C-ABI library builds, loads and exports every declared symbol; the
+host-side mirror reproduces the reference's argument handling; the product path refuses to
+run without a GPU instead of silently falling back to anything."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(REPO, 'include', 'vbx_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(vbx_[a-z_0-9]+)\s*\(', text)))
+
+
+def test_library_builds_and_exports_the_declared_abi():
+    from vbx_amd import _capi, build
+    path = build.build()
+    assert os.path.exists(path)
+    lib = _capi.load()
+    assert lib.vbx_abi_version() == 1
+    syms = declared_symbols()
+    assert set(syms) == set(_capi.ABI_SYMBOLS), set(syms) ^ set(_capi.ABI_SYMBOLS)
+    exported = subprocess.run(['nm', '-D', '--defined-only', path], capture_output=True, text=True).stdout
+    for s in syms:
+        assert re.search(rf'\bT {s}\b', exported), f'{s} is declared in include/vbx_hip.h but not exported'
+
+
+def test_code_object_is_gfx950_and_uses_mfma_and_dpp():
+    from vbx_amd import build
+    path = build.build()
+    blob = open(path, 'rb').read()
+    assert b'gfx950' in blob
+    objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+    if not os.path.exists(objdump):
+        pytest.skip('llvm-objdump not available')
+    # the device code object sits in the .hip_fatbin section of the shared object
+    import tempfile
+    llvm = os.path.dirname(objdump)
+    with tempfile.TemporaryDirectory() as tmp:
+        subprocess.run([f'{llvm}/llvm-objcopy', '--dump-section', f'.hip_fatbin={tmp}/fat.bin', path],
+                       capture_output=True)
+        subprocess.run([f'{llvm}/clang-offload-bundler', '--unbundle', '--type=o',
+                        '--targets=hipv4-amdgcn-amd-amdhsa--gfx950', f'--input={tmp}/fat.bin',
+                        f'--output={tmp}/dev.co'], capture_output=True)
+        if not os.path.exists(f'{tmp}/dev.co'):
+            pytest.skip('could not unbundle the device code object')
+        dis = subprocess.run([objdump, '-d', f'{tmp}/dev.co'], capture_output=True, text=True).stdout
+    assert 'v_mfma_f32_16x16x4_f32' in dis or 'v_mfma_f32_16x16x4f32' in dis
+    assert 'v_mfma_f64_16x16x4_f64' in dis or 'v_mfma_f64_16x16x4f64' in dis
+    assert 'row_mirror' in dis and 'quad_perm' in dis
+
+
+def test_no_gpu_means_a_loud_error_not_a_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is present')
+    import vbx_amd
+    from vbx_amd import _capi
+    X = np.random.default_rng(0).standard_normal((10, 16))
+    with pytest.raises(_capi.VbxError):
+        vbx_amd.VBx(X, np.ones(16), pi=3, gamma=np.full((10, 3), 1 / 3), maxIters=2)
+
+
+def test_product_code_never_imports_the_oracle():
+    for root, _, files in os.walk(os.path.join(REPO, 'vbx_amd')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.hpp', '.h')):
+                src = open(os.path.join(root, f)).read()
+                assert 'oracle' not in src.replace('the oracle here', ''), f
+    assert 'oracle' not in open(os.path.join(REPO, 'vbx_drop_in', 'VBx.py')).read()
+
+
+def test_argument_handling_before_the_device_is_touched():
+    import vbx_amd
+    X = np.random.default_rng(0).standard_normal((20, 16))
+    Phi = np.ones(16)
+    with pytest.raises(AssertionError):                       # VBx.py:85
+        vbx_amd.VBx(X, Phi, pi=4, gamma=np.full((20, 5), 0.2))
+    with pytest.raises(TypeError):                            # VBx.py:76: numpy ints are not `int`
+        vbx_amd.VBx(X, Phi, pi=np.int64(4))
+    g0 = np.full((20, 4), 0.25)
+    gamma, pi, Li = vbx_amd.VBx(X, Phi, pi=4, gamma=g0, maxIters=0)
+    assert gamma is g0 and Li == [] and np.allclose(pi, 0.25)
+    out = vbx_amd.VBx(X, Phi, pi=4, gamma=g0, maxIters=0, return_model=True)
+    assert len(out) == 5 and out[3] is None and out[4] is None
+
+
+def test_der_matches_oracle():
+    from oracle import vbx_oracle
+    import vbx_amd
+    rng = np.random.default_rng(5)
+    q = rng.random((200, 6))
+    q /= q.sum(1, keepdims=True)
+    ref = rng.integers(0, 4, 200)
+    for kw in ({}, {'expected': False}, {'xentropy': True}, {'expected': False, 'xentropy': True}):
+        assert np.isclose(vbx_amd.DER(q, ref, **kw), vbx_oracle.DER(q, ref, **kw), rtol=1e-12), kw
+
+
+def test_transition_structure_detection():
+    from vbx_amd.VBx import _split_transition
+    pi = np.array([0.2, 0.5, 0.3])
+    lp, off = _split_transition(np.eye(3) * 0.9 + 0.1 * pi)
+    assert np.isclose(lp, 0.9) and np.allclose(off, 0.1 * pi)
+    with pytest.raises(NotImplementedError):
+        _split_transition(np.array([[0.5, 0.5, 0.0], [0.1, 0.8, 0.1], [0.3, 0.3, 0.4]]))
+
+
+def test_drop_in_module_exports_reference_names():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('VBx_dropin', os.path.join(REPO, 'vbx_drop_in', 'VBx.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    import inspect
+    sig = inspect.signature(mod.VBx)
+    names = list(sig.parameters)
+    assert names[:15] == ['X', 'Phi', 'loopProb', 'Fa', 'Fb', 'pi', 'gamma', 'maxIters', 'epsilon', 'alphaQInit',
+                          'ref', 'plot', 'return_model', 'alpha', 'invL']          # VBx.py:27-29
+    d = {k: v.default for k, v in sig.parameters.items()}
+    assert (d['loopProb'], d['Fa'], d['Fb'], d['pi'], d['maxIters'], d['epsilon'], d['alphaQInit']) == \
+        (0.9, 1.0, 1.0, 10, 10, 1e-4, 1.0)
+    assert callable(mod.forward_backward) and callable(mod.DER)

@@ -1,0 +1,256 @@
+"""ctypes binding of libvbx_hip.so (include/vbx_hip.h).  No CPU fallback: if the library or
+a gfx950 device is missing, every entry point raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+VBX_F32, VBX_F64 = 0, 1
+PREC_FP32, PREC_FP64 = 0, 1
+FB_AUTO, FB_SEQUENTIAL, FB_CHUNKED = 0, 1, 2
+OPT_FB_ALGO, OPT_CHECK_EVERY, OPT_PROFILE, OPT_CHUNK_FRAMES = 1, 2, 3, 4
+K_NAMES = ['prep', 'mstep_acc', 'mstep_fin', 'loglik', 'fb', 'fb_aux', 'post', 'iter_fin']
+MAX_SPEAKERS = 256
+
+ABI_SYMBOLS = [
+    'vbx_abi_version', 'vbx_create', 'vbx_destroy', 'vbx_last_error', 'vbx_device_info',
+    'vbx_batch_create', 'vbx_batch_destroy', 'vbx_batch_set_option', 'vbx_batch_set_recording',
+    'vbx_batch_run', 'vbx_batch_get_result', 'vbx_batch_last_run_ms', 'vbx_batch_kernel_times',
+    'vbx_run', 'vbx_forward_backward', 'vbx_mstep', 'vbx_loglik',
+]
+
+
+class VbxError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def library_path() -> str:
+    return _build.LIB
+
+
+def load():
+    """Load (building if the sources are newer) the HIP library.  Raises when unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if not os.path.exists(path) or (_build.is_stale() and os.environ.get('VBX_AMD_NO_REBUILD') != '1'):
+        try:
+            path = _build.build()
+        except Exception as exc:  # a stale-but-present library is still usable on a box without hipcc
+            if not os.path.exists(path):
+                raise VbxError(f'libvbx_hip.so is not built and cannot be built here: {exc}') from exc
+    lib = C.CDLL(path)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    lib.vbx_abi_version.restype = C.c_int
+    lib.vbx_create.argtypes = [C.POINTER(vp), C.c_int]
+    lib.vbx_destroy.argtypes = [vp]
+    lib.vbx_last_error.argtypes = [vp]
+    lib.vbx_last_error.restype = C.c_char_p
+    lib.vbx_device_info.argtypes = [vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(i64)]
+    lib.vbx_batch_create.argtypes = [vp, C.c_int, C.POINTER(i64), C.POINTER(i32), i32, C.c_int, C.c_int,
+                                     C.POINTER(vp)]
+    lib.vbx_batch_destroy.argtypes = [vp]
+    lib.vbx_batch_set_option.argtypes = [vp, C.c_int, i64]
+    lib.vbx_batch_set_recording.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, dbl, dbl, dbl]
+    lib.vbx_batch_run.argtypes = [vp, C.c_int, dbl]
+    lib.vbx_batch_get_result.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, C.POINTER(C.c_int),
+                                         C.POINTER(C.c_int), vp, vp]
+    lib.vbx_batch_last_run_ms.argtypes = [vp, C.POINTER(dbl), C.POINTER(C.c_int)]
+    lib.vbx_batch_kernel_times.argtypes = [vp, vp, vp]
+    lib.vbx_run.argtypes = [vp, vp, vp]
+    lib.vbx_forward_backward.argtypes = [vp, i64, i32, vp, vp, vp, dbl, C.c_int, C.c_int, vp, C.POINTER(dbl),
+                                         vp, vp, vp]
+    lib.vbx_mstep.argtypes = [vp, i64, i32, i32, vp, vp, vp, dbl, dbl, C.c_int, vp, vp]
+    lib.vbx_loglik.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, dbl, C.c_int, vp]
+    for name in ABI_SYMBOLS:
+        fn = getattr(lib, name)          # AttributeError here = the .so does not export the ABI
+        if name not in ('vbx_last_error', 'vbx_abi_version'):
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+def precision_code(precision) -> int:
+    if precision in (PREC_FP32, 'fp32', 'f32', 'float32', np.float32):
+        return PREC_FP32
+    if precision in (PREC_FP64, 'fp64', 'f64', 'float64', np.float64):
+        return PREC_FP64
+    raise ValueError(f'unknown precision {precision!r}')
+
+
+class Context:
+    """One device + one HIP stream (vbx_ctx)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load()
+        h = C.c_void_p()
+        rc = self._lib.vbx_create(C.byref(h), int(device))
+        if rc != 0:
+            raise VbxError(f'vbx_create(device={device}) failed ({rc}): '
+                           f'{self._lib.vbx_last_error(None).decode()}')
+        self._h = h
+        self.device = int(device)
+
+    def check(self, rc: int, what: str):
+        if rc != 0:
+            raise VbxError(f'{what} failed ({rc}): {self._lib.vbx_last_error(self._h).decode()}')
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus, hbm = C.c_int(), C.c_int64()
+        self.check(self._lib.vbx_device_info(self._h, name, 256, C.byref(cus), C.byref(hbm)), 'vbx_device_info')
+        return {'name': name.value.decode(), 'compute_units': cus.value, 'hbm_bytes': hbm.value}
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.vbx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- step-level entry points (parity tests) -------------------------------------------
+    def forward_backward(self, lls, pi, loopProb, ip=None, precision='fp64', fb_algo=FB_AUTO, want_logs=False):
+        lls = _f64(lls)
+        T, S = lls.shape
+        pi = _f64(pi)
+        ip = _f64(ip)
+        gamma = np.empty((T, S))
+        entered = np.empty(S)
+        tll = C.c_double()
+        lfw = np.empty((T, S)) if want_logs else None
+        lbw = np.empty((T, S)) if want_logs else None
+        self.check(self._lib.vbx_forward_backward(self._h, T, S, _ptr(lls), _ptr(pi), _ptr(ip), float(loopProb),
+                                                  precision_code(precision), int(fb_algo), _ptr(gamma),
+                                                  C.byref(tll), _ptr(entered), _ptr(lfw), _ptr(lbw)),
+                   'vbx_forward_backward')
+        return gamma, tll.value, entered, lfw, lbw
+
+    def mstep(self, X, Phi, gamma, Fa, Fb, precision='fp64'):
+        X, Phi, gamma = _f64(X), _f64(Phi), _f64(gamma)
+        T, D = X.shape
+        S = gamma.shape[1]
+        alpha, invL = np.empty((S, D)), np.empty((S, D))
+        self.check(self._lib.vbx_mstep(self._h, T, S, D, _ptr(X), _ptr(Phi), _ptr(gamma), float(Fa), float(Fb),
+                                       precision_code(precision), _ptr(alpha), _ptr(invL)), 'vbx_mstep')
+        return alpha, invL
+
+    def loglik(self, X, Phi, alpha, invL, Fa, precision='fp64'):
+        X, Phi, alpha, invL = _f64(X), _f64(Phi), _f64(alpha), _f64(invL)
+        T, D = X.shape
+        S = alpha.shape[0]
+        out = np.empty((T, S))
+        self.check(self._lib.vbx_loglik(self._h, T, S, D, _ptr(X), _ptr(Phi), _ptr(alpha), _ptr(invL), float(Fa),
+                                        precision_code(precision), _ptr(out)), 'vbx_loglik')
+        return out
+
+
+class Batch:
+    """A set of recordings resident in HBM (vbx_batch)."""
+
+    def __init__(self, ctx: Context, T, S, D: int, precision='fp32', max_iters: int = 40):
+        self.ctx = ctx
+        self._lib = ctx._lib
+        self.T = [int(t) for t in T]
+        self.S = [int(s) for s in S]
+        self.D = int(D)
+        self.n = len(self.T)
+        self.precision = precision_code(precision)
+        self.max_iters = int(max_iters)
+        h = C.c_void_p()
+        Ta = (C.c_int64 * self.n)(*self.T)
+        Sa = (C.c_int32 * self.n)(*self.S)
+        ctx.check(self._lib.vbx_batch_create(ctx._h, self.n, Ta, Sa, self.D, self.precision, self.max_iters,
+                                             C.byref(h)), 'vbx_batch_create')
+        self._h = h
+
+    def set_option(self, option: int, value: int):
+        self.ctx.check(self._lib.vbx_batch_set_option(self._h, int(option), int(value)), 'vbx_batch_set_option')
+
+    def set_recording(self, b, X, Phi, pi0, gamma0, loopProb, Fa, Fb, alpha0=None, invL0=None):
+        X = np.ascontiguousarray(X)
+        if X.dtype != np.float32:
+            X = np.ascontiguousarray(X, dtype=np.float64)
+        gamma0 = np.ascontiguousarray(gamma0)
+        if gamma0.dtype != np.float32:
+            gamma0 = np.ascontiguousarray(gamma0, dtype=np.float64)
+        assert X.shape == (self.T[b], self.D) and gamma0.shape == (self.T[b], self.S[b])
+        Phi, pi0, alpha0, invL0 = _f64(Phi), _f64(pi0), _f64(alpha0), _f64(invL0)
+        assert Phi.shape == (self.D,) and pi0.shape == (self.S[b],)
+        self.ctx.check(self._lib.vbx_batch_set_recording(
+            self._h, int(b), _ptr(X), VBX_F32 if X.dtype == np.float32 else VBX_F64, _ptr(Phi), _ptr(pi0),
+            _ptr(gamma0), VBX_F32 if gamma0.dtype == np.float32 else VBX_F64, _ptr(alpha0), _ptr(invL0),
+            float(loopProb), float(Fa), float(Fb)), 'vbx_batch_set_recording')
+
+    def run(self, iters: int, epsilon: float = -np.inf):
+        eps = float(epsilon)
+        if not np.isfinite(eps):
+            eps = -1e300 if eps < 0 else 1e300
+        self.ctx.check(self._lib.vbx_batch_run(self._h, int(iters), eps), 'vbx_batch_run')
+
+    def last_run_ms(self):
+        ms, it = C.c_double(), C.c_int()
+        self.ctx.check(self._lib.vbx_batch_last_run_ms(self._h, C.byref(ms), C.byref(it)), 'vbx_batch_last_run_ms')
+        return ms.value, it.value
+
+    def kernel_times(self):
+        ms = np.zeros(len(K_NAMES))
+        n = np.zeros(len(K_NAMES), dtype=np.int64)
+        self.ctx.check(self._lib.vbx_batch_kernel_times(self._h, _ptr(ms), _ptr(n)), 'vbx_batch_kernel_times')
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(K_NAMES)}
+
+    def result(self, b, want_gamma=True, want_model=True):
+        T, S, D = self.T[b], self.S[b], self.D
+        gamma = np.empty((T, S)) if want_gamma else None
+        pi = np.empty(S)
+        Li = np.zeros(max(self.max_iters, 1))
+        alpha = np.empty((S, D)) if want_model else None
+        invL = np.empty((S, D)) if want_model else None
+        n_iters, warned = C.c_int(), C.c_int()
+        self.ctx.check(self._lib.vbx_batch_get_result(self._h, int(b), _ptr(gamma), _ptr(pi), _ptr(Li), len(Li),
+                                                      C.byref(n_iters), C.byref(warned), _ptr(alpha), _ptr(invL)),
+                       'vbx_batch_get_result')
+        n = min(n_iters.value, self.max_iters)
+        return {'gamma': gamma, 'pi': pi, 'Li': Li[:n].copy(), 'n_iters': n_iters.value,
+                'warned': bool(warned.value), 'alpha': alpha, 'invL': invL}
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.vbx_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device: int | None = None) -> Context:
+    if device is None:
+        device = int(os.environ.get('VBX_AMD_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]

@@ -1,0 +1,50 @@
+"""Build libvbx_hip.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+The shared object lands next to its sources (vbx_amd/csrc/libvbx_hip.so) so that it travels
+with a snapshot of the repository; it is git-ignored.  hipcc cross-compiles without a GPU.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(CSRC, 'libvbx_hip.so')
+SOURCES = ['vbx_capi.hip']
+HEADERS = ['vbx_device.hpp', 'vbx_kernels.hpp', os.path.join('..', '..', 'include', 'vbx_hip.h')]
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-Wno-pass-failed']
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError('hipcc not found (need ROCm >= 7.0 to build libvbx_hip.so for gfx950)')
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    built = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    return any(os.path.getmtime(d) > built for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the library if it is missing or older than its sources; return its path."""
+    if not force and not is_stale():
+        return LIB
+    cmd = [_hipcc()] + FLAGS + ['-o', LIB + '.tmp'] + SOURCES
+    if verbose:
+        print(' '.join(cmd))
+    res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError('hipcc failed:\n' + res.stdout + res.stderr)
+    os.replace(LIB + '.tmp', LIB)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force=True, verbose=True))

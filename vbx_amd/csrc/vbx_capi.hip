@@ -1,0 +1,841 @@
+// vbx_capi.hip -- host runtime + C ABI (include/vbx_hip.h) of libvbx_hip.so.
+//
+// The runtime owns: the device context (one device, one stream), the HBM arena of a batch
+// of recordings, the launch sequence of one VB iteration (reference: VBx/VBx.py:91-125) and
+// the convergence bookkeeping.  Nothing here computes on the CPU except argument packing
+// (padding to Sp/Dp, f64 -> working precision) -- there is no CPU fallback.
+#include "../../include/vbx_hip.h"
+#include "vbx_kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace vbx;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+struct vbx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop;
+    std::string err;
+};
+
+#define HIPCHK(ctx_, call)                                                                    \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            char buf_[512];                                                                    \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                     __FILE__, __LINE__);                                                      \
+            (ctx_)->err = buf_;                                                                \
+            return VBX_ERR_HIP;                                                                \
+        }                                                                                      \
+    } while (0)
+
+#define FAIL(ctx_, code_, ...)                    \
+    do {                                          \
+        char buf_[512];                           \
+        snprintf(buf_, sizeof buf_, __VA_ARGS__); \
+        (ctx_)->err = buf_;                       \
+        return (code_);                           \
+    } while (0)
+
+struct EventPair {
+    int klass;
+    hipEvent_t a, b;
+};
+
+struct vbx_batch {
+    vbx_ctx* ctx = nullptr;
+    int n_rec = 0, D = 0, Dp = 0, Sp = 0, NT = 0, precision = 0, max_iters = 0;
+    size_t rsize = 4;
+    long long sum_T = 0;
+    int ntiles_total = 0;
+    std::vector<RecDesc> recs;
+    std::vector<char> is_set;
+    bool recs_dirty = true;
+    // options
+    int fb_algo = VBX_FB_AUTO, check_every = 4, profile = 0, chunk_frames = 0;
+    // device memory
+    RecDesc* d_recs = nullptr;
+    RecState* d_state = nullptr;
+    int *d_tile_rec = nullptr, *d_tile_t0 = nullptr;
+    double *d_phi = nullptr, *d_sqrt_phi = nullptr, *d_gtile = nullptr;
+    void *d_rho = nullptr, *d_gamma = nullptr, *d_bmat = nullptr, *d_mrow = nullptr, *d_ahat = nullptr,
+         *d_bhat = nullptr, *d_alpha = nullptr, *d_invL = nullptr, *d_bias = nullptr, *d_mpart = nullptr,
+         *d_npart = nullptr, *d_lraw = nullptr;
+    double *d_emodel = nullptr, *d_pi = nullptr, *d_epart = nullptr, *d_Li = nullptr;
+    double* d_ip = nullptr;                       // step-level API only; VBx() uses pi (VBx.py:99)
+    void *d_fw_scale = nullptr, *d_bw_scale = nullptr;   // step-level API only
+    void* d_xstage = nullptr;
+    size_t xstage_bytes = 0;
+    // timing
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    double last_ms = 0.0;
+    int iters_launched = 0;
+    std::vector<EventPair> ev_pool;
+    size_t ev_used = 0;
+    double k_ms[VBX_K_COUNT] = {0};
+    int64_t k_launches[VBX_K_COUNT] = {0};
+
+    template <typename R> BatchView<R> view(double epsilon) const {
+        BatchView<R> v;
+        v.n_rec = n_rec; v.Sp = Sp; v.Dp = Dp; v.D = D; v.max_iters = max_iters;
+        v.ntiles_total = ntiles_total;
+        v.recs = d_recs; v.state = d_state; v.tile_rec = d_tile_rec; v.tile_t0 = d_tile_t0;
+        v.phi = d_phi;
+        v.rho = (R*)d_rho; v.gamma = (R*)d_gamma; v.bmat = (R*)d_bmat; v.mrow = (R*)d_mrow;
+        v.ahat = (R*)d_ahat; v.bhat = (R*)d_bhat; v.alpha = (R*)d_alpha; v.invL = (R*)d_invL;
+        v.bias = (R*)d_bias; v.emodel = d_emodel; v.pi = d_pi; v.mpart = (R*)d_mpart;
+        v.npart = (R*)d_npart; v.epart = d_epart; v.Li = d_Li; v.epsilon = epsilon;
+        v.ip = d_ip ? d_ip : d_pi; v.fw_scale = (R*)d_fw_scale; v.bw_scale = (R*)d_bw_scale;
+        return v;
+    }
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// launch helpers
+// ---------------------------------------------------------------------------------------
+struct LaunchScope {   // brackets one kernel launch with events when profiling is on
+    vbx_batch* b;
+    EventPair* ep = nullptr;
+    LaunchScope(vbx_batch* b_, int klass) : b(b_) {
+        if (!b->profile) return;
+        if (b->ev_used == b->ev_pool.size()) {
+            EventPair p{klass, nullptr, nullptr};
+            if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+            b->ev_pool.push_back(p);
+        }
+        ep = &b->ev_pool[b->ev_used++];
+        ep->klass = klass;
+        (void)hipEventRecord(ep->a, b->ctx->stream);
+    }
+    ~LaunchScope() {
+        if (ep) (void)hipEventRecord(ep->b, b->ctx->stream);
+    }
+};
+
+#define NT_SWITCH(nt_, BODY)                                   \
+    switch (nt_) {                                             \
+        case 1: { constexpr int kNT = 1; BODY } break;         \
+        case 2: { constexpr int kNT = 2; BODY } break;         \
+        case 4: { constexpr int kNT = 4; BODY } break;         \
+        case 8: { constexpr int kNT = 8; BODY } break;         \
+        case 16: { constexpr int kNT = 16; BODY } break;       \
+        default: break;                                        \
+    }
+
+template <typename R> void launch_mstep(vbx_batch* b, double eps) {
+    auto v = b->view<R>(eps);
+    {
+        LaunchScope ls(b, VBX_K_MSTEP_ACC);
+        dim3 grid(b->ntiles_total, b->Dp / 32);
+        NT_SWITCH(b->NT, hipLaunchKernelGGL((mstep_acc_kernel<R, kNT>), grid, dim3(64), 0, b->ctx->stream, v);)
+    }
+    {
+        LaunchScope ls(b, VBX_K_MSTEP_FIN);
+        hipLaunchKernelGGL((mstep_fin_kernel<R>), dim3(b->n_rec, b->Sp), dim3(128), 0, b->ctx->stream, v);
+    }
+}
+
+template <typename R> void launch_loglik(vbx_batch* b, double eps, bool raw) {
+    auto v = b->view<R>(eps);
+    LaunchScope ls(b, VBX_K_LOGLIK);
+    R* lraw = raw ? (R*)b->d_lraw : nullptr;
+    NT_SWITCH(b->NT, hipLaunchKernelGGL((loglik_kernel<R, kNT>), dim3(b->ntiles_total), dim3(256), 0,
+                                        b->ctx->stream, v, lraw);)
+}
+
+template <typename R> void launch_fb(vbx_batch* b, double eps) {
+    auto v = b->view<R>(eps);
+    LaunchScope ls(b, VBX_K_FB);
+    const int nreg = std::max(1, b->Sp / 64);
+    switch (nreg) {
+        case 1: hipLaunchKernelGGL((fb_seq_kernel<R, 1>), dim3(b->n_rec), dim3(128), 0, b->ctx->stream, v); break;
+        case 2: hipLaunchKernelGGL((fb_seq_kernel<R, 2>), dim3(b->n_rec), dim3(128), 0, b->ctx->stream, v); break;
+        case 4: hipLaunchKernelGGL((fb_seq_kernel<R, 4>), dim3(b->n_rec), dim3(128), 0, b->ctx->stream, v); break;
+        default: break;
+    }
+}
+
+template <typename R> void launch_post(vbx_batch* b, double eps) {
+    auto v = b->view<R>(eps);
+    LaunchScope ls(b, VBX_K_POST);
+    dim3 grid(b->ntiles_total), block(256);
+    switch (b->Sp) {
+        case 16: hipLaunchKernelGGL((post_kernel<R, 16>), grid, block, 0, b->ctx->stream, v); break;
+        case 32: hipLaunchKernelGGL((post_kernel<R, 32>), grid, block, 0, b->ctx->stream, v); break;
+        case 64: hipLaunchKernelGGL((post_kernel<R, 64>), grid, block, 0, b->ctx->stream, v); break;
+        case 128: hipLaunchKernelGGL((post_kernel<R, 128>), grid, block, 0, b->ctx->stream, v); break;
+        case 256: hipLaunchKernelGGL((post_kernel<R, 256>), grid, block, 0, b->ctx->stream, v); break;
+        default: break;
+    }
+}
+
+template <typename R> void launch_iter_fin(vbx_batch* b, double eps) {
+    auto v = b->view<R>(eps);
+    LaunchScope ls(b, VBX_K_ITER_FIN);
+    hipLaunchKernelGGL((iter_fin_kernel<R>), dim3(b->n_rec), dim3(256), 0, b->ctx->stream, v);
+}
+
+template <typename R> void launch_iteration(vbx_batch* b, double eps) {
+    launch_mstep<R>(b, eps);
+    launch_loglik<R>(b, eps, false);
+    launch_fb<R>(b, eps);
+    launch_post<R>(b, eps);
+    launch_iter_fin<R>(b, eps);
+}
+
+template <typename R, typename XT>
+void launch_prep(vbx_batch* b, const RecDesc& rd) {
+    LaunchScope ls(b, VBX_K_PREP);
+    R* rho = (R*)b->d_rho + rd.row0 * b->Dp;
+    hipLaunchKernelGGL((prep_kernel<R, XT>), dim3(rd.ntiles), dim3(256), 0, b->ctx->stream,
+                       (const XT*)b->d_xstage, (const double*)b->d_sqrt_phi, rho, b->d_gtile + rd.tile0, rd.T,
+                       b->D, b->Dp);
+}
+
+int upload_recs(vbx_batch* b) {
+    if (!b->recs_dirty) return VBX_OK;
+    HIPCHK(b->ctx, hipMemcpyAsync(b->d_recs, b->recs.data(), sizeof(RecDesc) * b->n_rec, hipMemcpyHostToDevice,
+                                  b->ctx->stream));
+    HIPCHK(b->ctx, hipStreamSynchronize(b->ctx->stream));
+    b->recs_dirty = false;
+    return VBX_OK;
+}
+
+int collect_profile(vbx_batch* b) {
+    for (size_t i = 0; i < b->ev_used; ++i) {
+        float ms = 0.f;
+        HIPCHK(b->ctx, hipEventElapsedTime(&ms, b->ev_pool[i].a, b->ev_pool[i].b));
+        b->k_ms[b->ev_pool[i].klass] += ms;
+        b->k_launches[b->ev_pool[i].klass] += 1;
+    }
+    b->ev_used = 0;
+    return VBX_OK;
+}
+
+template <typename T> int dmalloc(vbx_ctx* ctx, T** p, size_t count) {
+    HIPCHK(ctx, hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T)));
+    return VBX_OK;
+}
+int dmalloc_bytes(vbx_ctx* ctx, void** p, size_t bytes) {
+    HIPCHK(ctx, hipMalloc(p, std::max<size_t>(bytes, 16)));
+    return VBX_OK;
+}
+
+// host <-> working precision packing --------------------------------------------------
+template <typename R, typename SRC>
+void pack_matrix(std::vector<R>& dst, const SRC* src, long long rows, int cols, int cols_p, R pad) {
+    dst.assign((size_t)rows * cols_p, pad);
+    for (long long r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) dst[(size_t)r * cols_p + c] = (R)src[(size_t)r * cols + c];
+}
+
+}  // namespace
+
+// =========================================================================================
+// C ABI
+// =========================================================================================
+extern "C" {
+
+int vbx_abi_version(void) { return VBX_ABI_VERSION; }
+
+const char* vbx_last_error(const vbx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int vbx_create(vbx_ctx** out, int device) {
+    if (!out) return VBX_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_create_error = std::string("no HIP device visible: ") + hipGetErrorString(e);
+        return VBX_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) {
+        g_create_error = "device index out of range";
+        return VBX_ERR_INVALID;
+    }
+    vbx_ctx* ctx = new vbx_ctx();
+    ctx->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&ctx->prop, device)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+        g_create_error = std::string("device setup failed: ") + hipGetErrorString(e);
+        delete ctx;
+        return VBX_ERR_HIP;
+    }
+    if (std::strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_error = std::string("libvbx_hip.so is built for gfx950 only; device reports ") + ctx->prop.gcnArchName;
+        (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return VBX_ERR_NO_DEVICE;
+    }
+    *out = ctx;
+    return VBX_OK;
+}
+
+int vbx_destroy(vbx_ctx* ctx) {
+    if (!ctx) return VBX_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return VBX_OK;
+}
+
+int vbx_device_info(vbx_ctx* ctx, char* name, int cap, int* compute_units, int64_t* hbm_bytes) {
+    if (!ctx) return VBX_ERR_INVALID;
+    if (name && cap > 0) {
+        std::snprintf(name, cap, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    }
+    if (compute_units) *compute_units = ctx->prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)ctx->prop.totalGlobalMem;
+    return VBX_OK;
+}
+
+int vbx_batch_destroy(vbx_batch* b) {
+    if (!b) return VBX_OK;
+    (void)hipSetDevice(b->ctx->device);
+    void* ptrs[] = {b->d_recs, b->d_state, b->d_tile_rec, b->d_tile_t0, b->d_phi, b->d_sqrt_phi, b->d_gtile,
+                    b->d_rho, b->d_gamma, b->d_bmat, b->d_mrow, b->d_ahat, b->d_bhat, b->d_alpha, b->d_invL,
+                    b->d_bias, b->d_mpart, b->d_npart, b->d_lraw, b->d_emodel, b->d_pi, b->d_epart, b->d_Li,
+                    b->d_xstage, b->d_ip, b->d_fw_scale, b->d_bw_scale};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (b->ev_start) (void)hipEventDestroy(b->ev_start);
+    if (b->ev_stop) (void)hipEventDestroy(b->ev_stop);
+    for (auto& ep : b->ev_pool) {
+        (void)hipEventDestroy(ep.a);
+        (void)hipEventDestroy(ep.b);
+    }
+    delete b;
+    return VBX_OK;
+}
+
+int vbx_batch_create(vbx_ctx* ctx, int n_rec, const int64_t* T, const int32_t* S, int32_t D, int precision,
+                     int max_iters, vbx_batch** out) {
+    if (!ctx) return VBX_ERR_INVALID;
+    if (!out || !T || !S || n_rec <= 0 || D <= 0 || max_iters < 0) FAIL(ctx, VBX_ERR_INVALID, "vbx_batch_create: bad argument");
+    if (precision != VBX_PREC_FP32 && precision != VBX_PREC_FP64) FAIL(ctx, VBX_ERR_INVALID, "unknown precision %d", precision);
+    *out = nullptr;
+    int smax = 0;
+    for (int i = 0; i < n_rec; ++i) {
+        if (T[i] <= 0 || T[i] > 0x7fffffffLL / 512) FAIL(ctx, VBX_ERR_INVALID, "recording %d: T=%lld out of range", i, (long long)T[i]);
+        if (S[i] <= 0) FAIL(ctx, VBX_ERR_INVALID, "recording %d: S=%d", i, S[i]);
+        smax = std::max(smax, (int)S[i]);
+    }
+    if (smax > VBX_MAX_SPEAKERS)
+        FAIL(ctx, VBX_ERR_UNSUPPORTED, "S=%d exceeds VBX_MAX_SPEAKERS=%d", smax, VBX_MAX_SPEAKERS);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    vbx_batch* b = new vbx_batch();
+    b->ctx = ctx;
+    b->n_rec = n_rec;
+    b->D = D;
+    b->Dp = round_up(D, 32);
+    int sp = 16;
+    while (sp < smax) sp *= 2;
+    b->Sp = sp;
+    b->NT = sp / 16;
+    b->precision = precision;
+    b->rsize = precision == VBX_PREC_FP64 ? 8 : 4;
+    b->max_iters = max_iters;
+    b->recs.resize(n_rec);
+    b->is_set.assign(n_rec, 0);
+    std::vector<int> tile_rec, tile_t0;
+    long long row = 0;
+    long long maxT = 0;
+    for (int i = 0; i < n_rec; ++i) {
+        RecDesc& rd = b->recs[i];
+        std::memset(&rd, 0, sizeof rd);
+        rd.row0 = row;
+        rd.T = (int)T[i];
+        rd.S = S[i];
+        rd.tile0 = (int)tile_rec.size();
+        rd.ntiles = (rd.T + kTileFrames - 1) / kTileFrames;
+        for (int tl = 0; tl < rd.ntiles; ++tl) {
+            tile_rec.push_back(i);
+            tile_t0.push_back(tl * kTileFrames);
+        }
+        row += rd.T;
+        maxT = std::max<long long>(maxT, rd.T);
+    }
+    b->sum_T = row;
+    b->ntiles_total = (int)tile_rec.size();
+    const size_t rs = b->rsize;
+    const size_t cells = (size_t)b->sum_T * b->Sp;
+    int rc = VBX_OK;
+#define ALLOC(expr) if (rc == VBX_OK) rc = (expr)
+    ALLOC(dmalloc(ctx, &b->d_recs, n_rec));
+    ALLOC(dmalloc(ctx, &b->d_state, n_rec));
+    ALLOC(dmalloc(ctx, &b->d_tile_rec, b->ntiles_total));
+    ALLOC(dmalloc(ctx, &b->d_tile_t0, b->ntiles_total));
+    ALLOC(dmalloc(ctx, &b->d_phi, (size_t)n_rec * b->Dp));
+    ALLOC(dmalloc(ctx, &b->d_sqrt_phi, b->Dp));
+    ALLOC(dmalloc(ctx, &b->d_gtile, b->ntiles_total));
+    ALLOC(dmalloc_bytes(ctx, &b->d_rho, (size_t)b->sum_T * b->Dp * rs));
+    ALLOC(dmalloc_bytes(ctx, &b->d_gamma, cells * rs));
+    ALLOC(dmalloc_bytes(ctx, &b->d_bmat, cells * rs));
+    ALLOC(dmalloc_bytes(ctx, &b->d_mrow, (size_t)b->sum_T * rs));
+    ALLOC(dmalloc_bytes(ctx, &b->d_ahat, cells * rs));
+    ALLOC(dmalloc_bytes(ctx, &b->d_bhat, cells * rs));
+    ALLOC(dmalloc_bytes(ctx, &b->d_alpha, (size_t)n_rec * b->Sp * b->Dp * rs));
+    ALLOC(dmalloc_bytes(ctx, &b->d_invL, (size_t)n_rec * b->Sp * b->Dp * rs));
+    ALLOC(dmalloc_bytes(ctx, &b->d_bias, (size_t)n_rec * b->Sp * rs));
+    ALLOC(dmalloc_bytes(ctx, &b->d_mpart, (size_t)b->ntiles_total * b->Sp * b->Dp * rs));
+    ALLOC(dmalloc_bytes(ctx, &b->d_npart, (size_t)b->ntiles_total * b->Sp * rs));
+    ALLOC(dmalloc(ctx, &b->d_emodel, (size_t)n_rec * b->Sp));
+    ALLOC(dmalloc(ctx, &b->d_pi, (size_t)n_rec * b->Sp));
+    ALLOC(dmalloc(ctx, &b->d_epart, (size_t)b->ntiles_total * b->Sp));
+    ALLOC(dmalloc(ctx, &b->d_Li, (size_t)n_rec * std::max(max_iters, 1)));
+    b->xstage_bytes = (size_t)maxT * D * 8;
+    ALLOC(dmalloc_bytes(ctx, &b->d_xstage, b->xstage_bytes));
+#undef ALLOC
+    if (rc != VBX_OK) {
+        vbx_batch_destroy(b);
+        return rc;
+    }
+    hipError_t e;
+    if ((e = hipMemcpy(b->d_tile_rec, tile_rec.data(), sizeof(int) * tile_rec.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(b->d_tile_t0, tile_t0.data(), sizeof(int) * tile_t0.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemset(b->d_state, 0, sizeof(RecState) * n_rec)) != hipSuccess ||
+        (e = hipMemset(b->d_gamma, 0, cells * rs)) != hipSuccess ||
+        (e = hipDeviceSynchronize()) != hipSuccess ||      // null-stream memsets vs. our non-blocking stream
+        (e = hipEventCreate(&b->ev_start)) != hipSuccess || (e = hipEventCreate(&b->ev_stop)) != hipSuccess) {
+        ctx->err = std::string("batch initialisation failed: ") + hipGetErrorString(e);
+        vbx_batch_destroy(b);
+        return VBX_ERR_HIP;
+    }
+    *out = b;
+    return VBX_OK;
+}
+
+int vbx_batch_set_option(vbx_batch* b, int option, int64_t value) {
+    if (!b) return VBX_ERR_INVALID;
+    switch (option) {
+        case VBX_OPT_FB_ALGO:
+            if (value < VBX_FB_AUTO || value > VBX_FB_CHUNKED) FAIL(b->ctx, VBX_ERR_INVALID, "bad fb algo");
+            b->fb_algo = (int)value;
+            return VBX_OK;
+        case VBX_OPT_CHECK_EVERY:
+            if (value < 1) FAIL(b->ctx, VBX_ERR_INVALID, "check_every must be >= 1");
+            b->check_every = (int)value;
+            return VBX_OK;
+        case VBX_OPT_PROFILE:
+            b->profile = value ? 1 : 0;
+            return VBX_OK;
+        case VBX_OPT_CHUNK_FRAMES:
+            if (value < 0) FAIL(b->ctx, VBX_ERR_INVALID, "chunk_frames must be >= 0");
+            b->chunk_frames = (int)value;
+            return VBX_OK;
+        default: FAIL(b->ctx, VBX_ERR_INVALID, "unknown option %d", option);
+    }
+}
+
+extern "C++" {
+namespace {
+template <typename R>
+int set_recording_impl(vbx_batch* b, int rec, const void* X, int x_dtype, const double* Phi, const double* pi0,
+                       const void* gamma0, int g_dtype, const double* alpha0, const double* invL0) {
+    vbx_ctx* ctx = b->ctx;
+    RecDesc& rd = b->recs[rec];
+    const int D = b->D, Dp = b->Dp, Sp = b->Sp, S = rd.S;
+    const long long T = rd.T;
+    // Phi, sqrt(Phi) (padded dims: 0)
+    std::vector<double> phi(Dp, 0.0), sphi(Dp, 0.0);
+    for (int d = 0; d < D; ++d) {
+        if (!(Phi[d] > 0.0)) FAIL(ctx, VBX_ERR_INVALID, "Phi[%d] must be positive", d);
+        phi[d] = Phi[d];
+        sphi[d] = std::sqrt(Phi[d]);
+    }
+    HIPCHK(ctx, hipMemcpyAsync(b->d_phi + (size_t)rec * Dp, phi.data(), sizeof(double) * Dp, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(b->d_sqrt_phi, sphi.data(), sizeof(double) * Dp, hipMemcpyHostToDevice, ctx->stream));
+    // X -> staging -> rho, G
+    const size_t xbytes = (size_t)T * D * (x_dtype == VBX_F64 ? 8 : 4);
+    HIPCHK(ctx, hipMemcpyAsync(b->d_xstage, X, xbytes, hipMemcpyHostToDevice, ctx->stream));
+    if (x_dtype == VBX_F64) launch_prep<R, double>(b, rd); else launch_prep<R, float>(b, rd);
+    HIPCHK(ctx, hipGetLastError());
+    std::vector<double> gt(rd.ntiles);
+    HIPCHK(ctx, hipMemcpyAsync(gt.data(), b->d_gtile + rd.tile0, sizeof(double) * rd.ntiles, hipMemcpyDeviceToHost, ctx->stream));
+    // gamma0, pi0 (padded speakers: 0)
+    std::vector<R> gp;
+    if (g_dtype == VBX_F64) pack_matrix<R, double>(gp, (const double*)gamma0, T, S, Sp, (R)0);
+    else pack_matrix<R, float>(gp, (const float*)gamma0, T, S, Sp, (R)0);
+    HIPCHK(ctx, hipMemcpyAsync((R*)b->d_gamma + rd.row0 * Sp, gp.data(), sizeof(R) * gp.size(), hipMemcpyHostToDevice, ctx->stream));
+    std::vector<double> pip(Sp, 0.0);
+    for (int s = 0; s < S; ++s) pip[s] = pi0[s];
+    HIPCHK(ctx, hipMemcpyAsync(b->d_pi + (size_t)rec * Sp, pip.data(), sizeof(double) * Sp, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<R> ap, ip;
+    rd.has_model = (alpha0 && invL0) ? 1 : 0;
+    if (rd.has_model) {
+        ap.assign((size_t)Sp * Dp, (R)0);
+        ip.assign((size_t)Sp * Dp, (R)1);
+        for (int s = 0; s < S; ++s)
+            for (int d = 0; d < D; ++d) {
+                ap[(size_t)s * Dp + d] = (R)alpha0[(size_t)s * D + d];
+                ip[(size_t)s * Dp + d] = (R)invL0[(size_t)s * D + d];
+            }
+        HIPCHK(ctx, hipMemcpyAsync((R*)b->d_alpha + (size_t)rec * Sp * Dp, ap.data(), sizeof(R) * ap.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync((R*)b->d_invL + (size_t)rec * Sp * Dp, ip.data(), sizeof(R) * ip.size(), hipMemcpyHostToDevice, ctx->stream));
+    }
+    RecState st;
+    std::memset(&st, 0, sizeof st);
+    HIPCHK(ctx, hipMemcpyAsync(b->d_state + rec, &st, sizeof st, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // host vectors go out of scope below
+    double gsum = 0.0;
+    for (double g : gt) gsum += g;
+    rd.gsum = gsum;
+    return VBX_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+int vbx_batch_set_recording(vbx_batch* b, int rec, const void* X, int x_dtype, const double* Phi, const double* pi0,
+                            const void* gamma0, int g_dtype, const double* alpha0, const double* invL0,
+                            double loopProb, double Fa, double Fb) {
+    if (!b) return VBX_ERR_INVALID;
+    vbx_ctx* ctx = b->ctx;
+    if (rec < 0 || rec >= b->n_rec) FAIL(ctx, VBX_ERR_INVALID, "recording index %d out of range", rec);
+    if (!X || !Phi || !pi0 || !gamma0) FAIL(ctx, VBX_ERR_INVALID, "vbx_batch_set_recording: NULL input");
+    if ((x_dtype != VBX_F32 && x_dtype != VBX_F64) || (g_dtype != VBX_F32 && g_dtype != VBX_F64))
+        FAIL(ctx, VBX_ERR_INVALID, "bad element type");
+    if ((alpha0 == nullptr) != (invL0 == nullptr)) { alpha0 = nullptr; invL0 = nullptr; }   // VBx.py:94 needs both
+    if (!(loopProb >= 0.0 && loopProb <= 1.0)) FAIL(ctx, VBX_ERR_INVALID, "loopProb=%g outside [0,1]", loopProb);
+    if (!(Fa > 0.0) || !(Fb > 0.0)) FAIL(ctx, VBX_ERR_INVALID, "Fa and Fb must be positive");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    RecDesc& rd = b->recs[rec];
+    rd.lp = loopProb;
+    rd.Fa = Fa;
+    rd.Fb = Fb;
+    int rc = b->precision == VBX_PREC_FP64
+                 ? set_recording_impl<double>(b, rec, X, x_dtype, Phi, pi0, gamma0, g_dtype, alpha0, invL0)
+                 : set_recording_impl<float>(b, rec, X, x_dtype, Phi, pi0, gamma0, g_dtype, alpha0, invL0);
+    if (rc != VBX_OK) return rc;
+    b->is_set[rec] = 1;
+    b->recs_dirty = true;
+    return VBX_OK;
+}
+
+int vbx_batch_run(vbx_batch* b, int max_iters, double epsilon) {
+    if (!b) return VBX_ERR_INVALID;
+    vbx_ctx* ctx = b->ctx;
+    if (max_iters < 0) FAIL(ctx, VBX_ERR_INVALID, "max_iters < 0");
+    for (int i = 0; i < b->n_rec; ++i)
+        if (!b->is_set[i]) FAIL(ctx, VBX_ERR_STATE, "recording %d has not been set", i);
+    if (b->fb_algo == VBX_FB_CHUNKED) FAIL(ctx, VBX_ERR_UNSUPPORTED, "chunked scan is not built into this library version");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = upload_recs(b);
+    if (rc != VBX_OK) return rc;
+    std::fill(b->k_ms, b->k_ms + VBX_K_COUNT, 0.0);
+    std::fill(b->k_launches, b->k_launches + VBX_K_COUNT, 0);
+    b->ev_used = 0;
+    const bool can_stop = epsilon > -1e299;
+    std::vector<RecState> st(b->n_rec);
+    HIPCHK(ctx, hipEventRecord(b->ev_start, ctx->stream));
+    int launched = 0;
+    for (int it = 0; it < max_iters; ++it) {
+        if (b->precision == VBX_PREC_FP64) launch_iteration<double>(b, epsilon);
+        else launch_iteration<float>(b, epsilon);
+        ++launched;
+        if (can_stop && ((it + 1) % b->check_every == 0) && it + 1 < max_iters) {
+            HIPCHK(ctx, hipMemcpyAsync(st.data(), b->d_state, sizeof(RecState) * b->n_rec, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            bool all_done = true;
+            for (auto& s : st) all_done = all_done && s.done;
+            if (all_done) break;
+        }
+    }
+    HIPCHK(ctx, hipEventRecord(b->ev_stop, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipGetLastError());
+    float ms = 0.f;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, b->ev_start, b->ev_stop));
+    b->last_ms = ms;
+    b->iters_launched = launched;
+    return collect_profile(b);
+}
+
+extern "C++" {
+namespace {
+template <typename R>
+int get_result_impl(vbx_batch* b, int rec, double* gamma, double* pi, double* Li, int li_cap, int* n_iters,
+                    int* warned, double* alpha, double* invL) {
+    vbx_ctx* ctx = b->ctx;
+    const RecDesc& rd = b->recs[rec];
+    const int Sp = b->Sp, Dp = b->Dp, S = rd.S, D = b->D;
+    RecState st;
+    HIPCHK(ctx, hipMemcpy(&st, b->d_state + rec, sizeof st, hipMemcpyDeviceToHost));
+    if (n_iters) *n_iters = st.n_iters;
+    if (warned) *warned = st.warned;
+    if (gamma) {
+        std::vector<R> g((size_t)rd.T * Sp);
+        HIPCHK(ctx, hipMemcpy(g.data(), (R*)b->d_gamma + rd.row0 * Sp, sizeof(R) * g.size(), hipMemcpyDeviceToHost));
+        for (long long t = 0; t < rd.T; ++t)
+            for (int s = 0; s < S; ++s) gamma[(size_t)t * S + s] = (double)g[(size_t)t * Sp + s];
+    }
+    if (pi) {
+        std::vector<double> p(Sp);
+        HIPCHK(ctx, hipMemcpy(p.data(), b->d_pi + (size_t)rec * Sp, sizeof(double) * Sp, hipMemcpyDeviceToHost));
+        for (int s = 0; s < S; ++s) pi[s] = p[s];
+    }
+    if (Li && li_cap > 0) {
+        const int n = std::min(std::min(st.n_iters, li_cap), b->max_iters);
+        if (n > 0) HIPCHK(ctx, hipMemcpy(Li, b->d_Li + (size_t)rec * b->max_iters, sizeof(double) * n, hipMemcpyDeviceToHost));
+    }
+    if (alpha || invL) {
+        std::vector<R> a((size_t)Sp * Dp), il((size_t)Sp * Dp);
+        HIPCHK(ctx, hipMemcpy(a.data(), (R*)b->d_alpha + (size_t)rec * Sp * Dp, sizeof(R) * a.size(), hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(il.data(), (R*)b->d_invL + (size_t)rec * Sp * Dp, sizeof(R) * il.size(), hipMemcpyDeviceToHost));
+        for (int s = 0; s < S; ++s)
+            for (int d = 0; d < D; ++d) {
+                if (alpha) alpha[(size_t)s * D + d] = (double)a[(size_t)s * Dp + d];
+                if (invL) invL[(size_t)s * D + d] = (double)il[(size_t)s * Dp + d];
+            }
+    }
+    return VBX_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+int vbx_batch_get_result(vbx_batch* b, int rec, double* gamma, double* pi, double* Li, int li_cap, int* n_iters,
+                         int* warned, double* alpha, double* invL) {
+    if (!b) return VBX_ERR_INVALID;
+    if (rec < 0 || rec >= b->n_rec) FAIL(b->ctx, VBX_ERR_INVALID, "recording index %d out of range", rec);
+    HIPCHK(b->ctx, hipSetDevice(b->ctx->device));
+    HIPCHK(b->ctx, hipStreamSynchronize(b->ctx->stream));
+    return b->precision == VBX_PREC_FP64
+               ? get_result_impl<double>(b, rec, gamma, pi, Li, li_cap, n_iters, warned, alpha, invL)
+               : get_result_impl<float>(b, rec, gamma, pi, Li, li_cap, n_iters, warned, alpha, invL);
+}
+
+int vbx_batch_last_run_ms(vbx_batch* b, double* total_ms, int* iters_launched) {
+    if (!b) return VBX_ERR_INVALID;
+    if (total_ms) *total_ms = b->last_ms;
+    if (iters_launched) *iters_launched = b->iters_launched;
+    return VBX_OK;
+}
+
+int vbx_batch_kernel_times(vbx_batch* b, double* ms, int64_t* launches) {
+    if (!b) return VBX_ERR_INVALID;
+    for (int k = 0; k < VBX_K_COUNT; ++k) {
+        if (ms) ms[k] = b->k_ms[k];
+        if (launches) launches[k] = b->k_launches[k];
+    }
+    return VBX_OK;
+}
+
+int vbx_run(vbx_ctx* ctx, const vbx_problem* p, vbx_result* r) {
+    if (!ctx) return VBX_ERR_INVALID;
+    if (!p || !r) FAIL(ctx, VBX_ERR_INVALID, "vbx_run: NULL problem/result");
+    vbx_batch* b = nullptr;
+    int64_t T = p->T;
+    int32_t S = p->S;
+    int rc = vbx_batch_create(ctx, 1, &T, &S, p->D, p->precision, p->max_iters, &b);
+    if (rc != VBX_OK) return rc;
+    rc = vbx_batch_set_option(b, VBX_OPT_FB_ALGO, p->fb_algo);
+    if (rc == VBX_OK)
+        rc = vbx_batch_set_recording(b, 0, p->X, p->x_dtype, p->Phi, p->pi0, p->gamma0, p->g_dtype, p->alpha0,
+                                     p->invL0, p->loopProb, p->Fa, p->Fb);
+    if (rc == VBX_OK) rc = vbx_batch_run(b, p->max_iters, p->epsilon);
+    if (rc == VBX_OK)
+        rc = vbx_batch_get_result(b, 0, r->gamma, r->pi, r->Li, p->max_iters, &r->n_iters, &r->warned, r->alpha,
+                                  r->invL);
+    if (rc == VBX_OK) r->run_ms = b->last_ms;
+    vbx_batch_destroy(b);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------
+// step-level entry points (parity tests)
+// ---------------------------------------------------------------------------------------
+extern "C++" {
+namespace {
+template <typename R>
+int fb_step_impl(vbx_batch* b, int64_t T, int32_t S, const double* lls, double* gamma, double* tll, double* entered,
+                 double* lfw, double* lbw) {
+    vbx_ctx* ctx = b->ctx;
+    const int Sp = b->Sp;
+    std::vector<R> bm((size_t)T * Sp, (R)0), mr((size_t)T);
+    for (int64_t t = 0; t < T; ++t) {
+        double m = -INFINITY;
+        for (int s = 0; s < S; ++s) m = std::max(m, lls[(size_t)t * S + s]);
+        const R mq = (R)m;                      // the device keeps the row max in working precision
+        mr[(size_t)t] = mq;
+        for (int s = 0; s < S; ++s) bm[(size_t)t * Sp + s] = (R)std::exp(lls[(size_t)t * S + s] - (double)mq);
+    }
+    HIPCHK(ctx, hipMemcpy(b->d_bmat, bm.data(), sizeof(R) * bm.size(), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(b->d_mrow, mr.data(), sizeof(R) * mr.size(), hipMemcpyHostToDevice));
+    const bool want_logs = lfw || lbw;
+    if (want_logs) {
+        int rc2 = dmalloc_bytes(ctx, &b->d_fw_scale, (size_t)T * sizeof(R));
+        if (rc2 == VBX_OK) rc2 = dmalloc_bytes(ctx, &b->d_bw_scale, (size_t)T * sizeof(R));
+        if (rc2 != VBX_OK) return rc2;
+    }
+    int rc = upload_recs(b);
+    if (rc != VBX_OK) return rc;
+    launch_fb<R>(b, 0.0);
+    launch_post<R>(b, 0.0);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipGetLastError());
+    RecState st;
+    HIPCHK(ctx, hipMemcpy(&st, b->d_state, sizeof st, hipMemcpyDeviceToHost));
+    if (tll) *tll = st.tll;
+    if (gamma) {
+        rc = get_result_impl<R>(b, 0, gamma, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr);
+        if (rc != VBX_OK) return rc;
+    }
+    if (entered) {
+        std::vector<double> ep((size_t)b->ntiles_total * Sp);
+        HIPCHK(ctx, hipMemcpy(ep.data(), b->d_epart, sizeof(double) * ep.size(), hipMemcpyDeviceToHost));
+        for (int s = 0; s < S; ++s) {
+            double acc = 0.0;
+            for (int tl = 0; tl < b->ntiles_total; ++tl) acc += ep[(size_t)tl * Sp + s];
+            entered[s] = acc;
+        }
+    }
+    if (want_logs) {
+        // lfw[t] = log ahat[t] + sum_{u<=t} (log s_u + m_u);  lbw[t] = log bhat[t] + sum_{u>t} (log q_{u-1} + m_u)
+        std::vector<R> ah((size_t)T * Sp), bh((size_t)T * Sp), fs((size_t)T), bs((size_t)T);
+        HIPCHK(ctx, hipMemcpy(ah.data(), b->d_ahat, sizeof(R) * ah.size(), hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(bh.data(), b->d_bhat, sizeof(R) * bh.size(), hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(fs.data(), b->d_fw_scale, sizeof(R) * fs.size(), hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(bs.data(), b->d_bw_scale, sizeof(R) * bs.size(), hipMemcpyDeviceToHost));
+        if (lfw) {
+            double cum = 0.0;
+            for (int64_t t = 0; t < T; ++t) {
+                cum += std::log((double)fs[(size_t)t]) + (double)mr[(size_t)t];
+                for (int s = 0; s < S; ++s) lfw[(size_t)t * S + s] = std::log((double)ah[(size_t)t * Sp + s]) + cum;
+            }
+        }
+        if (lbw) {
+            double cum = 0.0;
+            for (int64_t t = T - 1; t >= 0; --t) {
+                if (t < T - 1) cum += std::log((double)bs[(size_t)t]) + (double)mr[(size_t)t + 1];
+                for (int s = 0; s < S; ++s) lbw[(size_t)t * S + s] = std::log((double)bh[(size_t)t * Sp + s]) + cum;
+            }
+        }
+    }
+    return VBX_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+int vbx_forward_backward(vbx_ctx* ctx, int64_t T, int32_t S, const double* lls, const double* pi, const double* ip,
+                         double loopProb, int precision, int fb_algo, double* gamma, double* tll, double* entered,
+                         double* lfw, double* lbw) {
+    if (!ctx) return VBX_ERR_INVALID;
+    if (!lls || !pi || T <= 0 || S <= 0) FAIL(ctx, VBX_ERR_INVALID, "vbx_forward_backward: bad argument");
+    if (!(loopProb >= 0.0 && loopProb <= 1.0)) FAIL(ctx, VBX_ERR_INVALID, "loopProb=%g outside [0,1]", loopProb);
+    vbx_batch* b = nullptr;
+    int rc = vbx_batch_create(ctx, 1, &T, &S, 32, precision, 1, &b);
+    if (rc != VBX_OK) return rc;
+    rc = vbx_batch_set_option(b, VBX_OPT_FB_ALGO, fb_algo);
+    if (rc == VBX_OK) {
+        RecDesc& rd = b->recs[0];
+        rd.lp = loopProb;
+        rd.Fa = rd.Fb = 1.0;
+        std::vector<double> pip(b->Sp, 0.0), ipp(b->Sp, 0.0);
+        for (int s = 0; s < S; ++s) {
+            pip[s] = pi[s];
+            ipp[s] = ip ? ip[s] : pi[s];
+        }
+        rc = dmalloc(ctx, &b->d_ip, (size_t)b->Sp);
+        hipError_t e = hipSuccess;
+        if (rc == VBX_OK) e = hipMemcpy(b->d_pi, pip.data(), sizeof(double) * b->Sp, hipMemcpyHostToDevice);
+        if (rc == VBX_OK && e == hipSuccess) e = hipMemcpy(b->d_ip, ipp.data(), sizeof(double) * b->Sp, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            ctx->err = std::string("pi upload failed: ") + hipGetErrorString(e);
+            rc = VBX_ERR_HIP;
+        }
+        b->recs_dirty = true;
+    }
+    if (rc == VBX_OK)
+        rc = precision == VBX_PREC_FP64 ? fb_step_impl<double>(b, T, S, lls, gamma, tll, entered, lfw, lbw)
+                                        : fb_step_impl<float>(b, T, S, lls, gamma, tll, entered, lfw, lbw);
+    vbx_batch_destroy(b);
+    return rc;
+}
+
+int vbx_mstep(vbx_ctx* ctx, int64_t T, int32_t S, int32_t D, const double* X, const double* Phi, const double* gamma,
+              double Fa, double Fb, int precision, double* alpha, double* invL) {
+    if (!ctx) return VBX_ERR_INVALID;
+    if (!X || !Phi || !gamma) FAIL(ctx, VBX_ERR_INVALID, "vbx_mstep: NULL input");
+    vbx_batch* b = nullptr;
+    int rc = vbx_batch_create(ctx, 1, &T, &S, D, precision, 1, &b);
+    if (rc != VBX_OK) return rc;
+    std::vector<double> pi(S, 1.0 / S);
+    rc = vbx_batch_set_recording(b, 0, X, VBX_F64, Phi, pi.data(), gamma, VBX_F64, nullptr, nullptr, 0.9, Fa, Fb);
+    if (rc == VBX_OK) rc = upload_recs(b);
+    if (rc == VBX_OK) {
+        if (precision == VBX_PREC_FP64) launch_mstep<double>(b, 0.0); else launch_mstep<float>(b, 0.0);
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) {
+            ctx->err = std::string("mstep kernels failed: ") + hipGetErrorString(e);
+            rc = VBX_ERR_HIP;
+        }
+    }
+    if (rc == VBX_OK) rc = vbx_batch_get_result(b, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, alpha, invL);
+    vbx_batch_destroy(b);
+    return rc;
+}
+
+int vbx_loglik(vbx_ctx* ctx, int64_t T, int32_t S, int32_t D, const double* X, const double* Phi, const double* alpha,
+               const double* invL, double Fa, int precision, double* log_p) {
+    if (!ctx) return VBX_ERR_INVALID;
+    if (!X || !Phi || !alpha || !invL || !log_p) FAIL(ctx, VBX_ERR_INVALID, "vbx_loglik: NULL input");
+    vbx_batch* b = nullptr;
+    int rc = vbx_batch_create(ctx, 1, &T, &S, D, precision, 1, &b);
+    if (rc != VBX_OK) return rc;
+    std::vector<double> pi(S, 1.0 / S), g0((size_t)T * S, 1.0 / S);
+    rc = vbx_batch_set_recording(b, 0, X, VBX_F64, Phi, pi.data(), g0.data(), VBX_F64, alpha, invL, 0.9, Fa, 1.0);
+    if (rc == VBX_OK) rc = upload_recs(b);
+    const size_t cells = (size_t)T * b->Sp;
+    if (rc == VBX_OK) rc = dmalloc_bytes(ctx, &b->d_lraw, cells * b->rsize);
+    if (rc == VBX_OK) {
+        auto go = [&](auto tag) {
+            using R = decltype(tag);
+            auto v = b->view<R>(0.0);
+            hipLaunchKernelGGL((mstep_fin_kernel<R>), dim3(b->n_rec, b->Sp), dim3(128), 0, ctx->stream, v);
+            launch_loglik<R>(b, 0.0, true);
+        };
+        if (precision == VBX_PREC_FP64) go(double{}); else go(float{});
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) {
+            ctx->err = std::string("loglik kernels failed: ") + hipGetErrorString(e);
+            rc = VBX_ERR_HIP;
+        }
+    }
+    if (rc == VBX_OK) {
+        // add the per-frame constant Fa*G_t of VBx.py:87,97 on the host (f64)
+        auto fetch = [&](auto tag) -> int {
+            using R = decltype(tag);
+            std::vector<R> raw(cells);
+            HIPCHK(ctx, hipMemcpy(raw.data(), b->d_lraw, sizeof(R) * cells, hipMemcpyDeviceToHost));
+            for (int64_t t = 0; t < T; ++t) {
+                double ss = 0.0;
+                for (int d = 0; d < D; ++d) ss += X[(size_t)t * D + d] * X[(size_t)t * D + d];
+                const double G = -0.5 * (ss + D * std::log(2.0 * M_PI));
+                for (int s = 0; s < S; ++s) log_p[(size_t)t * S + s] = (double)raw[(size_t)t * b->Sp + s] + Fa * G;
+            }
+            return VBX_OK;
+        };
+        rc = precision == VBX_PREC_FP64 ? fetch(double{}) : fetch(float{});
+    }
+    vbx_batch_destroy(b);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,146 @@
+// vbx_device.hpp -- wavefront-level building blocks for gfx950 (CDNA4, wave64).
+//
+// Nothing here is portable HIP on purpose: 64-lane wavefronts, DPP row operations and the
+// f32/f64 16x16x4 MFMA fragment layouts of gfx950 are hard-wired.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vbx {
+
+constexpr int kWave = 64;
+constexpr int kTileFrames = 128;  // frames handled by one workgroup tile
+
+// ---------------------------------------------------------------------------------------
+// small vector types
+// ---------------------------------------------------------------------------------------
+template <typename R> struct Vec;
+template <> struct Vec<float> {
+    using v2 = float __attribute__((ext_vector_type(2)));
+    using v4 = float __attribute__((ext_vector_type(4)));
+};
+template <> struct Vec<double> {
+    using v2 = double __attribute__((ext_vector_type(2)));
+    using v4 = double __attribute__((ext_vector_type(4)));
+};
+
+// ---------------------------------------------------------------------------------------
+// MFMA 16x16x4, f32 and f64.  One A value and one B value per lane:
+//   A[i = lane & 15][k = lane >> 4],  B[k = lane >> 4][j = lane & 15]
+// C/D: col = lane & 15; row = 4*(lane>>4) + reg (f32)  |  (lane>>4) + 4*reg (f64).
+// The f32 form is an exact k-ordered fmaf chain (157 TF peak); f64 runs at 78.6 TF.
+// ---------------------------------------------------------------------------------------
+template <typename R> struct Mfma16;
+template <> struct Mfma16<float> {
+    using acc_t = Vec<float>::v4;
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int lane, int reg) { return ((lane >> 4) << 2) + reg; }
+};
+template <> struct Mfma16<double> {
+    using acc_t = Vec<double>::v4;
+    static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) + (reg << 2); }
+};
+
+// ---------------------------------------------------------------------------------------
+// DPP lane exchange (no LDS traffic).  All 64 lanes must be active at the call site.
+//   0xB1 quad_perm(1,0,3,2) = xor 1      0x4E quad_perm(2,3,0,1) = xor 2
+//   0x141 row_half_mirror (i -> 7-i)     0x140 row_mirror (i -> 15-i)
+// After the two quad steps every lane of a quad holds the quad sum, so the mirrors act as
+// xor 4 and xor 8 inside a butterfly.
+// ---------------------------------------------------------------------------------------
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
+    const long long bits = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xffffffffLL), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), CTRL, 0xF, 0xF, false);
+    const long long out = ((long long)hi << 32) | (unsigned int)lo;
+    return __builtin_bit_cast(double, out);
+}
+
+// Butterfly all-reduce over aligned groups of W lanes (W = 16, 32 or 64): every lane of a
+// group ends up with the group's sum (identical bits in every lane: each stage adds a
+// symmetric pair).
+template <int W, typename R> __device__ __forceinline__ R allreduce_sum(R v) {
+    static_assert(W == 16 || W == 32 || W == 64, "group width");
+#ifdef VBX_NO_DPP
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+#else
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+#endif
+    if (W >= 32) v += __shfl_xor(v, 16, 64);
+    if (W >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+template <typename R> __device__ __forceinline__ R vmax(R a, R b) { return a > b ? a : b; }
+
+template <int W, typename R> __device__ __forceinline__ R allreduce_max(R v) {
+    static_assert(W == 16 || W == 32 || W == 64, "group width");
+#ifdef VBX_NO_DPP
+    v = vmax(v, __shfl_xor(v, 1, 64));
+    v = vmax(v, __shfl_xor(v, 2, 64));
+    v = vmax(v, __shfl_xor(v, 4, 64));
+    v = vmax(v, __shfl_xor(v, 8, 64));
+#else
+    v = vmax(v, dpp_mov<0xB1>(v));
+    v = vmax(v, dpp_mov<0x4E>(v));
+    v = vmax(v, dpp_mov<0x141>(v));
+    v = vmax(v, dpp_mov<0x140>(v));
+#endif
+    if (W >= 32) v = vmax(v, __shfl_xor(v, 16, 64));
+    if (W >= 64) v = vmax(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// scalar math per arithmetic type
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }   // 1 ulp
+__device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
+__device__ __forceinline__ float exp_r(float x) { return expf(x); }
+__device__ __forceinline__ double exp_r(double x) { return exp(x); }
+template <typename R> __device__ __forceinline__ R neg_inf() { return -(R)INFINITY; }
+
+// Running product with an integer exponent on the side: prod * 2^expo, renormalised now and
+// then so that thousands of per-frame scales can be multiplied without a log per frame.
+struct ScaledProduct {
+    double mant = 1.0;
+    long long expo = 0;
+    __device__ __forceinline__ void mul(double s) { mant *= s; }
+    __device__ __forceinline__ void renorm() {
+        int e;
+        mant = frexp(mant, &e);
+        expo += e;
+    }
+    __device__ __forceinline__ double log_value() const {
+        return log(mant) + (double)expo * 0.69314718055994530942;
+    }
+};
+
+// Block-wide sum of one double per thread through LDS (blockDim.x multiple of 64, <= 1024).
+__device__ __forceinline__ double block_sum(double v, double* lds /* >= 16 doubles */) {
+    v = allreduce_sum<64>(v);
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) lds[wave] = v;
+    __syncthreads();
+    double tot = 0.0;
+    for (int w = 0; w < nw; ++w) tot += lds[w];
+    return tot;
+}
+
+}  // namespace vbx

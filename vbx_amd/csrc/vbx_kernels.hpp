@@ -1,0 +1,524 @@
+// vbx_kernels.hpp -- HIP kernels of one VB iteration (reference: VBx/VBx.py:87-125).
+//
+// HBM layout of a batch (all recordings share the padded widths Sp = 16*NT and Dp):
+//   rho    [sum_T][Dp]  R    x-vectors scaled by sqrt(Phi)           (VBx.py:89)
+//   gamma  [sum_T][Sp]  R    responsibilities (rows sum to 1)        (VBx.py:99)
+//   bmat   [sum_T][Sp]  R    exp(log_p - rowmax): shifted likelihoods
+//   mrow   [sum_T]      R    rowmax of log_p without the G term
+//   ahat   [sum_T][Sp]  R    normalised forward vectors
+//   bhat   [sum_T][Sp]  R    scaled backward vectors
+//   alpha, invL [n_rec][Sp][Dp] R   speaker posteriors                (VBx.py:95-96)
+//   pi     [n_rec][Sp]  f64  speaker priors                          (VBx.py:104)
+// Padded speakers (s >= S) carry gamma = b = 0 and never receive mass; padded feature
+// dims (d >= D) carry rho = 0 and Phi = 0, which makes invL = 1, alpha = 0 and every
+// contribution to the bias and the ELBO vanish.
+#pragma once
+#include "vbx_device.hpp"
+
+namespace vbx {
+
+struct RecDesc {
+    long long row0;   // first frame row of this recording in the frame-major arrays
+    int T, S;         // frames, speakers (unpadded)
+    int tile0;        // first workgroup tile
+    int ntiles;       // tiles of kTileFrames frames
+    int has_model;    // alpha/invL supplied by the caller: skip the first M-step (VBx.py:94)
+    int pad_;
+    double lp, Fa, Fb;
+    double gsum;      // sum_t G_t (VBx.py:87)
+};
+
+struct RecState {
+    double tll;        // total forward log-likelihood without the G term (VBx.py:173)
+    double elbo_prev;
+    int n_iters;
+    int done;
+    int warned;
+    int pad_;
+};
+
+template <typename R> struct BatchView {
+    int n_rec, Sp, Dp, D, max_iters;
+    int ntiles_total;
+    const RecDesc* recs;
+    RecState* state;
+    const int* tile_rec;   // [ntiles_total]
+    const int* tile_t0;    // [ntiles_total]
+    const double* phi;     // [n_rec][Dp]
+    R* rho;
+    R* gamma;
+    R* bmat;
+    R* mrow;
+    R* ahat;
+    R* bhat;
+    R* alpha;              // [n_rec][Sp][Dp]
+    R* invL;
+    R* bias;               // [n_rec][Sp]   -0.5 * sum_d (invL + alpha^2) Phi
+    double* emodel;        // [n_rec][Sp]   sum_d (log invL - invL - alpha^2 + 1)
+    double* pi;            // [n_rec][Sp]
+    const double* ip;      // [n_rec][Sp]   initial-state probabilities; aliases pi in VBx() (VBx.py:99)
+    R* fw_scale;           // [sum_T] or null: s_t = sum(a_t)   (only the step-level API asks for these)
+    R* bw_scale;           // [sum_T] or null: q_t = sum_j c_j e_{t+1}[j]
+    R* mpart;              // [ntiles_total][Sp][Dp]   gamma^T rho per tile
+    R* npart;              // [ntiles_total][Sp]       sum_t gamma per tile
+    double* epart;         // [ntiles_total][Sp]       "entered" statistic per tile (VBx.py:101-103)
+    double* Li;            // [n_rec][max_iters]
+    double epsilon;
+};
+
+// =======================================================================================
+// prep: rho = X * sqrt(Phi), G_t = -0.5 (|x_t|^2 + D log 2pi)              VBx.py:87-89
+// grid = tiles of the recording, block = 256.  One wavefront per frame row.
+// =======================================================================================
+template <typename R, typename XT>
+__global__ __launch_bounds__(256) void prep_kernel(const XT* __restrict__ X, const double* __restrict__ sqrt_phi,
+                                                   R* __restrict__ rho, double* __restrict__ gtile,
+                                                   int T, int D, int Dp) {
+    __shared__ double lds[16];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t0 = blockIdx.x * kTileFrames;
+    double gacc = 0.0;
+    for (int f = wave; f < kTileFrames; f += 4) {
+        const int t = t0 + f;
+        const bool ok = t < T;
+        double ss = 0.0;
+        for (int d = lane; d < Dp; d += 64) {
+            const double x = (ok && d < D) ? (double)X[(long long)t * D + d] : 0.0;
+            ss += x * x;
+            if (ok) rho[(long long)t * Dp + d] = (R)(x * sqrt_phi[d]);
+        }
+        ss = allreduce_sum<64>(ss);
+        if (ok) gacc += -0.5 * (ss + (double)D * 1.8378770664093454836);   // log(2 pi)
+    }
+    const double tot = block_sum(lane == 0 ? gacc : 0.0, lds);
+    if (threadIdx.x == 0) gtile[blockIdx.x] = tot;
+}
+
+// =======================================================================================
+// M-step accumulation: C[s][d] = sum_t gamma[t][s] rho[t][d] for one tile of frames and one
+// 32-column slab of d, on MFMA 16x16x4 (A = gamma^T fragment, B = rho fragment).      VBx.py:96
+// grid = (ntiles_total, Dp/32), block = 64 (one wavefront).
+//   k-step = 4 frames: lane group g = lane>>4 supplies frame k0+g.
+//   B fragment: lane (j,g) loads rho[k0+g][d0+2j .. d0+2j+1] as one 8/16-byte load; the two
+//   values feed two N-tiles whose column j means d = d0 + 2j + {0,1} (free relabelling of N).
+// =======================================================================================
+template <typename R, int NT>
+__global__ __launch_bounds__(64) void mstep_acc_kernel(BatchView<R> bt) {
+    using M = Mfma16<R>;
+    using acc_t = typename M::acc_t;
+    using R2 = typename Vec<R>::v2;
+    const int tile = blockIdx.x;
+    const int rec = bt.tile_rec[tile];
+    if (bt.state[rec].done) return;
+    const RecDesc rd = bt.recs[rec];
+    const int Sp = bt.Sp, Dp = bt.Dp;
+    const int t0 = bt.tile_t0[tile];
+    const int tend = min(t0 + kTileFrames, rd.T);
+    const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
+    const int d0 = blockIdx.y * 32;
+    const R* __restrict__ gam = bt.gamma + rd.row0 * Sp;
+    const R* __restrict__ rho = bt.rho + rd.row0 * Dp;
+
+    acc_t acc[NT][2];
+    R nsum[NT];
+#pragma unroll
+    for (int mu = 0; mu < NT; ++mu) {
+        acc[mu][0] = acc_t{0, 0, 0, 0};
+        acc[mu][1] = acc_t{0, 0, 0, 0};
+        nsum[mu] = 0;
+    }
+#pragma unroll 4
+    for (int k0 = t0; k0 < tend; k0 += 4) {
+        const int t = k0 + g;
+        const bool ok = t < tend;
+        R2 b = R2{0, 0};
+        if (ok) b = *reinterpret_cast<const R2*>(rho + (long long)t * Dp + d0 + 2 * i);
+#pragma unroll
+        for (int mu = 0; mu < NT; ++mu) {
+            const R a = ok ? gam[(long long)t * Sp + 16 * mu + i] : (R)0;
+            nsum[mu] += a;
+            acc[mu][0] = M::mma(a, b.x, acc[mu][0]);
+            acc[mu][1] = M::mma(a, b.y, acc[mu][1]);
+        }
+    }
+    R* __restrict__ part = bt.mpart + (long long)tile * Sp * Dp;
+#pragma unroll
+    for (int mu = 0; mu < NT; ++mu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int s = 16 * mu + M::row(lane, r);
+            R2 v = R2{acc[mu][0][r], acc[mu][1][r]};
+            *reinterpret_cast<R2*>(part + (long long)s * Dp + d0 + 2 * i) = v;
+        }
+    }
+    if (blockIdx.y == 0) {
+#pragma unroll
+        for (int mu = 0; mu < NT; ++mu) {
+            R v = nsum[mu];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (g == 0) bt.npart[(long long)tile * Sp + 16 * mu + i] = v;
+        }
+    }
+}
+
+// =======================================================================================
+// M-step finalisation for one speaker row: N_s, invL, alpha (VBx.py:95-96), the per-speaker
+// bias of eq. 23 (VBx.py:97) and the speaker's share of the ELBO model term (VBx.py:100).
+// Tile partials are combined in f64.  grid = (n_rec, Sp), block = 128.
+// =======================================================================================
+template <typename R>
+__global__ __launch_bounds__(128) void mstep_fin_kernel(BatchView<R> bt) {
+    __shared__ double lds[16];
+    const int rec = blockIdx.x, s = blockIdx.y;
+    const RecState st = bt.state[rec];
+    if (st.done) return;
+    const RecDesc rd = bt.recs[rec];
+    const int Sp = bt.Sp, Dp = bt.Dp;
+    const bool given = (st.n_iters == 0 && rd.has_model);
+    const double fafb = rd.Fa / rd.Fb;
+    double N = 0.0;
+    if (!given)
+        for (int tl = 0; tl < rd.ntiles; ++tl) N += (double)bt.npart[(long long)(rd.tile0 + tl) * Sp + s];
+    const long long sd = ((long long)rec * Sp + s) * Dp;
+    double bsum = 0.0, esum = 0.0;
+    for (int d = threadIdx.x; d < Dp; d += blockDim.x) {
+        const double phi = bt.phi[(long long)rec * Dp + d];
+        double il, al;
+        if (given) {
+            il = (double)bt.invL[sd + d];
+            al = (double)bt.alpha[sd + d];
+        } else {
+            double C = 0.0;
+            for (int tl = 0; tl < rd.ntiles; ++tl)
+                C += (double)bt.mpart[((long long)(rd.tile0 + tl) * Sp + s) * Dp + d];
+            il = 1.0 / (1.0 + fafb * N * phi);
+            al = fafb * il * C;
+            const R ilr = (R)il, alr = (R)al;      // the values every later kernel sees
+            bt.invL[sd + d] = ilr;
+            bt.alpha[sd + d] = alr;
+            il = (double)ilr;
+            al = (double)alr;
+        }
+        bsum += (il + al * al) * phi;
+        if (s < rd.S && d < bt.D) esum += log(il) - il - al * al + 1.0;
+    }
+    bsum = block_sum(bsum, lds);
+    esum = block_sum(esum, lds);
+    if (threadIdx.x == 0) {
+        bt.bias[(long long)rec * Sp + s] = (R)(-0.5 * bsum);
+        bt.emodel[(long long)rec * Sp + s] = esum;
+    }
+}
+
+// =======================================================================================
+// Per-frame speaker log-likelihoods on MFMA 16x16x4:                         VBx.py:97
+//   l[t][s] = Fa * (rho_t . alpha_s + bias_s)      (the per-frame G term is left out: it
+//   cancels in gamma and pi and enters the ELBO once as Fa * sum_t G_t)
+// epilogue: m_t = max_s l, b = exp(l - m_t) -> bmat, mrow.
+// grid = ntiles_total, block = 256: wave w owns frames [t0+32w, t0+32w+32) = 2 M-tiles.
+//   K is relabelled so that lane group g supplies k = 16q + 4g + r for MFMA r of block q:
+//   one 16-byte load per lane feeds four MFMAs, for A (rho rows) and B (alpha rows) alike.
+// =======================================================================================
+template <typename R, int NT>
+__global__ __launch_bounds__(256) void loglik_kernel(BatchView<R> bt, R* __restrict__ lraw) {
+    using M = Mfma16<R>;
+    using acc_t = typename M::acc_t;
+    using R4 = typename Vec<R>::v4;
+    const int tile = blockIdx.x;
+    const int rec = bt.tile_rec[tile];
+    if (bt.state[rec].done) return;
+    const RecDesc rd = bt.recs[rec];
+    const int Sp = bt.Sp, Dp = bt.Dp;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    const int f0 = bt.tile_t0[tile] + 32 * wave;
+    const R* __restrict__ rho = bt.rho + rd.row0 * Dp;
+    const R* __restrict__ alpha = bt.alpha + (long long)rec * Sp * Dp;
+
+    acc_t acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = acc_t{0, 0, 0, 0};
+    const int rowA0 = f0 + i, rowA1 = f0 + 16 + i;
+    const bool ok0 = rowA0 < rd.T, ok1 = rowA1 < rd.T;
+    for (int q = 0; q < Dp / 16; ++q) {
+        const int kk = 16 * q + 4 * g;
+        R4 a0 = R4{0, 0, 0, 0}, a1 = R4{0, 0, 0, 0};
+        if (ok0) a0 = *reinterpret_cast<const R4*>(rho + (long long)rowA0 * Dp + kk);
+        if (ok1) a1 = *reinterpret_cast<const R4*>(rho + (long long)rowA1 * Dp + kk);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const R4 b = *reinterpret_cast<const R4*>(alpha + (long long)(16 * n + i) * Dp + kk);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[0][n] = M::mma(a0[r], b[r], acc[0][n]);
+                acc[1][n] = M::mma(a1[r], b[r], acc[1][n]);
+            }
+        }
+    }
+    const R Fa = (R)rd.Fa;
+    R biasv[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) biasv[n] = bt.bias[(long long)rec * Sp + 16 * n + i];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int frame = f0 + 16 * m + M::row(lane, r);
+            R v[NT];
+            R mx = neg_inf<R>();
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int s = 16 * n + i;
+                v[n] = (s < rd.S) ? Fa * (acc[m][n][r] + biasv[n]) : neg_inf<R>();
+                mx = vmax(mx, v[n]);
+            }
+            mx = allreduce_max<16>(mx);
+            if (frame < rd.T) {
+                const long long cell = (rd.row0 + frame) * Sp;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    bt.bmat[cell + 16 * n + i] = exp_r(v[n] - mx);
+                    if (lraw) lraw[cell + 16 * n + i] = v[n];
+                }
+                if (i == 0) bt.mrow[rd.row0 + frame] = mx;
+            }
+        }
+    }
+}
+
+// =======================================================================================
+// Sequential forward-backward (VBX_FB_SEQUENTIAL): wave 0 walks forward, wave 1 backward,
+// lane = speaker (NREG registers per lane when Sp > 64).                VBx.py:146-175
+// With c_j = (1-lp) pi_j + 1e-8 the matrix (tr + 1e-8) of VBx.py:158 is lp*I + 1 c^T, so
+//   a_t  = b_t * (lp * ahat_{t-1} + c)            ahat = a / sum(a)          (VBx.py:167-168)
+//   be_t = (lp * e + q) / q,  e = b_{t+1} * be_{t+1},  q = sum_j c_j e_j     (VBx.py:170-171)
+// One cross-lane reduction per step.  tll = sum_t log sum(a_t) + sum_t m_t (VBx.py:173).
+// grid = n_rec, block = 128.
+// =======================================================================================
+template <typename R, int NREG, int U>
+struct RowBlock {
+    R v[U][NREG];
+};
+
+template <typename R, int NREG>
+__global__ __launch_bounds__(128) void fb_seq_kernel(BatchView<R> bt) {
+    constexpr int U = 8;
+    const int rec = blockIdx.x;
+    if (bt.state[rec].done) return;
+    const RecDesc rd = bt.recs[rec];
+    const int Sp = bt.Sp, T = rd.T;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const R lp = (R)rd.lp;
+    const R* __restrict__ B = bt.bmat + rd.row0 * Sp;
+    R c[NREG], p0[NREG];
+    bool act[NREG];
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) {
+        const int j = lane + 64 * r;
+        act[r] = j < Sp;
+        const double pj = (j < rd.S) ? bt.pi[(long long)rec * Sp + j] : 0.0;
+        c[r] = (j < rd.S) ? (R)((1.0 - rd.lp) * pj + 1e-8) : (R)0;
+        p0[r] = (j < rd.S) ? (R)(bt.ip[(long long)rec * Sp + j] + 1e-8) : (R)0;
+    }
+    auto load_rows = [&](RowBlock<R, NREG, U>& blk, int tfirst, int dir) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = tfirst + dir * u;
+#pragma unroll
+            for (int r = 0; r < NREG; ++r)
+                blk.v[u][r] = (t >= 0 && t < T && act[r]) ? B[(long long)t * Sp + lane + 64 * r] : (R)0;
+        }
+    };
+
+    if (wave == 0) {
+        // ------------------------------------------------------------------ forward
+        R* __restrict__ A = bt.ahat + rd.row0 * Sp;
+        R ah[NREG];
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) ah[r] = 0;
+        ScaledProduct sp;
+        auto run = [&](const RowBlock<R, NREG, U>& blk, int tfirst) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = tfirst + u;
+                if (t >= T) break;        // wave-uniform
+                R a[NREG];
+                R s = 0;
+#pragma unroll
+                for (int r = 0; r < NREG; ++r) {
+                    a[r] = (t == 0) ? blk.v[u][r] * p0[r] : blk.v[u][r] * (lp * ah[r] + c[r]);
+                    s += a[r];
+                }
+                s = allreduce_sum<64>(s);
+                const R inv = fast_rcp(s);
+#pragma unroll
+                for (int r = 0; r < NREG; ++r) {
+                    ah[r] = a[r] * inv;
+                    if (act[r]) A[(long long)t * Sp + lane + 64 * r] = ah[r];
+                }
+                sp.mul((double)s);
+                if ((t & 15) == 15) sp.renorm();
+                if (bt.fw_scale && lane == 0) bt.fw_scale[rd.row0 + t] = s;
+            }
+        };
+        RowBlock<R, NREG, U> b0, b1;
+        load_rows(b0, 0, 1);
+        for (int tb = 0; tb < T; tb += 2 * U) {
+            load_rows(b1, tb + U, 1);
+            run(b0, tb);
+            load_rows(b0, tb + 2 * U, 1);
+            run(b1, tb + U);
+        }
+        double msum = 0.0;
+        for (int t = lane; t < T; t += 64) msum += (double)bt.mrow[rd.row0 + t];
+        msum = allreduce_sum<64>(msum);
+        sp.renorm();
+        if (lane == 0) bt.state[rec].tll = sp.log_value() + msum;
+    } else {
+        // ------------------------------------------------------------------ backward
+        R* __restrict__ Bh = bt.bhat + rd.row0 * Sp;
+        R bh[NREG];
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) {
+            bh[r] = 1;
+            if (act[r]) Bh[(long long)(T - 1) * Sp + lane + 64 * r] = bh[r];
+        }
+        // block rows are b[t+1] for t = tfirst, tfirst-1, ...
+        auto run = [&](const RowBlock<R, NREG, U>& blk, int tfirst) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = tfirst - u;
+                if (t < 0) break;         // wave-uniform
+                R e[NREG];
+                R q = 0;
+#pragma unroll
+                for (int r = 0; r < NREG; ++r) {
+                    e[r] = blk.v[u][r] * bh[r];
+                    q += c[r] * e[r];
+                }
+                q = allreduce_sum<64>(q);
+                const R sc = lp * fast_rcp(q);
+                if (bt.bw_scale && lane == 0) bt.bw_scale[rd.row0 + t] = q;
+#pragma unroll
+                for (int r = 0; r < NREG; ++r) {
+                    bh[r] = sc * e[r] + (R)1;
+                    if (act[r]) Bh[(long long)t * Sp + lane + 64 * r] = bh[r];
+                }
+            }
+        };
+        RowBlock<R, NREG, U> b0, b1;
+        load_rows(b0, T - 1, -1);            // rows T-1, T-2, ... serve t = T-2, T-3, ...
+        for (int tb = T - 2; tb >= 0; tb -= 2 * U) {
+            load_rows(b1, tb + 1 - U, -1);
+            run(b0, tb);
+            load_rows(b0, tb + 1 - 2 * U, -1);
+            run(b1, tb - U);
+        }
+    }
+}
+
+// =======================================================================================
+// Posteriors and prior statistics from ahat/bhat:                 VBx.py:101-103, 174
+//   gamma_t = ahat_t * bhat_t / sum(ahat_t * bhat_t)
+//   entered_j += gamma_t[j] / (lp * ahat_{t-1}[j] + c_j)   for t >= 1   
+// grid = ntiles_total, block = 256.  A frame occupies W = min(Sp, 64) adjacent lanes.
+// =======================================================================================
+template <typename R, int SP>
+__global__ __launch_bounds__(256) void post_kernel(BatchView<R> bt) {
+    constexpr int W = SP < 64 ? SP : 64;
+    constexpr int FPW = 64 / W;        // frames per wavefront pass
+    constexpr int NREG = SP / W;
+    __shared__ double ent_lds[SP];
+    const int tile = blockIdx.x;
+    const int rec = bt.tile_rec[tile];
+    if (bt.state[rec].done) return;
+    const RecDesc rd = bt.recs[rec];
+    const int t0 = bt.tile_t0[tile];
+    const int tend = min(t0 + kTileFrames, rd.T);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int sub = lane / W, jl = lane % W;
+    const R lp = (R)rd.lp;
+    const R* __restrict__ A = bt.ahat + rd.row0 * SP;
+    const R* __restrict__ Bh = bt.bhat + rd.row0 * SP;
+    R* __restrict__ G = bt.gamma + rd.row0 * SP;
+    for (int j = threadIdx.x; j < SP; j += 256) ent_lds[j] = 0.0;
+    __syncthreads();
+    R c[NREG];
+    double ent[NREG];
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) {
+        const int j = jl + W * r;
+        c[r] = (j < rd.S) ? (R)((1.0 - rd.lp) * bt.pi[(long long)rec * SP + j] + 1e-8) : (R)1;
+        ent[r] = 0.0;
+    }
+    for (int fb = t0 + wave * FPW; fb < t0 + kTileFrames; fb += 4 * FPW) {
+        const int f = fb + sub;
+        const bool ok = f < tend;
+        R g[NREG], ap[NREG];
+        R sum = 0;
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) {
+            const int j = jl + W * r;
+            const R a = ok ? A[(long long)f * SP + j] : (R)0;
+            const R b = ok ? Bh[(long long)f * SP + j] : (R)0;
+            ap[r] = (ok && f >= 1) ? A[(long long)(f - 1) * SP + j] : (R)0;
+            g[r] = a * b;
+            sum += g[r];
+        }
+        sum = allreduce_sum<W>(sum);
+        const R inv = ok ? (R)1 / sum : (R)0;
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) {
+            const int j = jl + W * r;
+            const R gm = g[r] * inv;
+            if (ok) G[(long long)f * SP + j] = gm;
+            if (ok && f >= 1 && j < rd.S) ent[r] += (double)(gm / (lp * ap[r] + c[r]));
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) atomicAdd(&ent_lds[jl + W * r], ent[r]);
+    __syncthreads();
+    for (int j = threadIdx.x; j < SP; j += 256) bt.epart[(long long)tile * SP + j] = ent_lds[j];
+}
+
+// =======================================================================================
+// End of an iteration: ELBO (VBx.py:100), pi update (VBx.py:101-104), history (VBx.py:105)
+// and the convergence test (VBx.py:122-125).  grid = n_rec, block = 256 (thread = speaker).
+// =======================================================================================
+template <typename R>
+__global__ __launch_bounds__(256) void iter_fin_kernel(BatchView<R> bt) {
+    __shared__ double lds[16];
+    const int rec = blockIdx.x;
+    RecState st = bt.state[rec];
+    if (st.done) return;
+    const RecDesc rd = bt.recs[rec];
+    const int Sp = bt.Sp, j = threadIdx.x;
+    double pn = 0.0, em = 0.0;
+    if (j < rd.S) {
+        double ent = 0.0;
+        for (int tl = 0; tl < rd.ntiles; ++tl) ent += bt.epart[(long long)(rd.tile0 + tl) * Sp + j];
+        const double pj = bt.pi[(long long)rec * Sp + j];
+        const double g0 = (double)bt.gamma[rd.row0 * Sp + j];
+        pn = g0 + (1.0 - rd.lp) * pj * ent;
+        em = bt.emodel[(long long)rec * Sp + j];
+    }
+    const double tot = block_sum(pn, lds);
+    const double emt = block_sum(em, lds);
+    if (j < Sp) bt.pi[(long long)rec * Sp + j] = pn / tot;
+    if (j == 0) {
+        const double elbo = st.tll + rd.Fa * rd.gsum + 0.5 * rd.Fb * emt;
+        const int it = st.n_iters;
+        if (it < bt.max_iters) bt.Li[(long long)rec * bt.max_iters + it] = elbo;
+        if (it > 0 && elbo - st.elbo_prev < bt.epsilon) {
+            st.done = 1;
+            if (elbo - st.elbo_prev < 0) st.warned = 1;
+        }
+        st.elbo_prev = elbo;
+        st.n_iters = it + 1;
+        bt.state[rec] = st;
+    }
+}
+
+}  // namespace vbx
