@@ -80,6 +80,58 @@ def test_forward_backward_known_answers(ctx, fb_cases, precision):
         np.testing.assert_allclose(lbw[fin], c['lbw'][fin], rtol=0, atol=ltol * 10, err_msg=name)
 
 
+@pytest.mark.parametrize('precision', ['fp64', 'fp32'])
+def test_chunked_scan_equals_sequential_and_reference(ctx, fb_cases, precision):
+    """The exact chunked parallel scan (scan1/2/3) against the one-wavefront walk and the reference."""
+    from vbx_amd import _capi
+    from vbx_amd.synth import make_lls
+    tol = 1e-9 if precision == 'fp64' else 2e-5
+    cases = {k: (c['lls'], c['pi'], float(c['loopProb']), c['post'], float(c['tll'])) for k, c in fb_cases.items()
+             if c['lls'].shape[1] <= 64}
+    for T, S, lp, seed in ((1000, 30, 0.99, 7), (2049, 10, 0.9, 8), (700, 50, 0.35, 9), (513, 64, 0.9, 10),
+                           (385, 16, 0.0, 11), (300, 3, 1.0, 12)):
+        lls, pi = make_lls(T, S, seed=seed, scale=6.0)
+        post, tll, _ = _orc().fb_linear(lls, pi, lp)
+        cases[f'big_T{T}_S{S}'] = (lls, pi, lp, post, tll)
+    for name, (lls, pi, lp, post, tll) in cases.items():
+        gs, ts, es, _, _ = ctx.forward_backward(lls, pi, lp, precision=precision, fb_algo=_capi.FB_SEQUENTIAL)
+        gc, tc, ec, _, _ = ctx.forward_backward(lls, pi, lp, precision=precision, fb_algo=_capi.FB_CHUNKED)
+        np.testing.assert_allclose(gc, post, rtol=0, atol=tol, err_msg=name)
+        np.testing.assert_allclose(gc, gs, rtol=0, atol=tol, err_msg=name)
+        np.testing.assert_allclose(tc, tll, rtol=1e-11 if precision == 'fp64' else 2e-6, err_msg=name)
+        np.testing.assert_allclose(ec, es, rtol=tol * 100, atol=tol * 10, err_msg=name)
+
+
+def test_chunked_scan_survives_extreme_dynamic_range(ctx):
+    """Well separated speakers: likelihood ratios of e^-300 between states, exact zeros in b, speaker
+    changes inside and at chunk boundaries -- the power-of-two column rescaling must not lose them."""
+    from vbx_amd import _capi
+    rng = np.random.default_rng(3)
+    T, S = 1500, 12
+    lab = (np.arange(T) // 97) % 5
+    lls = -400.0 * rng.random((T, S)) - 300.0
+    lls[np.arange(T), lab] = -5.0 * rng.random(T)
+    pi = np.ones(S) / S
+    post, tll, ent = _orc().fb_linear(lls, pi, 0.9)
+    for precision, tol in (('fp64', 1e-9), ('fp32', 2e-5)):
+        g, t, e, _, _ = ctx.forward_backward(lls, pi, 0.9, precision=precision, fb_algo=_capi.FB_CHUNKED)
+        assert np.all(np.isfinite(g)) and np.isfinite(t)
+        np.testing.assert_allclose(g, post, rtol=0, atol=tol)
+        np.testing.assert_allclose(t, tll, rtol=1e-10 if precision == 'fp64' else 2e-6)
+
+
+@pytest.mark.parametrize('algo', ['sequential', 'chunked'])
+def test_vbx_same_answer_with_either_scan(synth_cases, monkeypatch, algo):
+    monkeypatch.setenv('VBX_AMD_FB_ALGO', algo)
+    for name in ('soft_T600_S12', 'soft_T1000_S30', 'soft_T700_S50', 'easy_T500_S10', 'two_frames_S4',
+                 'loop1_T250_S5', 'early_stop_T450_S9'):
+        c = synth_cases[name]
+        (gamma, pi, Li, alpha, invL), warned = run_case(c, 'fp64')
+        assert len(Li) == len(c['Li']), (name, algo)
+        np.testing.assert_allclose(gamma, c['gamma'], rtol=0, atol=2e-7, err_msg=name)
+        np.testing.assert_allclose([r[0] for r in Li], c['Li'], rtol=1e-10, err_msg=name)
+
+
 def test_module_level_forward_backward(fb_cases):
     import vbx_amd
     c = fb_cases['fb_T257_S31']

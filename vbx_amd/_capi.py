@@ -182,6 +182,10 @@ class Batch:
         ctx.check(self._lib.vbx_batch_create(ctx._h, self.n, Ta, Sa, self.D, self.precision, self.max_iters,
                                              C.byref(h)), 'vbx_batch_create')
         self._h = h
+        algo = os.environ.get('VBX_AMD_FB_ALGO')          # 'sequential' | 'chunked' (default: auto)
+        if algo:
+            self.set_option(OPT_FB_ALGO, {'auto': FB_AUTO, 'sequential': FB_SEQUENTIAL,
+                                          'chunked': FB_CHUNKED}[algo])
 
     def set_option(self, option: int, value: int):
         self.ctx.check(self._lib.vbx_batch_set_option(self._h, int(option), int(value)), 'vbx_batch_set_option')

@@ -6,6 +6,7 @@
 // (padding to Sp/Dp, f64 -> working precision) -- there is no CPU fallback.
 #include "../../include/vbx_hip.h"
 #include "vbx_kernels.hpp"
+#include "vbx_scan.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -78,6 +79,11 @@ struct vbx_batch {
     double *d_emodel = nullptr, *d_pi = nullptr, *d_epart = nullptr, *d_Li = nullptr;
     double* d_ip = nullptr;                       // step-level API only; VBx() uses pi (VBx.py:99)
     void *d_fw_scale = nullptr, *d_bw_scale = nullptr;   // step-level API only
+    // chunked scan
+    void *d_op = nullptr, *d_fbound = nullptr, *d_gbound = nullptr;
+    int* d_opexp = nullptr;
+    double* d_tllpart = nullptr;
+    bool use_chunked = false;
     void* d_xstage = nullptr;
     size_t xstage_bytes = 0;
     // timing
@@ -100,6 +106,8 @@ struct vbx_batch {
         v.bias = (R*)d_bias; v.emodel = d_emodel; v.pi = d_pi; v.mpart = (R*)d_mpart;
         v.npart = (R*)d_npart; v.epart = d_epart; v.Li = d_Li; v.epsilon = epsilon;
         v.ip = d_ip ? d_ip : d_pi; v.fw_scale = (R*)d_fw_scale; v.bw_scale = (R*)d_bw_scale;
+        v.op = (R*)d_op; v.opexp = d_opexp; v.fbound = (R*)d_fbound; v.gbound = (R*)d_gbound;
+        v.tllpart = use_chunked ? d_tllpart : nullptr;
         return v;
     }
 };
@@ -159,8 +167,33 @@ template <typename R> void launch_loglik(vbx_batch* b, double eps, bool raw) {
                                         b->ctx->stream, v, lraw);)
 }
 
+template <typename R, int SP> void launch_scan(vbx_batch* b, const BatchView<R>& v) {
+    hipStream_t st = b->ctx->stream;
+    {
+        LaunchScope ls(b, VBX_K_FB);
+        hipLaunchKernelGGL((scan1_kernel<R, SP>), dim3(b->ntiles_total, 2), dim3(64), 0, st, v);
+    }
+    {
+        LaunchScope ls(b, VBX_K_FB_AUX);
+        hipLaunchKernelGGL((scan2_kernel<R, SP>), dim3(b->n_rec), dim3(128), 0, st, v);
+    }
+    {
+        LaunchScope ls(b, VBX_K_FB);
+        constexpr int kBlock = 64 * ((2 * SP + 63) / 64);
+        hipLaunchKernelGGL((scan3_kernel<R, SP>), dim3(b->ntiles_total), dim3(kBlock), 0, st, v);
+    }
+}
+
 template <typename R> void launch_fb(vbx_batch* b, double eps) {
     auto v = b->view<R>(eps);
+    if (b->use_chunked) {
+        switch (b->Sp) {
+            case 16: launch_scan<R, 16>(b, v); return;
+            case 32: launch_scan<R, 32>(b, v); return;
+            case 64: launch_scan<R, 64>(b, v); return;
+            default: break;
+        }
+    }
     LaunchScope ls(b, VBX_K_FB);
     const int nreg = std::max(1, b->Sp / 64);
     switch (nreg) {
@@ -208,6 +241,36 @@ void launch_prep(vbx_batch* b, const RecDesc& rd) {
                        b->D, b->Dp);
 }
 
+template <typename T> int dmalloc(vbx_ctx* ctx, T** p, size_t count) {
+    HIPCHK(ctx, hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T)));
+    return VBX_OK;
+}
+int dmalloc_bytes(vbx_ctx* ctx, void** p, size_t bytes) {
+    HIPCHK(ctx, hipMalloc(p, std::max<size_t>(bytes, 16)));
+    return VBX_OK;
+}
+
+// Decide between the sequential walk and the chunked scan, allocating the scan buffers on first use.
+int choose_fb_algo(vbx_batch* b, bool step_api_logs) {
+    int maxtiles = 0;
+    for (auto& rd : b->recs) maxtiles = std::max(maxtiles, rd.ntiles);
+    bool chunked = b->Sp <= 64 && (b->fb_algo == VBX_FB_CHUNKED || (b->fb_algo == VBX_FB_AUTO && maxtiles >= 3));
+    if (step_api_logs) chunked = false;      // lfw/lbw reconstruction uses the sequential kernel's scales
+    if (b->fb_algo == VBX_FB_CHUNKED && b->Sp > 64)
+        FAIL(b->ctx, VBX_ERR_UNSUPPORTED, "chunked scan supports S <= 64 (got padded S = %d)", b->Sp);
+    if (chunked && !b->d_op) {
+        const size_t rs = b->rsize, nt = (size_t)b->ntiles_total, sp = (size_t)b->Sp;
+        int rc = dmalloc_bytes(b->ctx, &b->d_op, nt * 2 * sp * sp * rs);
+        if (rc == VBX_OK) rc = dmalloc(b->ctx, &b->d_opexp, nt * 2 * sp);
+        if (rc == VBX_OK) rc = dmalloc_bytes(b->ctx, &b->d_fbound, nt * sp * rs);
+        if (rc == VBX_OK) rc = dmalloc_bytes(b->ctx, &b->d_gbound, nt * sp * rs);
+        if (rc == VBX_OK) rc = dmalloc(b->ctx, &b->d_tllpart, nt);
+        if (rc != VBX_OK) return rc;
+    }
+    b->use_chunked = chunked;
+    return VBX_OK;
+}
+
 int upload_recs(vbx_batch* b) {
     if (!b->recs_dirty) return VBX_OK;
     HIPCHK(b->ctx, hipMemcpyAsync(b->d_recs, b->recs.data(), sizeof(RecDesc) * b->n_rec, hipMemcpyHostToDevice,
@@ -225,15 +288,6 @@ int collect_profile(vbx_batch* b) {
         b->k_launches[b->ev_pool[i].klass] += 1;
     }
     b->ev_used = 0;
-    return VBX_OK;
-}
-
-template <typename T> int dmalloc(vbx_ctx* ctx, T** p, size_t count) {
-    HIPCHK(ctx, hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T)));
-    return VBX_OK;
-}
-int dmalloc_bytes(vbx_ctx* ctx, void** p, size_t bytes) {
-    HIPCHK(ctx, hipMalloc(p, std::max<size_t>(bytes, 16)));
     return VBX_OK;
 }
 
@@ -311,7 +365,8 @@ int vbx_batch_destroy(vbx_batch* b) {
     void* ptrs[] = {b->d_recs, b->d_state, b->d_tile_rec, b->d_tile_t0, b->d_phi, b->d_sqrt_phi, b->d_gtile,
                     b->d_rho, b->d_gamma, b->d_bmat, b->d_mrow, b->d_ahat, b->d_bhat, b->d_alpha, b->d_invL,
                     b->d_bias, b->d_mpart, b->d_npart, b->d_lraw, b->d_emodel, b->d_pi, b->d_epart, b->d_Li,
-                    b->d_xstage, b->d_ip, b->d_fw_scale, b->d_bw_scale};
+                    b->d_xstage, b->d_ip, b->d_fw_scale, b->d_bw_scale, b->d_op, b->d_fbound, b->d_gbound,
+                    b->d_opexp, b->d_tllpart};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (b->ev_start) (void)hipEventDestroy(b->ev_start);
@@ -533,9 +588,10 @@ int vbx_batch_run(vbx_batch* b, int max_iters, double epsilon) {
     if (max_iters < 0) FAIL(ctx, VBX_ERR_INVALID, "max_iters < 0");
     for (int i = 0; i < b->n_rec; ++i)
         if (!b->is_set[i]) FAIL(ctx, VBX_ERR_STATE, "recording %d has not been set", i);
-    if (b->fb_algo == VBX_FB_CHUNKED) FAIL(ctx, VBX_ERR_UNSUPPORTED, "chunked scan is not built into this library version");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    int rc = upload_recs(b);
+    int rc = choose_fb_algo(b, false);
+    if (rc != VBX_OK) return rc;
+    rc = upload_recs(b);
     if (rc != VBX_OK) return rc;
     std::fill(b->k_ms, b->k_ms + VBX_K_COUNT, 0.0);
     std::fill(b->k_launches, b->k_launches + VBX_K_COUNT, 0);
@@ -682,7 +738,9 @@ int fb_step_impl(vbx_batch* b, int64_t T, int32_t S, const double* lls, double* 
         if (rc2 == VBX_OK) rc2 = dmalloc_bytes(ctx, &b->d_bw_scale, (size_t)T * sizeof(R));
         if (rc2 != VBX_OK) return rc2;
     }
-    int rc = upload_recs(b);
+    int rc = choose_fb_algo(b, want_logs);
+    if (rc != VBX_OK) return rc;
+    rc = upload_recs(b);
     if (rc != VBX_OK) return rc;
     launch_fb<R>(b, 0.0);
     launch_post<R>(b, 0.0);
@@ -690,6 +748,12 @@ int fb_step_impl(vbx_batch* b, int64_t T, int32_t S, const double* lls, double* 
     HIPCHK(ctx, hipGetLastError());
     RecState st;
     HIPCHK(ctx, hipMemcpy(&st, b->d_state, sizeof st, hipMemcpyDeviceToHost));
+    if (b->use_chunked) {
+        std::vector<double> tp((size_t)b->ntiles_total);
+        HIPCHK(ctx, hipMemcpy(tp.data(), b->d_tllpart, sizeof(double) * tp.size(), hipMemcpyDeviceToHost));
+        st.tll = 0.0;
+        for (double v : tp) st.tll += v;
+    }
     if (tll) *tll = st.tll;
     if (gamma) {
         rc = get_result_impl<R>(b, 0, gamma, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr);

@@ -64,6 +64,12 @@ template <typename R> struct BatchView {
     double* epart;         // [ntiles_total][Sp]       "entered" statistic per tile (VBx.py:101-103)
     double* Li;            // [n_rec][max_iters]
     double epsilon;
+    // chunked scan (VBX_FB_CHUNKED): one chunk = one tile of kTileFrames frames
+    R* op;                 // [ntiles_total][2][Sp][Sp]  transfer-operator columns (dir 0 fwd, 1 bwd)
+    int* opexp;            // [ntiles_total][2][Sp]      power-of-two exponent of every column
+    R* fbound;             // [ntiles_total][Sp]  forward vector entering the chunk (ahat[t0-1], any scale)
+    R* gbound;             // [ntiles_total][Sp]  backward vector at the chunk's last frame (any scale)
+    double* tllpart;       // [ntiles_total] or null: sum over the chunk of log s_t + m_t
 };
 
 // =======================================================================================
@@ -178,8 +184,12 @@ __global__ __launch_bounds__(128) void mstep_fin_kernel(BatchView<R> bt) {
     const bool given = (st.n_iters == 0 && rd.has_model);
     const double fafb = rd.Fa / rd.Fb;
     double N = 0.0;
-    if (!given)
-        for (int tl = 0; tl < rd.ntiles; ++tl) N += (double)bt.npart[(long long)(rd.tile0 + tl) * Sp + s];
+    if (!given) {
+        double part = 0.0;
+        for (int tl = threadIdx.x; tl < rd.ntiles; tl += blockDim.x)
+            part += (double)bt.npart[(long long)(rd.tile0 + tl) * Sp + s];
+        N = block_sum(part, lds);
+    }
     const long long sd = ((long long)rec * Sp + s) * Dp;
     double bsum = 0.0, esum = 0.0;
     for (int d = threadIdx.x; d < Dp; d += blockDim.x) {
@@ -189,9 +199,20 @@ __global__ __launch_bounds__(128) void mstep_fin_kernel(BatchView<R> bt) {
             il = (double)bt.invL[sd + d];
             al = (double)bt.alpha[sd + d];
         } else {
+            // eight independent loads in flight per thread (a single dependent chain of ~80 L2 round
+            // trips cost 45 us in the first version of this kernel)
             double C = 0.0;
-            for (int tl = 0; tl < rd.ntiles; ++tl)
-                C += (double)bt.mpart[((long long)(rd.tile0 + tl) * Sp + s) * Dp + d];
+            const R* __restrict__ mp = bt.mpart + ((long long)rd.tile0 * Sp + s) * Dp + d;
+            const long long stride = (long long)Sp * Dp;
+            int tl = 0;
+            for (; tl + 8 <= rd.ntiles; tl += 8) {
+                R v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = mp[(long long)(tl + u) * stride];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) C += (double)v[u];
+            }
+            for (; tl < rd.ntiles; ++tl) C += (double)mp[(long long)tl * stride];
             il = 1.0 / (1.0 + fafb * N * phi);
             al = fafb * il * C;
             const R ilr = (R)il, alr = (R)al;      // the values every later kernel sees
@@ -490,15 +511,25 @@ __global__ __launch_bounds__(256) void post_kernel(BatchView<R> bt) {
 template <typename R>
 __global__ __launch_bounds__(256) void iter_fin_kernel(BatchView<R> bt) {
     __shared__ double lds[16];
+    __shared__ double ent_sh[256];
     const int rec = blockIdx.x;
     RecState st = bt.state[rec];
     if (st.done) return;
     const RecDesc rd = bt.recs[rec];
     const int Sp = bt.Sp, j = threadIdx.x;
+    // "entered" statistic: thread (slot, state) sums tiles slot, slot+nslot, ... ; Sp divides 256
+    const int nslot = 256 / Sp, slot = threadIdx.x / Sp, sj = threadIdx.x % Sp;
+    double part = 0.0;
+    for (int tl = slot; tl < rd.ntiles; tl += nslot) part += bt.epart[(long long)(rd.tile0 + tl) * Sp + sj];
+    ent_sh[threadIdx.x] = part;
+    double tpart = 0.0;
+    if (bt.tllpart)
+        for (int tl = threadIdx.x; tl < rd.ntiles; tl += 256) tpart += bt.tllpart[rd.tile0 + tl];
+    __syncthreads();
     double pn = 0.0, em = 0.0;
     if (j < rd.S) {
         double ent = 0.0;
-        for (int tl = 0; tl < rd.ntiles; ++tl) ent += bt.epart[(long long)(rd.tile0 + tl) * Sp + j];
+        for (int q = 0; q < nslot; ++q) ent += ent_sh[q * Sp + j];
         const double pj = bt.pi[(long long)rec * Sp + j];
         const double g0 = (double)bt.gamma[rd.row0 * Sp + j];
         pn = g0 + (1.0 - rd.lp) * pj * ent;
@@ -506,15 +537,17 @@ __global__ __launch_bounds__(256) void iter_fin_kernel(BatchView<R> bt) {
     }
     const double tot = block_sum(pn, lds);
     const double emt = block_sum(em, lds);
+    const double tll = bt.tllpart ? block_sum(tpart, lds) : st.tll;
     if (j < Sp) bt.pi[(long long)rec * Sp + j] = pn / tot;
     if (j == 0) {
-        const double elbo = st.tll + rd.Fa * rd.gsum + 0.5 * rd.Fb * emt;
+        const double elbo = tll + rd.Fa * rd.gsum + 0.5 * rd.Fb * emt;
         const int it = st.n_iters;
         if (it < bt.max_iters) bt.Li[(long long)rec * bt.max_iters + it] = elbo;
         if (it > 0 && elbo - st.elbo_prev < bt.epsilon) {
             st.done = 1;
             if (elbo - st.elbo_prev < 0) st.warned = 1;
         }
+        st.tll = tll;
         st.elbo_prev = elbo;
         st.n_iters = it + 1;
         bt.state[rec] = st;

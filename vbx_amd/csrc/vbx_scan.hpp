@@ -1,0 +1,269 @@
+// vbx_scan.hpp -- exact chunked parallel scan for the forward-backward recursion.
+//
+// reference: VBx/VBx.py:146-175 (forward_backward).  With c_j = (1-lp) pi_j + 1e-8 the matrix
+// (tr + 1e-8) of VBx.py:158 is  lp*I + 1 c^T,  so one frame acts on the forward vector as
+//     a_t     = M_t a_{t-1},        M_t  = diag(b_t) (lp*I + c 1^T)               (VBx.py:167-168)
+// and on the backward vector as
+//     be_{t-1} = Mt_t be_t,         Mt_t = (lp*I + 1 c^T) diag(b_t)               (VBx.py:170-171)
+// Both are linear, so T frames are cut into chunks (one chunk = one tile of kTileFrames frames)
+// and the 2T-step dependency chain becomes
+//   scan1  per chunk, all chunks in parallel: the S x S transfer operators
+//             F_k = M_{t1-1} ... M_{t0}   and   B_k = Mt_{t0} ... Mt_{t1-1}
+//          one operator column per lane (group), the column lives in registers, every sum over
+//          states is in-lane; columns are rescaled by exact powers of two (exponent kept aside).
+//   scan2  per recording: K-1 sequential mat-vecs give the vectors at every chunk boundary.
+//   scan3  per chunk, all chunks in parallel: re-run the chunk from its true boundary vectors,
+//          lane = speaker, one cross-lane reduction per frame; writes ahat, bhat and the chunk's
+//          share of the total log-likelihood.
+// The result is the same recursion in a different association order -- no approximation.
+#pragma once
+#include "vbx_kernels.hpp"
+
+namespace vbx {
+
+__device__ __forceinline__ int exponent_of(float v) { return __builtin_amdgcn_frexp_expf(v); }
+__device__ __forceinline__ int exponent_of(double v) { return __builtin_amdgcn_frexp_exp(v); }
+__device__ __forceinline__ float scale2(float v, int e) { return __builtin_amdgcn_ldexpf(v, e); }
+__device__ __forceinline__ double scale2(double v, int e) { return __builtin_amdgcn_ldexp(v, e); }
+
+// sum over the PH adjacent lanes that share one operator column (PH = 1, 2 or 4)
+template <int PH, typename R> __device__ __forceinline__ R column_sum(R v) {
+    if (PH >= 2) v += dpp_mov<0xB1>(v);
+    if (PH >= 4) v += dpp_mov<0x4E>(v);
+    return v;
+}
+
+// =======================================================================================
+// scan1: transfer operators of one chunk.  grid = (ntiles_total, 2 directions), block = 64.
+// lane = (column, part): PH = 64/SP lanes share a column, each holds NR = SP/PH states.
+// =======================================================================================
+template <typename R, int SP>
+__global__ __launch_bounds__(64) void scan1_kernel(BatchView<R> bt) {
+    constexpr int PH = 64 / SP;
+    constexpr int NR = SP / PH;
+    using R4 = typename Vec<R>::v4;
+    __shared__ __attribute__((aligned(16))) R btile[kTileFrames * SP];
+    const int tile = blockIdx.x, dir = blockIdx.y;
+    const int rec = bt.tile_rec[tile];
+    if (bt.state[rec].done) return;
+    const RecDesc rd = bt.recs[rec];
+    const int t0 = bt.tile_t0[tile];
+    const int len = min(kTileFrames, rd.T - t0);
+    const int lane = threadIdx.x;
+    // stage the chunk's rows of b in LDS (coalesced 16-byte loads)
+    {
+        const R4* __restrict__ src = reinterpret_cast<const R4*>(bt.bmat + (rd.row0 + t0) * SP);
+        R4* dst = reinterpret_cast<R4*>(btile);
+        for (int q = lane; q < len * SP / 4; q += 64) dst[q] = src[q];
+    }
+    __syncthreads();
+    const int col = lane / PH, j0 = (lane % PH) * NR;
+    const R lp = (R)rd.lp;
+    R x[NR], c[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int j = j0 + r;
+        x[r] = (j == col) ? (R)1 : (R)0;
+        c[r] = (j < rd.S) ? (R)((1.0 - rd.lp) * bt.pi[(long long)rec * SP + j] + 1e-8) : (R)0;
+    }
+    int expo = 0;
+    if (dir == 0) {
+        // forward: x <- b_t * (lp*x + c*sum(x)),  t = t0 .. t0+len-1   (frame 0 of the recording only
+        // applies b_0: the initial vector ip + 1e-8 of VBx.py:163 is fed in by scan2)
+        for (int step = 0; step < len; ++step) {
+            const R* brow = btile + step * SP + j0;
+            R sig = 0;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) sig += x[r];
+            sig = column_sum<PH>(sig);
+            const int e = sig > (R)0 ? exponent_of(sig) : 0;
+            expo += e;
+            const bool first = (t0 + step == 0);
+            const R lps = first ? scale2((R)1, -e) : scale2(lp, -e);
+            const R sgs = first ? (R)0 : scale2(sig, -e);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) x[r] = brow[r] * (lps * x[r] + c[r] * sgs);
+        }
+    } else {
+        // backward: x <- lp*u + sum(c*u),  u = b_t * x,  t = t0+len-1 .. t0
+        for (int step = 0; step < len; ++step) {
+            const R* brow = btile + (len - 1 - step) * SP + j0;
+            R sig = 0;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) sig += x[r];
+            sig = column_sum<PH>(sig);
+            const int e = sig > (R)0 ? exponent_of(sig) : 0;
+            expo += e;
+            const R sc = scale2((R)1, -e);
+            R u[NR];
+            R q = 0;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                u[r] = brow[r] * (x[r] * sc);
+                q += c[r] * u[r];
+            }
+            q = column_sum<PH>(q);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) x[r] = lp * u[r] + q;
+        }
+    }
+    {   // final power-of-two normalisation: column sums end in [0.5, 1)
+        R sig = 0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) sig += x[r];
+        sig = column_sum<PH>(sig);
+        const int e = sig > (R)0 ? exponent_of(sig) : 0;
+        expo += e;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) x[r] = scale2(x[r], -e);
+    }
+    R* __restrict__ dst = bt.op + (((long long)tile * 2 + dir) * SP + col) * SP + j0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) dst[r] = x[r];
+    if ((lane % PH) == 0) bt.opexp[((long long)tile * 2 + dir) * SP + col] = expo;
+}
+
+// =======================================================================================
+// scan2: chunk-boundary vectors of one recording.  grid = n_rec, block = 128:
+// wave 0 chains the forward operators, wave 1 the backward operators; lane = speaker.
+//   y' = sum_i (y_i 2^{E_i}) col_i     with the weights shifted by the largest exponent on the
+//   support of y, so that nothing that matters can underflow.
+// =======================================================================================
+template <typename R, int SP>
+__global__ __launch_bounds__(128) void scan2_kernel(BatchView<R> bt) {
+    __shared__ __attribute__((aligned(16))) R wl[2][SP];
+    const int rec = blockIdx.x;
+    if (bt.state[rec].done) return;
+    const RecDesc rd = bt.recs[rec];
+    const int K = rd.ntiles;
+    const int dir = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = lane < SP ? lane : SP - 1;
+    const bool act = lane < SP;
+    R y;
+    if (dir == 0) y = (act && j < rd.S) ? (R)(bt.ip[(long long)rec * SP + j] + 1e-8) : (R)0;
+    else y = (act && j < rd.S) ? (R)1 : (R)0;
+    R* __restrict__ bound = dir == 0 ? bt.fbound : bt.gbound;
+    if (act) bound[(long long)(rd.tile0 + (dir == 0 ? 0 : K - 1)) * SP + j] = y;
+    R opa[SP], opb[SP];
+    auto load_op = [&](R (&dst)[SP], int n) {     // operator that step n of this chain applies
+        const bool ok = n < K - 1;
+        const int k = dir == 0 ? n : K - 1 - n;
+        const R* __restrict__ src = bt.op + ((long long)(rd.tile0 + (ok ? k : 0)) * 2 + dir) * SP * SP + j;
+#pragma unroll
+        for (int i = 0; i < SP; ++i) dst[i] = ok ? src[(long long)i * SP] : (R)0;
+    };
+    auto apply = [&](const R (&opr)[SP], int n) {
+        if (n >= K - 1) return;                   // wave-uniform
+        const int k = dir == 0 ? n : K - 1 - n;
+        const int ej = bt.opexp[((long long)(rd.tile0 + k) * 2 + dir) * SP + j];
+        const bool pos = act && y > (R)0;
+        const float tj = pos ? (float)(ej + exponent_of(y)) : -3.0e38f;
+        const int top = (int)allreduce_max<64>(tj);
+        const R w = pos ? scale2(y, ej - top) : (R)0;
+        if (act) wl[dir][j] = w;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        R acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+#pragma unroll
+        for (int i = 0; i < SP; i += 4) {
+            acc0 += wl[dir][i] * opr[i];
+            acc1 += wl[dir][i + 1] * opr[i + 1];
+            acc2 += wl[dir][i + 2] * opr[i + 2];
+            acc3 += wl[dir][i + 3] * opr[i + 3];
+        }
+        y = (acc0 + acc1) + (acc2 + acc3);
+        __builtin_amdgcn_wave_barrier();
+        const int kb = dir == 0 ? k + 1 : k - 1;
+        if (act) bound[(long long)(rd.tile0 + kb) * SP + j] = y;
+    };
+    load_op(opa, 0);
+    for (int n = 0; n < K - 1; n += 2) {
+        load_op(opb, n + 1);
+        apply(opa, n);
+        load_op(opa, n + 2);
+        apply(opb, n + 1);
+    }
+}
+
+// =======================================================================================
+// scan3: re-run one chunk from its boundary vectors.  lane = speaker; a group of SP lanes runs
+// one direction, so a wavefront carries both directions of the chunk when SP <= 32.
+// grid = ntiles_total, block = 64 * max(1, 2*SP/64).  One cross-lane reduction per frame:
+//   fwd: u = b_t (lp*ahat + c)      r = sum u        ahat' = u / r        (tll += log r)
+//   bwd: u = b_t * bhat             r = sum c*u      bhat' = lp*u/r + 1
+// =======================================================================================
+template <typename R, int SP>
+__global__ __launch_bounds__(64 * ((2 * SP + 63) / 64)) void scan3_kernel(BatchView<R> bt) {
+    constexpr int U = 8;
+    const int tile = blockIdx.x;
+    const int rec = bt.tile_rec[tile];
+    if (bt.state[rec].done) return;
+    const RecDesc rd = bt.recs[rec];
+    const int t0 = bt.tile_t0[tile];
+    const int len = min(kTileFrames, rd.T - t0);
+    const int grp = threadIdx.x / SP, j = threadIdx.x % SP;
+    const bool fwd = (grp & 1) == 0;
+    const bool owner = grp < 2;                    // SP = 16: groups 2,3 shadow groups 0,1
+    const bool chunk0 = (t0 == 0);
+    const R lp = (R)rd.lp;
+    const R* __restrict__ B = bt.bmat + rd.row0 * SP;
+    const R cj = (j < rd.S) ? (R)((1.0 - rd.lp) * bt.pi[(long long)rec * SP + j] + 1e-8) : (R)0;
+    const R wgt = fwd ? (R)1 : cj;
+    const R m1 = fwd ? (R)1 : lp, m0 = fwd ? (R)0 : (R)1;
+    R* __restrict__ out = (fwd ? bt.ahat : bt.bhat) + rd.row0 * SP;
+    const int row_first = fwd ? t0 : t0 + len - 1, sgn = fwd ? 1 : -1;
+
+    R x = (fwd ? bt.fbound : bt.gbound)[(long long)tile * SP + j];
+    {
+        const R s = allreduce_sum<SP>(x);
+        if (fwd && !chunk0) x = x * fast_rcp(s);          // sum(ahat) = 1 is assumed by the step
+        if (!fwd) {
+            x = x * fast_rcp(s) * (R)SP;                   // any positive scale will do
+            if (owner) out[(long long)(t0 + len - 1) * SP + j] = x;
+        }
+    }
+    ScaledProduct sp;
+    R blk0[U], blk1[U];
+    auto load_rows = [&](R (&blk)[U], int i0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u;
+            blk[u] = (i < len) ? B[(long long)(row_first + sgn * i) * SP + j] : (R)0;
+        }
+    };
+    auto run = [&](const R (&blk)[U], int i0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u;
+            if (i >= len) break;                           // block-uniform
+            const bool plain = !fwd || (chunk0 && i == 0); // no transition applied before b
+            const R pre = plain ? x : lp * x + cj;
+            const R uu = blk[u] * pre;
+            const R r = allreduce_sum<SP>(wgt * uu);
+            const R inv = fast_rcp(r);
+            x = uu * (m1 * inv) + m0;
+            const int orow = fwd ? t0 + i : t0 + len - 2 - i;
+            if (owner && orow >= t0) out[(long long)orow * SP + j] = x;
+            if (fwd) {
+                sp.mul((double)r);
+                if ((i & 15) == 15) sp.renorm();
+            }
+        }
+    };
+    load_rows(blk0, 0);
+    for (int ib = 0; ib < len; ib += 2 * U) {
+        load_rows(blk1, ib + U);
+        run(blk0, ib);
+        load_rows(blk0, ib + 2 * U);
+        run(blk1, ib + U);
+    }
+    // chunk share of the total log-likelihood: sum log r_t + sum m_t          (VBx.py:173)
+    double msum = 0.0;
+    for (int t = t0 + j; t < t0 + len; t += SP) msum += (double)bt.mrow[rd.row0 + t];
+    msum = allreduce_sum<SP>(msum);
+    sp.renorm();
+    if (threadIdx.x == 0) bt.tllpart[tile] = sp.log_value() + msum;
+}
+
+}  // namespace vbx
