@@ -1,0 +1,132 @@
+"""NumPy model of the chunked parallel scan (vbx_amd/csrc/vbx_scan.hpp)  --  TEST INFRASTRUCTURE.
+
+Mirrors the three device kernels step for step (power-of-two column rescaling with integer
+exponents, support-aware weighting in the boundary chain, per-frame normalisation in the
+re-run) so that the algebra, including its corner cases (exact zeros in b, zero operator
+columns, one-frame chunks), can be checked on the CPU against ``vbx_oracle.fb_linear`` and the
+reference's log-domain answers.  ``dtype`` selects the working precision (float32 mimics the
+fp32 device path).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+EPS = 1e-8
+NEG_BIG = -10 ** 9
+
+
+def _exp2i(e):
+    return e
+
+
+def scan1(B, c, lp, dtype, first_chunk, direction, zero_column_fix=True):
+    """Transfer operator of one chunk.  Returns (cols[S,S] with cols[i] = operator column i, expo[S])."""
+    L, S = B.shape
+    X = np.eye(S, dtype=dtype)                    # X[i] = column i (a vector over states)
+    expo = np.zeros(S, dtype=np.int64)
+    lp = dtype(lp)
+    for step in range(L):
+        sig = X.sum(axis=1)
+        e = np.where(sig > 0, np.frexp(sig)[1], 0).astype(np.int64)
+        expo += e
+        if direction == 0:
+            b = B[step]
+            first = first_chunk and step == 0
+            lps = np.ldexp(dtype(1) if first else lp, -e).astype(dtype)
+            sgs = np.zeros(S, dtype=dtype) if first else np.ldexp(sig, -e).astype(dtype)
+            X = (b[None, :] * (lps[:, None] * X + c[None, :] * sgs[:, None])).astype(dtype)
+        else:
+            b = B[L - 1 - step]
+            sc = np.ldexp(dtype(1), -e).astype(dtype)
+            U = (b[None, :] * (X * sc[:, None])).astype(dtype)
+            q = (U * c[None, :]).sum(axis=1).astype(dtype)
+            X = (lp * U + q[:, None]).astype(dtype)
+    sig = X.sum(axis=1)
+    e = np.where(sig > 0, np.frexp(sig)[1], 0).astype(np.int64)
+    expo += e
+    X = np.ldexp(X, -e[:, None]).astype(dtype)
+    if zero_column_fix:
+        expo = np.where(sig > 0, expo, NEG_BIG)   # a zero column carries no weight at all
+    return X, expo
+
+
+def scan2_apply(y, cols, expo, dtype):
+    pos = y > 0
+    with np.errstate(divide='ignore'):
+        tj = np.where(pos, expo + np.frexp(y)[1], NEG_BIG * 4)
+    top = tj.max()
+    w = np.where(pos, np.ldexp(y, np.clip(expo - top, -100000, 100000)), 0).astype(dtype)
+    return (w[:, None] * cols).sum(axis=0).astype(dtype)
+
+
+def forward_backward_chunked(lls, pi, loopProb, ip=None, chunk=128, dtype=np.float64, pad_to=None,
+                             zero_column_fix=True):
+    """gamma, tll, entered -- same contract as vbx_oracle.fb_linear, computed the chunked way.
+    ``pad_to`` appends padded speakers exactly as the device layout does (b = 0, c = 0, no initial
+    mass); ``zero_column_fix=False`` reproduces the bug the first device version had."""
+    lls = np.asarray(lls, dtype=np.float64)
+    T, S_true = lls.shape
+    pi = np.asarray(pi, dtype=np.float64)
+    ip = pi if ip is None else np.asarray(ip, dtype=np.float64)
+    m = lls.max(axis=1).astype(dtype)
+    B = np.exp(lls - m[:, None].astype(np.float64)).astype(dtype)
+    c = ((1.0 - loopProb) * pi + EPS).astype(dtype)
+    ip0 = (ip + EPS).astype(dtype)
+    S = S_true
+    if pad_to is not None and pad_to > S_true:
+        S = pad_to
+        B = np.concatenate([B, np.zeros((T, S - S_true), dtype=dtype)], axis=1)
+        c = np.concatenate([c, np.zeros(S - S_true, dtype=dtype)])
+        ip0 = np.concatenate([ip0, np.zeros(S - S_true, dtype=dtype)])
+    lp = dtype(loopProb)
+    starts = list(range(0, T, chunk))
+    K = len(starts)
+    ops = []
+    for k, t0 in enumerate(starts):
+        Bk = B[t0:t0 + chunk]
+        ops.append((scan1(Bk, c, lp, dtype, k == 0, 0, zero_column_fix),
+                    scan1(Bk, c, lp, dtype, k == 0, 1, zero_column_fix)))
+    fbound = [None] * K
+    gbound = [None] * K
+    fbound[0] = ip0
+    gbound[K - 1] = np.concatenate([np.ones(S_true, dtype=dtype), np.zeros(S - S_true, dtype=dtype)])
+    live = np.arange(S) < S_true
+    for k in range(K - 1):
+        fbound[k + 1] = scan2_apply(fbound[k], *ops[k][0], dtype)
+    for k in range(K - 1, 0, -1):
+        gbound[k - 1] = scan2_apply(gbound[k], *ops[k][1], dtype)
+        if zero_column_fix:
+            gbound[k - 1] = np.where(live, gbound[k - 1], 0).astype(dtype)
+    ahat = np.empty((T, S), dtype=dtype)
+    bhat = np.empty((T, S), dtype=dtype)
+    tll = 0.0
+    for k, t0 in enumerate(starts):
+        Bk = B[t0:t0 + chunk]
+        L = len(Bk)
+        x = fbound[k]
+        if k > 0:
+            x = (x / x.sum()).astype(dtype)
+        for i in range(L):
+            pre = x if (k == 0 and i == 0) else (lp * x + c).astype(dtype)
+            u = (Bk[i] * pre).astype(dtype)
+            r = u.sum(dtype=dtype)
+            x = (u / r).astype(dtype)
+            ahat[t0 + i] = x
+            tll += float(np.log(np.float64(r))) + float(m[t0 + i])
+        x = gbound[k]
+        with np.errstate(invalid='ignore', divide='ignore'):
+            x = (x / x.sum() * S).astype(dtype)
+        bhat[t0 + L - 1] = x
+        for i in range(L - 1):
+            u = (Bk[L - 1 - i] * x).astype(dtype)
+            r = (c * u).sum(dtype=dtype)
+            x = (u * (lp / r) + dtype(1)).astype(dtype)
+            bhat[t0 + L - 2 - i] = x
+    g = ahat.astype(np.float64) * bhat.astype(np.float64)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        gamma = g / g.sum(axis=1, keepdims=True)
+        entered = np.zeros(S)
+        if T > 1:
+            den = loopProb * ahat[:-1].astype(np.float64) + c.astype(np.float64)
+            entered = np.where(live, (gamma[1:] / np.where(den > 0, den, 1.0)).sum(axis=0), 0.0)
+    return gamma[:, :S_true], tll, entered[:S_true]

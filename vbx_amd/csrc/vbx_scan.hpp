@@ -116,6 +116,9 @@ __global__ __launch_bounds__(64) void scan1_kernel(BatchView<R> bt) {
         expo += e;
 #pragma unroll
         for (int r = 0; r < NR; ++r) x[r] = scale2(x[r], -e);
+        // an all-zero column (b = 0 for its state somewhere in the chunk, or a padded state) must
+        // never win the exponent maximum in scan2
+        if (!(sig > (R)0)) expo = -(1 << 24);
     }
     R* __restrict__ dst = bt.op + (((long long)tile * 2 + dir) * SP + col) * SP + j0;
 #pragma unroll
@@ -145,17 +148,19 @@ __global__ __launch_bounds__(128) void scan2_kernel(BatchView<R> bt) {
     R* __restrict__ bound = dir == 0 ? bt.fbound : bt.gbound;
     if (act) bound[(long long)(rd.tile0 + (dir == 0 ? 0 : K - 1)) * SP + j] = y;
     R opa[SP], opb[SP];
-    auto load_op = [&](R (&dst)[SP], int n) {     // operator that step n of this chain applies
+    int expa = 0, expb = 0;
+    auto load_op = [&](R (&dst)[SP], int& dexp, int n) {   // operator that step n of this chain applies
         const bool ok = n < K - 1;
         const int k = dir == 0 ? n : K - 1 - n;
-        const R* __restrict__ src = bt.op + ((long long)(rd.tile0 + (ok ? k : 0)) * 2 + dir) * SP * SP + j;
+        const long long base = ((long long)(rd.tile0 + (ok ? k : 0)) * 2 + dir) * SP;
+        const R* __restrict__ src = bt.op + base * SP + j;
 #pragma unroll
         for (int i = 0; i < SP; ++i) dst[i] = ok ? src[(long long)i * SP] : (R)0;
+        dexp = ok ? bt.opexp[base + j] : 0;
     };
-    auto apply = [&](const R (&opr)[SP], int n) {
+    auto apply = [&](const R (&opr)[SP], int ej, int n) {
         if (n >= K - 1) return;                   // wave-uniform
         const int k = dir == 0 ? n : K - 1 - n;
-        const int ej = bt.opexp[((long long)(rd.tile0 + k) * 2 + dir) * SP + j];
         const bool pos = act && y > (R)0;
         const float tj = pos ? (float)(ej + exponent_of(y)) : -3.0e38f;
         const int top = (int)allreduce_max<64>(tj);
@@ -173,16 +178,17 @@ __global__ __launch_bounds__(128) void scan2_kernel(BatchView<R> bt) {
             acc3 += wl[dir][i + 3] * opr[i + 3];
         }
         y = (acc0 + acc1) + (acc2 + acc3);
+        if (j >= rd.S) y = 0;                      // padded speakers carry no mass in either direction
         __builtin_amdgcn_wave_barrier();
         const int kb = dir == 0 ? k + 1 : k - 1;
         if (act) bound[(long long)(rd.tile0 + kb) * SP + j] = y;
     };
-    load_op(opa, 0);
+    load_op(opa, expa, 0);
     for (int n = 0; n < K - 1; n += 2) {
-        load_op(opb, n + 1);
-        apply(opa, n);
-        load_op(opa, n + 2);
-        apply(opb, n + 1);
+        load_op(opb, expb, n + 1);
+        apply(opa, expa, n);
+        load_op(opa, expa, n + 2);
+        apply(opb, expb, n + 1);
     }
 }
 
