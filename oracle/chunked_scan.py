@@ -19,7 +19,12 @@ def _exp2i(e):
     return e
 
 
-def scan1(B, c, lp, dtype, first_chunk, direction, zero_column_fix=True):
+def _rescale_exponent(sig, dtype, clamp=True):
+    lim = (126 if dtype is np.float32 else 1022) if clamp else 10 ** 6
+    return np.where(sig > 0, np.clip(np.frexp(sig)[1], -lim, lim), 0).astype(np.int64)
+
+
+def scan1(B, c, lp, dtype, first_chunk, direction, zero_column_fix=True, clamp=True):
     """Transfer operator of one chunk.  Returns (cols[S,S] with cols[i] = operator column i, expo[S])."""
     L, S = B.shape
     X = np.eye(S, dtype=dtype)                    # X[i] = column i (a vector over states)
@@ -27,7 +32,7 @@ def scan1(B, c, lp, dtype, first_chunk, direction, zero_column_fix=True):
     lp = dtype(lp)
     for step in range(L):
         sig = X.sum(axis=1)
-        e = np.where(sig > 0, np.frexp(sig)[1], 0).astype(np.int64)
+        e = _rescale_exponent(sig, dtype, clamp)
         expo += e
         if direction == 0:
             b = B[step]
@@ -42,7 +47,7 @@ def scan1(B, c, lp, dtype, first_chunk, direction, zero_column_fix=True):
             q = (U * c[None, :]).sum(axis=1).astype(dtype)
             X = (lp * U + q[:, None]).astype(dtype)
     sig = X.sum(axis=1)
-    e = np.where(sig > 0, np.frexp(sig)[1], 0).astype(np.int64)
+    e = _rescale_exponent(sig, dtype, clamp)
     expo += e
     X = np.ldexp(X, -e[:, None]).astype(dtype)
     if zero_column_fix:
@@ -60,7 +65,7 @@ def scan2_apply(y, cols, expo, dtype):
 
 
 def forward_backward_chunked(lls, pi, loopProb, ip=None, chunk=128, dtype=np.float64, pad_to=None,
-                             zero_column_fix=True):
+                             zero_column_fix=True, clamp=True):
     """gamma, tll, entered -- same contract as vbx_oracle.fb_linear, computed the chunked way.
     ``pad_to`` appends padded speakers exactly as the device layout does (b = 0, c = 0, no initial
     mass); ``zero_column_fix=False`` reproduces the bug the first device version had."""
@@ -84,8 +89,8 @@ def forward_backward_chunked(lls, pi, loopProb, ip=None, chunk=128, dtype=np.flo
     ops = []
     for k, t0 in enumerate(starts):
         Bk = B[t0:t0 + chunk]
-        ops.append((scan1(Bk, c, lp, dtype, k == 0, 0, zero_column_fix),
-                    scan1(Bk, c, lp, dtype, k == 0, 1, zero_column_fix)))
+        ops.append((scan1(Bk, c, lp, dtype, k == 0, 0, zero_column_fix, clamp),
+                    scan1(Bk, c, lp, dtype, k == 0, 1, zero_column_fix, clamp)))
     fbound = [None] * K
     gbound = [None] * K
     fbound[0] = ip0

@@ -118,6 +118,19 @@ def test_chunked_scan_survives_extreme_dynamic_range(ctx):
         assert np.all(np.isfinite(g)) and np.isfinite(t)
         np.testing.assert_allclose(g, post, rtol=0, atol=tol)
         np.testing.assert_allclose(t, tll, rtol=1e-10 if precision == 'fp64' else 2e-6)
+    # subnormal float32 likelihoods (b = exp(-95)): regression for the 2^132 = inf rescaling overflow
+    rng = np.random.default_rng(5)
+    T, S = 400, 6
+    lab = (np.arange(T) // 61) % 3
+    lls = np.full((T, S), -95.0) - 3.0 * rng.random((T, S))
+    lls[np.arange(T), lab] = -rng.random(T)
+    pi = np.ones(S) / S
+    post, tll, ent = _orc().fb_linear(lls, pi, 0.9)
+    for algo in (_capi.FB_CHUNKED, _capi.FB_SEQUENTIAL):
+        g, t, e, _, _ = ctx.forward_backward(lls, pi, 0.9, precision='fp32', fb_algo=algo)
+        assert np.all(np.isfinite(g)) and np.isfinite(t)
+        np.testing.assert_allclose(g, post, rtol=0, atol=2e-5)
+        np.testing.assert_allclose(t, tll, rtol=2e-6)
 
 
 @pytest.mark.parametrize('algo', ['sequential', 'chunked'])

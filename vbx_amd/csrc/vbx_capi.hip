@@ -175,7 +175,7 @@ template <typename R, int SP> void launch_scan(vbx_batch* b, const BatchView<R>&
     }
     {
         LaunchScope ls(b, VBX_K_FB_AUX);
-        hipLaunchKernelGGL((scan2_kernel<R, SP>), dim3(b->n_rec), dim3(128), 0, st, v);
+        hipLaunchKernelGGL((scan2_kernel<R, SP>), dim3(b->n_rec, 2), dim3(256), 0, st, v);
     }
     {
         LaunchScope ls(b, VBX_K_FB);

@@ -23,6 +23,14 @@ namespace vbx {
 
 __device__ __forceinline__ int exponent_of(float v) { return __builtin_amdgcn_frexp_expf(v); }
 __device__ __forceinline__ int exponent_of(double v) { return __builtin_amdgcn_frexp_exp(v); }
+// Exponent used to rescale an operator column whose sum is v.  Clamped so that 2^-e stays finite
+// when v is subnormal (b can be a subnormal number; the next frame finishes the renormalisation).
+__device__ __forceinline__ int rescale_exponent(float v) {
+    return v > 0.0f ? max(-126, min(126, __builtin_amdgcn_frexp_expf(v))) : 0;
+}
+__device__ __forceinline__ int rescale_exponent(double v) {
+    return v > 0.0 ? max(-1022, min(1022, __builtin_amdgcn_frexp_exp(v))) : 0;
+}
 __device__ __forceinline__ float scale2(float v, int e) { return __builtin_amdgcn_ldexpf(v, e); }
 __device__ __forceinline__ double scale2(double v, int e) { return __builtin_amdgcn_ldexp(v, e); }
 
@@ -76,7 +84,7 @@ __global__ __launch_bounds__(64) void scan1_kernel(BatchView<R> bt) {
 #pragma unroll
             for (int r = 0; r < NR; ++r) sig += x[r];
             sig = column_sum<PH>(sig);
-            const int e = sig > (R)0 ? exponent_of(sig) : 0;
+            const int e = rescale_exponent(sig);
             expo += e;
             const bool first = (t0 + step == 0);
             const R lps = first ? scale2((R)1, -e) : scale2(lp, -e);
@@ -92,7 +100,7 @@ __global__ __launch_bounds__(64) void scan1_kernel(BatchView<R> bt) {
 #pragma unroll
             for (int r = 0; r < NR; ++r) sig += x[r];
             sig = column_sum<PH>(sig);
-            const int e = sig > (R)0 ? exponent_of(sig) : 0;
+            const int e = rescale_exponent(sig);
             expo += e;
             const R sc = scale2((R)1, -e);
             R u[NR];
@@ -112,7 +120,7 @@ __global__ __launch_bounds__(64) void scan1_kernel(BatchView<R> bt) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) sig += x[r];
         sig = column_sum<PH>(sig);
-        const int e = sig > (R)0 ? exponent_of(sig) : 0;
+        const int e = rescale_exponent(sig);
         expo += e;
 #pragma unroll
         for (int r = 0; r < NR; ++r) x[r] = scale2(x[r], -e);
@@ -127,68 +135,105 @@ __global__ __launch_bounds__(64) void scan1_kernel(BatchView<R> bt) {
 }
 
 // =======================================================================================
-// scan2: chunk-boundary vectors of one recording.  grid = n_rec, block = 128:
-// wave 0 chains the forward operators, wave 1 the backward operators; lane = speaker.
-//   y' = sum_i (y_i 2^{E_i}) col_i     with the weights shifted by the largest exponent on the
-//   support of y, so that nothing that matters can underflow.
+// scan2: chunk-boundary vectors of one recording and one direction.
+// grid = (n_rec, 2), block = 256: wave 0 walks the chain of K-1 mat-vecs, waves 1-3 stream the
+// operators (4 KB each at SP = 32) from L2 into a double-buffered LDS ring RB operators ahead --
+// a single wave waiting on its own global loads spent 5 us per chunk in the first version.
+//   y' = sum_i (y_i 2^{E_i}) col_i,  weights shifted by the largest exponent on the support of y
+//   so that nothing that matters can underflow.
+// lane = (row j, part h): HL = 64/SP lanes share an output row and split the columns.
 // =======================================================================================
+template <typename R, int SP> struct Scan2Cfg {
+    static constexpr int kOpElems = SP * SP;
+    static constexpr int kOpBytes = kOpElems * (int)sizeof(R);
+    static constexpr int kBudget = 57344;
+    static constexpr int RB = (kOpBytes * 16 <= kBudget) ? 8 : (kOpBytes * 8 <= kBudget) ? 4
+                              : (kOpBytes * 4 <= kBudget) ? 2 : 1;
+    static constexpr int NBUF = (2 * RB * kOpBytes <= kBudget) ? 2 : 1;
+};
+
 template <typename R, int SP>
-__global__ __launch_bounds__(128) void scan2_kernel(BatchView<R> bt) {
-    __shared__ __attribute__((aligned(16))) R wl[2][SP];
-    const int rec = blockIdx.x;
+__global__ __launch_bounds__(256) void scan2_kernel(BatchView<R> bt) {
+    using Cfg = Scan2Cfg<R, SP>;
+    using R4 = typename Vec<R>::v4;
+    constexpr int HL = 64 / SP, NI = SP / HL, RB = Cfg::RB, NBUF = Cfg::NBUF, OPSZ = Cfg::kOpElems;
+    __shared__ __attribute__((aligned(16))) R ring[NBUF * RB * OPSZ];
+    __shared__ int exps[NBUF * RB * SP];
+    __shared__ __attribute__((aligned(16))) R wl[SP];
+    const int rec = blockIdx.x, dir = blockIdx.y;
     if (bt.state[rec].done) return;
     const RecDesc rd = bt.recs[rec];
-    const int K = rd.ntiles;
-    const int dir = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int j = lane < SP ? lane : SP - 1;
-    const bool act = lane < SP;
-    R y;
-    if (dir == 0) y = (act && j < rd.S) ? (R)(bt.ip[(long long)rec * SP + j] + 1e-8) : (R)0;
-    else y = (act && j < rd.S) ? (R)1 : (R)0;
+    const int K = rd.ntiles, nops = K - 1;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = lane / HL, h = lane % HL;
     R* __restrict__ bound = dir == 0 ? bt.fbound : bt.gbound;
-    if (act) bound[(long long)(rd.tile0 + (dir == 0 ? 0 : K - 1)) * SP + j] = y;
-    R opa[SP], opb[SP];
-    int expa = 0, expb = 0;
-    auto load_op = [&](R (&dst)[SP], int& dexp, int n) {   // operator that step n of this chain applies
-        const bool ok = n < K - 1;
-        const int k = dir == 0 ? n : K - 1 - n;
-        const long long base = ((long long)(rd.tile0 + (ok ? k : 0)) * 2 + dir) * SP;
-        const R* __restrict__ src = bt.op + base * SP + j;
-#pragma unroll
-        for (int i = 0; i < SP; ++i) dst[i] = ok ? src[(long long)i * SP] : (R)0;
-        dexp = ok ? bt.opexp[base + j] : 0;
-    };
-    auto apply = [&](const R (&opr)[SP], int ej, int n) {
-        if (n >= K - 1) return;                   // wave-uniform
-        const int k = dir == 0 ? n : K - 1 - n;
-        const bool pos = act && y > (R)0;
-        const float tj = pos ? (float)(ej + exponent_of(y)) : -3.0e38f;
-        const int top = (int)allreduce_max<64>(tj);
-        const R w = pos ? scale2(y, ej - top) : (R)0;
-        if (act) wl[dir][j] = w;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        R acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
-#pragma unroll
-        for (int i = 0; i < SP; i += 4) {
-            acc0 += wl[dir][i] * opr[i];
-            acc1 += wl[dir][i + 1] * opr[i + 1];
-            acc2 += wl[dir][i + 2] * opr[i + 2];
-            acc3 += wl[dir][i + 3] * opr[i + 3];
+
+    // copies the operators of round r (chain steps r*RB ...) into ring buffer `buf`
+    auto load_round = [&](int r, int buf, int tid, int nthreads) {
+        for (int q = 0; q < RB; ++q) {
+            const int n = r * RB + q;
+            if (n >= nops) break;
+            const int k = dir == 0 ? n : K - 1 - n;
+            const long long base = ((long long)(rd.tile0 + k) * 2 + dir) * SP;
+            const R4* __restrict__ src = reinterpret_cast<const R4*>(bt.op + base * SP);
+            R4* dst = reinterpret_cast<R4*>(ring + (long long)(buf * RB + q) * OPSZ);
+            for (int e = tid; e < OPSZ / 4; e += nthreads) dst[e] = src[e];
+            for (int e = tid; e < SP; e += nthreads) exps[(buf * RB + q) * SP + e] = bt.opexp[base + e];
         }
-        y = (acc0 + acc1) + (acc2 + acc3);
-        if (j >= rd.S) y = 0;                      // padded speakers carry no mass in either direction
-        __builtin_amdgcn_wave_barrier();
-        const int kb = dir == 0 ? k + 1 : k - 1;
-        if (act) bound[(long long)(rd.tile0 + kb) * SP + j] = y;
     };
-    load_op(opa, expa, 0);
-    for (int n = 0; n < K - 1; n += 2) {
-        load_op(opb, expb, n + 1);
-        apply(opa, expa, n);
-        load_op(opa, expa, n + 2);
-        apply(opb, expb, n + 1);
+
+    R y = 0;
+    if (wave == 0) {
+        if (dir == 0) y = (j < rd.S) ? (R)(bt.ip[(long long)rec * SP + j] + 1e-8) : (R)0;
+        else y = (j < rd.S) ? (R)1 : (R)0;
+        if (h == 0) bound[(long long)(rd.tile0 + (dir == 0 ? 0 : K - 1)) * SP + j] = y;
+    }
+    auto compute_round = [&](int r, int buf) {
+        for (int q = 0; q < RB; ++q) {
+            const int n = r * RB + q;
+            if (n >= nops) break;
+            const int k = dir == 0 ? n : K - 1 - n;
+            const R* opl = ring + (long long)(buf * RB + q) * OPSZ;
+            const int ej = exps[(buf * RB + q) * SP + j];
+            const bool pos = y > (R)0;
+            const float tj = pos ? (float)(ej + exponent_of(y)) : -3.0e38f;
+            const int top = (int)allreduce_max<64>(tj);
+            const R w = pos ? scale2(y, ej - top) : (R)0;
+            if (h == 0) wl[j] = w;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            R acc[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int ii = 0; ii < NI; ++ii) {
+                const int i = h * NI + ii;
+                acc[ii & 3] += wl[i] * opl[i * SP + j];
+            }
+            R tot = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            tot = column_sum<HL>(tot);
+            y = (j < rd.S) ? tot : (R)0;          // padded speakers carry no mass in either direction
+            __builtin_amdgcn_wave_barrier();
+            const int kb = dir == 0 ? k + 1 : k - 1;
+            if (h == 0) bound[(long long)(rd.tile0 + kb) * SP + j] = y;
+        }
+    };
+
+    const int rounds = (nops + RB - 1) / RB;
+    if (NBUF == 2) {
+        load_round(0, 0, threadIdx.x, 256);
+        __syncthreads();
+        for (int r = 0; r < rounds; ++r) {
+            if (wave == 0) compute_round(r, r & 1);
+            else if (r + 1 < rounds) load_round(r + 1, (r + 1) & 1, threadIdx.x - 64, 192);
+            __syncthreads();
+        }
+    } else {
+        for (int r = 0; r < rounds; ++r) {
+            load_round(r, 0, threadIdx.x, 256);
+            __syncthreads();
+            if (wave == 0) compute_round(r, 0);
+            __syncthreads();
+        }
     }
 }
 
