@@ -83,6 +83,7 @@ struct vbx_batch {
     void *d_op = nullptr, *d_fbound = nullptr, *d_gbound = nullptr;
     int* d_opexp = nullptr;
     double* d_tllpart = nullptr;
+    void* d_sfw = nullptr;
     bool use_chunked = false;
     void* d_xstage = nullptr;
     size_t xstage_bytes = 0;
@@ -107,7 +108,7 @@ struct vbx_batch {
         v.npart = (R*)d_npart; v.epart = d_epart; v.Li = d_Li; v.epsilon = epsilon;
         v.ip = d_ip ? d_ip : d_pi; v.fw_scale = (R*)d_fw_scale; v.bw_scale = (R*)d_bw_scale;
         v.op = (R*)d_op; v.opexp = d_opexp; v.fbound = (R*)d_fbound; v.gbound = (R*)d_gbound;
-        v.tllpart = use_chunked ? d_tllpart : nullptr;
+        v.tllpart = use_chunked ? d_tllpart : nullptr; v.sfw = (R*)d_sfw;
         return v;
     }
 };
@@ -265,6 +266,7 @@ int choose_fb_algo(vbx_batch* b, bool step_api_logs) {
         if (rc == VBX_OK) rc = dmalloc_bytes(b->ctx, &b->d_fbound, nt * sp * rs);
         if (rc == VBX_OK) rc = dmalloc_bytes(b->ctx, &b->d_gbound, nt * sp * rs);
         if (rc == VBX_OK) rc = dmalloc(b->ctx, &b->d_tllpart, nt);
+        if (rc == VBX_OK) rc = dmalloc_bytes(b->ctx, &b->d_sfw, (size_t)b->sum_T * rs);
         if (rc != VBX_OK) return rc;
     }
     b->use_chunked = chunked;
@@ -366,7 +368,7 @@ int vbx_batch_destroy(vbx_batch* b) {
                     b->d_rho, b->d_gamma, b->d_bmat, b->d_mrow, b->d_ahat, b->d_bhat, b->d_alpha, b->d_invL,
                     b->d_bias, b->d_mpart, b->d_npart, b->d_lraw, b->d_emodel, b->d_pi, b->d_epart, b->d_Li,
                     b->d_xstage, b->d_ip, b->d_fw_scale, b->d_bw_scale, b->d_op, b->d_fbound, b->d_gbound,
-                    b->d_opexp, b->d_tllpart};
+                    b->d_opexp, b->d_tllpart, b->d_sfw};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (b->ev_start) (void)hipEventDestroy(b->ev_start);

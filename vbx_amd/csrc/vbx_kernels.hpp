@@ -70,6 +70,7 @@ template <typename R> struct BatchView {
     R* fbound;             // [ntiles_total][Sp]  forward vector entering the chunk (ahat[t0-1], any scale)
     R* gbound;             // [ntiles_total][Sp]  backward vector at the chunk's last frame (any scale)
     double* tllpart;       // [ntiles_total] or null: sum over the chunk of log s_t + m_t
+    R* sfw;                // [sum_T] forward scales s_t = sum(a_t) written by scan3
 };
 
 // =======================================================================================
@@ -502,6 +503,14 @@ __global__ __launch_bounds__(256) void post_kernel(BatchView<R> bt) {
     for (int r = 0; r < NREG; ++r) atomicAdd(&ent_lds[jl + W * r], ent[r]);
     __syncthreads();
     for (int j = threadIdx.x; j < SP; j += 256) bt.epart[(long long)tile * SP + j] = ent_lds[j];
+    if (bt.tllpart) {      // chunked scan: this tile's share of the total log-likelihood (VBx.py:173)
+        __shared__ double tl_lds[16];
+        double part = 0.0;
+        for (int f = t0 + threadIdx.x; f < tend; f += 256)
+            part += log((double)bt.sfw[rd.row0 + f]) + (double)bt.mrow[rd.row0 + f];
+        part = block_sum(part, tl_lds);
+        if (threadIdx.x == 0) bt.tllpart[tile] = part;
+    }
 }
 
 // =======================================================================================

@@ -78,6 +78,7 @@ __global__ __launch_bounds__(64) void scan1_kernel(BatchView<R> bt) {
     if (dir == 0) {
         // forward: x <- b_t * (lp*x + c*sum(x)),  t = t0 .. t0+len-1   (frame 0 of the recording only
         // applies b_0: the initial vector ip + 1e-8 of VBx.py:163 is fed in by scan2)
+#pragma unroll 4
         for (int step = 0; step < len; ++step) {
             const R* brow = btile + step * SP + j0;
             R sig = 0;
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(64) void scan1_kernel(BatchView<R> bt) {
         }
     } else {
         // backward: x <- lp*u + sum(c*u),  u = b_t * x,  t = t0+len-1 .. t0
+#pragma unroll 4
         for (int step = 0; step < len; ++step) {
             const R* brow = btile + (len - 1 - step) * SP + j0;
             R sig = 0;
@@ -189,15 +191,25 @@ __global__ __launch_bounds__(256) void scan2_kernel(BatchView<R> bt) {
         if (h == 0) bound[(long long)(rd.tile0 + (dir == 0 ? 0 : K - 1)) * SP + j] = y;
     }
     auto compute_round = [&](int r, int buf) {
+        R opv[2][NI];
+        int ejv[2];
+        auto fetch = [&](int q, int slot) {       // LDS -> registers, issued one chain step ahead
+            const R* opl = ring + (long long)(buf * RB + q) * OPSZ;
+#pragma unroll
+            for (int ii = 0; ii < NI; ++ii) opv[slot][ii] = opl[(h * NI + ii) * SP + j];
+            ejv[slot] = exps[(buf * RB + q) * SP + j];
+        };
+        fetch(0, 0);
+#pragma unroll
         for (int q = 0; q < RB; ++q) {
             const int n = r * RB + q;
             if (n >= nops) break;
             const int k = dir == 0 ? n : K - 1 - n;
-            const R* opl = ring + (long long)(buf * RB + q) * OPSZ;
-            const int ej = exps[(buf * RB + q) * SP + j];
+            if (q + 1 < RB) fetch(q + 1, (q + 1) & 1);
+            const int ej = ejv[q & 1];
             const bool pos = y > (R)0;
-            const float tj = pos ? (float)(ej + exponent_of(y)) : -3.0e38f;
-            const int top = (int)allreduce_max<64>(tj);
+            const int tj = pos ? ej + exponent_of(y) : -(1 << 28);
+            const int top = allreduce_max<64>(tj);
             const R w = pos ? scale2(y, ej - top) : (R)0;
             if (h == 0) wl[j] = w;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -205,10 +217,7 @@ __global__ __launch_bounds__(256) void scan2_kernel(BatchView<R> bt) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             R acc[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int ii = 0; ii < NI; ++ii) {
-                const int i = h * NI + ii;
-                acc[ii & 3] += wl[i] * opl[i * SP + j];
-            }
+            for (int ii = 0; ii < NI; ++ii) acc[ii & 3] += wl[h * NI + ii] * opv[q & 1][ii];
             R tot = (acc[0] + acc[1]) + (acc[2] + acc[3]);
             tot = column_sum<HL>(tot);
             y = (j < rd.S) ? tot : (R)0;          // padded speakers carry no mass in either direction
@@ -241,29 +250,37 @@ __global__ __launch_bounds__(256) void scan2_kernel(BatchView<R> bt) {
 // scan3: re-run one chunk from its boundary vectors.  lane = speaker; a group of SP lanes runs
 // one direction, so a wavefront carries both directions of the chunk when SP <= 32.
 // grid = ntiles_total, block = 64 * max(1, 2*SP/64).  One cross-lane reduction per frame:
-//   fwd: u = b_t (lp*ahat + c)      r = sum u        ahat' = u / r        (tll += log r)
+//   fwd: u = b_t (lp*ahat + c)      r = sum u        ahat' = u / r        (s_t = r -> sfw)
 //   bwd: u = b_t * bhat             r = sum c*u      bhat' = lp*u/r + 1
+// The chunk's rows of b are staged in LDS first (every load of the tile in flight at once: a
+// block of eight rows prefetched per eight frames left the wave waiting on L2 half of the time).
 // =======================================================================================
 template <typename R, int SP>
 __global__ __launch_bounds__(64 * ((2 * SP + 63) / 64)) void scan3_kernel(BatchView<R> bt) {
-    constexpr int U = 8;
+    using R4 = typename Vec<R>::v4;
+    constexpr int kThreads = 64 * ((2 * SP + 63) / 64);
+    __shared__ __attribute__((aligned(16))) R btile[kTileFrames * SP];
     const int tile = blockIdx.x;
     const int rec = bt.tile_rec[tile];
     if (bt.state[rec].done) return;
     const RecDesc rd = bt.recs[rec];
     const int t0 = bt.tile_t0[tile];
     const int len = min(kTileFrames, rd.T - t0);
+    {
+        const R4* __restrict__ src = reinterpret_cast<const R4*>(bt.bmat + (rd.row0 + t0) * SP);
+        R4* dst = reinterpret_cast<R4*>(btile);
+        for (int q = threadIdx.x; q < len * SP / 4; q += kThreads) dst[q] = src[q];
+    }
     const int grp = threadIdx.x / SP, j = threadIdx.x % SP;
     const bool fwd = (grp & 1) == 0;
     const bool owner = grp < 2;                    // SP = 16: groups 2,3 shadow groups 0,1
     const bool chunk0 = (t0 == 0);
     const R lp = (R)rd.lp;
-    const R* __restrict__ B = bt.bmat + rd.row0 * SP;
     const R cj = (j < rd.S) ? (R)((1.0 - rd.lp) * bt.pi[(long long)rec * SP + j] + 1e-8) : (R)0;
     const R wgt = fwd ? (R)1 : cj;
     const R m1 = fwd ? (R)1 : lp, m0 = fwd ? (R)0 : (R)1;
     R* __restrict__ out = (fwd ? bt.ahat : bt.bhat) + rd.row0 * SP;
-    const int row_first = fwd ? t0 : t0 + len - 1, sgn = fwd ? 1 : -1;
+    R* __restrict__ sfw = bt.sfw + rd.row0;
 
     R x = (fwd ? bt.fbound : bt.gbound)[(long long)tile * SP + j];
     {
@@ -274,47 +291,23 @@ __global__ __launch_bounds__(64 * ((2 * SP + 63) / 64)) void scan3_kernel(BatchV
             if (owner) out[(long long)(t0 + len - 1) * SP + j] = x;
         }
     }
-    ScaledProduct sp;
-    R blk0[U], blk1[U];
-    auto load_rows = [&](R (&blk)[U], int i0) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = i0 + u;
-            blk[u] = (i < len) ? B[(long long)(row_first + sgn * i) * SP + j] : (R)0;
-        }
-    };
-    auto run = [&](const R (&blk)[U], int i0) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = i0 + u;
-            if (i >= len) break;                           // block-uniform
-            const bool plain = !fwd || (chunk0 && i == 0); // no transition applied before b
-            const R pre = plain ? x : lp * x + cj;
-            const R uu = blk[u] * pre;
-            const R r = allreduce_sum<SP>(wgt * uu);
-            const R inv = fast_rcp(r);
-            x = uu * (m1 * inv) + m0;
-            const int orow = fwd ? t0 + i : t0 + len - 2 - i;
-            if (owner && orow >= t0) out[(long long)orow * SP + j] = x;
-            if (fwd) {
-                sp.mul((double)r);
-                if ((i & 15) == 15) sp.renorm();
-            }
-        }
-    };
-    load_rows(blk0, 0);
-    for (int ib = 0; ib < len; ib += 2 * U) {
-        load_rows(blk1, ib + U);
-        run(blk0, ib);
-        load_rows(blk0, ib + 2 * U);
-        run(blk1, ib + U);
+    __syncthreads();
+    const int lrow0 = fwd ? 0 : len - 1, sgn = fwd ? 1 : -1;
+    R bnext = btile[lrow0 * SP + j];
+#pragma unroll 4
+    for (int i = 0; i < len; ++i) {
+        const R bcur = bnext;
+        if (i + 1 < len) bnext = btile[(lrow0 + sgn * (i + 1)) * SP + j];
+        const bool plain = !fwd || (chunk0 && i == 0);     // no transition applied before b
+        const R pre = plain ? x : lp * x + cj;
+        const R uu = bcur * pre;
+        const R r = allreduce_sum<SP>(wgt * uu);
+        const R inv = fast_rcp(r);
+        x = uu * (m1 * inv) + m0;
+        const int orow = fwd ? t0 + i : t0 + len - 2 - i;
+        if (owner && orow >= t0) out[(long long)orow * SP + j] = x;
+        if (fwd && threadIdx.x == 0) sfw[t0 + i] = r;      // log s_t is summed by post_kernel
     }
-    // chunk share of the total log-likelihood: sum log r_t + sum m_t          (VBx.py:173)
-    double msum = 0.0;
-    for (int t = t0 + j; t < t0 + len; t += SP) msum += (double)bt.mrow[rd.row0 + t];
-    msum = allreduce_sum<SP>(msum);
-    sp.renorm();
-    if (threadIdx.x == 0) bt.tllpart[tile] = sp.log_value() + msum;
 }
 
 }  // namespace vbx
