@@ -154,6 +154,27 @@ __device__ __forceinline__ float exp_r(float x) { return expf(x); }
 __device__ __forceinline__ double exp_r(double x) { return exp(x); }
 template <typename R> __device__ __forceinline__ R neg_inf() { return -(R)INFINITY; }
 
+// Copy `count` vectors from global memory to LDS with N independent loads in flight per thread.
+// A plain `dst[q] = src[q]` loop waits for every load before issuing the next one: at ~0.6 us per
+// round trip (data written by the previous kernel usually sits behind another XCD's L2) that
+// serialisation was the largest single cost of the first scan kernels.
+template <int N, typename V>
+__device__ __forceinline__ void stage_to_lds(V* dst, const V* __restrict__ src, int count, int tid, int nthreads) {
+    for (int base = 0; base < count; base += N * nthreads) {
+        V tmp[N];
+#pragma unroll
+        for (int u = 0; u < N; ++u) {
+            const int idx = base + u * nthreads + tid;
+            if (idx < count) tmp[u] = src[idx];
+        }
+#pragma unroll
+        for (int u = 0; u < N; ++u) {
+            const int idx = base + u * nthreads + tid;
+            if (idx < count) dst[idx] = tmp[u];
+        }
+    }
+}
+
 // Running product with an integer exponent on the side: prod * 2^expo, renormalised now and
 // then so that thousands of per-frame scales can be multiplied without a log per frame.
 struct ScaledProduct {

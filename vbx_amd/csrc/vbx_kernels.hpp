@@ -134,18 +134,31 @@ __global__ __launch_bounds__(64) void mstep_acc_kernel(BatchView<R> bt) {
         acc[mu][1] = acc_t{0, 0, 0, 0};
         nsum[mu] = 0;
     }
-#pragma unroll 4
-    for (int k0 = t0; k0 < tend; k0 += 4) {
-        const int t = k0 + g;
-        const bool ok = t < tend;
-        R2 b = R2{0, 0};
-        if (ok) b = *reinterpret_cast<const R2*>(rho + (long long)t * Dp + d0 + 2 * i);
+    // Issue every load of a half tile (16 k-steps = 64 frames) before the first MFMA: a wave that
+    // consumes each fragment right after loading it pays one L2/fabric round trip per k-step.
+    constexpr int kWords = NT * (int)(sizeof(R) / 4);                 // registers per k-step of gamma fragments
+    constexpr int KB = kWords >= 32 ? 2 : kWords >= 16 ? 4 : kWords >= 8 ? 8 : 16;
+#pragma unroll 1
+    for (int kb0 = t0; kb0 < tend; kb0 += 4 * KB) {
+        R2 bv[KB];
+        R av[KB][NT];
 #pragma unroll
-        for (int mu = 0; mu < NT; ++mu) {
-            const R a = ok ? gam[(long long)t * Sp + 16 * mu + i] : (R)0;
-            nsum[mu] += a;
-            acc[mu][0] = M::mma(a, b.x, acc[mu][0]);
-            acc[mu][1] = M::mma(a, b.y, acc[mu][1]);
+        for (int u = 0; u < KB; ++u) {
+            const int t = kb0 + 4 * u + g;
+            const bool ok = t < tend;
+            bv[u] = R2{0, 0};
+            if (ok) bv[u] = *reinterpret_cast<const R2*>(rho + (long long)t * Dp + d0 + 2 * i);
+#pragma unroll
+            for (int mu = 0; mu < NT; ++mu) av[u][mu] = ok ? gam[(long long)t * Sp + 16 * mu + i] : (R)0;
+        }
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+#pragma unroll
+            for (int mu = 0; mu < NT; ++mu) {
+                nsum[mu] += av[u][mu];
+                acc[mu][0] = M::mma(av[u][mu], bv[u].x, acc[mu][0]);
+                acc[mu][1] = M::mma(av[u][mu], bv[u].y, acc[mu][1]);
+            }
         }
     }
     R* __restrict__ part = bt.mpart + (long long)tile * Sp * Dp;
@@ -200,20 +213,19 @@ __global__ __launch_bounds__(128) void mstep_fin_kernel(BatchView<R> bt) {
             il = (double)bt.invL[sd + d];
             al = (double)bt.alpha[sd + d];
         } else {
-            // eight independent loads in flight per thread (a single dependent chain of ~80 L2 round
+            // sixteen independent loads in flight per thread (a single dependent chain of ~80 L2 round
             // trips cost 45 us in the first version of this kernel)
             double C = 0.0;
             const R* __restrict__ mp = bt.mpart + ((long long)rd.tile0 * Sp + s) * Dp + d;
             const long long stride = (long long)Sp * Dp;
             int tl = 0;
-            for (; tl + 8 <= rd.ntiles; tl += 8) {
-                R v[8];
+            for (; tl < rd.ntiles; tl += 16) {
+                R v[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = mp[(long long)(tl + u) * stride];
+                for (int u = 0; u < 16; ++u) v[u] = (tl + u < rd.ntiles) ? mp[(long long)(tl + u) * stride] : (R)0;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) C += (double)v[u];
+                for (int u = 0; u < 16; ++u) C += (double)v[u];
             }
-            for (; tl < rd.ntiles; ++tl) C += (double)mp[(long long)tl * stride];
             il = 1.0 / (1.0 + fafb * N * phi);
             al = fafb * il * C;
             const R ilr = (R)il, alr = (R)al;      // the values every later kernel sees
@@ -264,19 +276,43 @@ __global__ __launch_bounds__(256) void loglik_kernel(BatchView<R> bt, R* __restr
         for (int n = 0; n < NT; ++n) acc[m][n] = acc_t{0, 0, 0, 0};
     const int rowA0 = f0 + i, rowA1 = f0 + 16 + i;
     const bool ok0 = rowA0 < rd.T, ok1 = rowA1 < rd.T;
-    for (int q = 0; q < Dp / 16; ++q) {
-        const int kk = 16 * q + 4 * g;
-        R4 a0 = R4{0, 0, 0, 0}, a1 = R4{0, 0, 0, 0};
-        if (ok0) a0 = *reinterpret_cast<const R4*>(rho + (long long)rowA0 * Dp + kk);
-        if (ok1) a1 = *reinterpret_cast<const R4*>(rho + (long long)rowA1 * Dp + kk);
+    constexpr int QB = sizeof(R) == 8 ? (NT >= 8 ? 2 : 4) : 8;   // K blocks of 16 loaded together
+    constexpr int NB = NT < 2 ? NT : 2;     // speaker tiles whose alpha fragments are in flight together
+    const int nq = Dp / 16;
+#pragma unroll 1
+    for (int q0 = 0; q0 < nq; q0 += QB) {
+        R4 a0[QB], a1[QB];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const R4 b = *reinterpret_cast<const R4*>(alpha + (long long)(16 * n + i) * Dp + kk);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc[0][n] = M::mma(a0[r], b[r], acc[0][n]);
-                acc[1][n] = M::mma(a1[r], b[r], acc[1][n]);
+        for (int u = 0; u < QB; ++u) {
+            const int kk = 16 * (q0 + u) + 4 * g;
+            a0[u] = R4{0, 0, 0, 0};
+            a1[u] = R4{0, 0, 0, 0};
+            if (q0 + u < nq) {
+                if (ok0) a0[u] = *reinterpret_cast<const R4*>(rho + (long long)rowA0 * Dp + kk);
+                if (ok1) a1[u] = *reinterpret_cast<const R4*>(rho + (long long)rowA1 * Dp + kk);
             }
+        }
+#pragma unroll
+        for (int n0 = 0; n0 < NT; n0 += NB) {
+            R4 bfr[NB][QB];
+#pragma unroll
+            for (int nn = 0; nn < NB; ++nn)
+#pragma unroll
+                for (int u = 0; u < QB; ++u) {
+                    const int kk = 16 * (q0 + u) + 4 * g;
+                    bfr[nn][u] = R4{0, 0, 0, 0};
+                    if (q0 + u < nq)
+                        bfr[nn][u] = *reinterpret_cast<const R4*>(alpha + (long long)(16 * (n0 + nn) + i) * Dp + kk);
+                }
+#pragma unroll
+            for (int nn = 0; nn < NB; ++nn)
+#pragma unroll
+                for (int u = 0; u < QB; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        acc[0][n0 + nn] = M::mma(a0[u][r], bfr[nn][u][r], acc[0][n0 + nn]);
+                        acc[1][n0 + nn] = M::mma(a1[u][r], bfr[nn][u][r], acc[1][n0 + nn]);
+                    }
         }
     }
     const R Fa = (R)rd.Fa;
@@ -475,28 +511,44 @@ __global__ __launch_bounds__(256) void post_kernel(BatchView<R> bt) {
         c[r] = (j < rd.S) ? (R)((1.0 - rd.lp) * bt.pi[(long long)rec * SP + j] + 1e-8) : (R)1;
         ent[r] = 0.0;
     }
-    for (int fb = t0 + wave * FPW; fb < t0 + kTileFrames; fb += 4 * FPW) {
-        const int f = fb + sub;
-        const bool ok = f < tend;
-        R g[NREG], ap[NREG];
-        R sum = 0;
+    constexpr int kPasses = kTileFrames / (4 * FPW);                 // passes of this wavefront over the tile
+    constexpr int PB = (kPasses * NREG <= 32) ? kPasses : 32 / NREG;   // passes whose loads are in flight together
+    static_assert(kPasses % PB == 0, "pass batching");
+#pragma unroll 1
+    for (int p0 = 0; p0 < kPasses; p0 += PB) {
+        R av[PB][NREG], bv[PB][NREG], apv[PB][NREG];
 #pragma unroll
-        for (int r = 0; r < NREG; ++r) {
-            const int j = jl + W * r;
-            const R a = ok ? A[(long long)f * SP + j] : (R)0;
-            const R b = ok ? Bh[(long long)f * SP + j] : (R)0;
-            ap[r] = (ok && f >= 1) ? A[(long long)(f - 1) * SP + j] : (R)0;
-            g[r] = a * b;
-            sum += g[r];
+        for (int p = 0; p < PB; ++p) {
+            const int f = t0 + wave * FPW + (p0 + p) * 4 * FPW + sub;
+            const bool ok = f < tend;
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) {
+                const int j = jl + W * r;
+                av[p][r] = ok ? A[(long long)f * SP + j] : (R)0;
+                bv[p][r] = ok ? Bh[(long long)f * SP + j] : (R)0;
+                apv[p][r] = (ok && f >= 1) ? A[(long long)(f - 1) * SP + j] : (R)0;
+            }
         }
-        sum = allreduce_sum<W>(sum);
-        const R inv = ok ? (R)1 / sum : (R)0;
 #pragma unroll
-        for (int r = 0; r < NREG; ++r) {
-            const int j = jl + W * r;
-            const R gm = g[r] * inv;
-            if (ok) G[(long long)f * SP + j] = gm;
-            if (ok && f >= 1 && j < rd.S) ent[r] += (double)(gm / (lp * ap[r] + c[r]));
+        for (int p = 0; p < PB; ++p) {
+            const int f = t0 + wave * FPW + (p0 + p) * 4 * FPW + sub;
+            const bool ok = f < tend;
+            R g[NREG];
+            R sum = 0;
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) {
+                g[r] = av[p][r] * bv[p][r];
+                sum += g[r];
+            }
+            sum = allreduce_sum<W>(sum);
+            const R inv = ok ? (R)1 / sum : (R)0;
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) {
+                const int j = jl + W * r;
+                const R gm = g[r] * inv;
+                if (ok) G[(long long)f * SP + j] = gm;
+                if (ok && f >= 1 && j < rd.S) ent[r] += (double)(gm / (lp * apv[p][r] + c[r]));
+            }
         }
     }
 #pragma unroll
@@ -529,7 +581,14 @@ __global__ __launch_bounds__(256) void iter_fin_kernel(BatchView<R> bt) {
     // "entered" statistic: thread (slot, state) sums tiles slot, slot+nslot, ... ; Sp divides 256
     const int nslot = 256 / Sp, slot = threadIdx.x / Sp, sj = threadIdx.x % Sp;
     double part = 0.0;
-    for (int tl = slot; tl < rd.ntiles; tl += nslot) part += bt.epart[(long long)(rd.tile0 + tl) * Sp + sj];
+    for (int tl = slot; tl < rd.ntiles; tl += 16 * nslot) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            v[u] = (tl + u * nslot < rd.ntiles) ? bt.epart[(long long)(rd.tile0 + tl + u * nslot) * Sp + sj] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) part += v[u];
+    }
     ent_sh[threadIdx.x] = part;
     double tpart = 0.0;
     if (bt.tllpart)

@@ -59,11 +59,9 @@ __global__ __launch_bounds__(64) void scan1_kernel(BatchView<R> bt) {
     const int len = min(kTileFrames, rd.T - t0);
     const int lane = threadIdx.x;
     // stage the chunk's rows of b in LDS (coalesced 16-byte loads)
-    {
-        const R4* __restrict__ src = reinterpret_cast<const R4*>(bt.bmat + (rd.row0 + t0) * SP);
-        R4* dst = reinterpret_cast<R4*>(btile);
-        for (int q = lane; q < len * SP / 4; q += 64) dst[q] = src[q];
-    }
+    stage_to_lds<(sizeof(R) == 8 ? 8 : 16)>(reinterpret_cast<R4*>(btile),
+                                            reinterpret_cast<const R4*>(bt.bmat + (rd.row0 + t0) * SP),
+                                            len * SP / 4, lane, 64);
     __syncthreads();
     const int col = lane / PH, j0 = (lane % PH) * NR;
     const R lp = (R)rd.lp;
@@ -170,17 +168,35 @@ __global__ __launch_bounds__(256) void scan2_kernel(BatchView<R> bt) {
     const int j = lane / HL, h = lane % HL;
     R* __restrict__ bound = dir == 0 ? bt.fbound : bt.gbound;
 
-    // copies the operators of round r (chain steps r*RB ...) into ring buffer `buf`
+    // copies the operators of round r (chain steps r*RB ...) into ring buffer `buf`; every load of
+    // the round is issued before the first LDS store
     auto load_round = [&](int r, int buf, int tid, int nthreads) {
+        constexpr int PER = (OPSZ / 4 + 191) / 192;       // vectors per thread per operator (192 loaders)
+        R4 tmp[RB][PER];
+        int etmp[RB];
+#pragma unroll
         for (int q = 0; q < RB; ++q) {
             const int n = r * RB + q;
-            if (n >= nops) break;
             const int k = dir == 0 ? n : K - 1 - n;
-            const long long base = ((long long)(rd.tile0 + k) * 2 + dir) * SP;
+            const long long base = ((long long)(rd.tile0 + (n < nops ? k : 0)) * 2 + dir) * SP;
             const R4* __restrict__ src = reinterpret_cast<const R4*>(bt.op + base * SP);
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int e = u * nthreads + tid;
+                if (n < nops && e < OPSZ / 4) tmp[q][u] = src[e];
+            }
+            etmp[q] = (n < nops && tid < SP) ? bt.opexp[base + tid] : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+            const int n = r * RB + q;
             R4* dst = reinterpret_cast<R4*>(ring + (long long)(buf * RB + q) * OPSZ);
-            for (int e = tid; e < OPSZ / 4; e += nthreads) dst[e] = src[e];
-            for (int e = tid; e < SP; e += nthreads) exps[(buf * RB + q) * SP + e] = bt.opexp[base + e];
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int e = u * nthreads + tid;
+                if (n < nops && e < OPSZ / 4) dst[e] = tmp[q][u];
+            }
+            if (n < nops && tid < SP) exps[(buf * RB + q) * SP + tid] = etmp[q];
         }
     };
 
@@ -266,11 +282,8 @@ __global__ __launch_bounds__(64 * ((2 * SP + 63) / 64)) void scan3_kernel(BatchV
     const RecDesc rd = bt.recs[rec];
     const int t0 = bt.tile_t0[tile];
     const int len = min(kTileFrames, rd.T - t0);
-    {
-        const R4* __restrict__ src = reinterpret_cast<const R4*>(bt.bmat + (rd.row0 + t0) * SP);
-        R4* dst = reinterpret_cast<R4*>(btile);
-        for (int q = threadIdx.x; q < len * SP / 4; q += kThreads) dst[q] = src[q];
-    }
+    stage_to_lds<16>(reinterpret_cast<R4*>(btile), reinterpret_cast<const R4*>(bt.bmat + (rd.row0 + t0) * SP),
+                     len * SP / 4, (int)threadIdx.x, kThreads);
     const int grp = threadIdx.x / SP, j = threadIdx.x % SP;
     const bool fwd = (grp & 1) == 0;
     const bool owner = grp < 2;                    // SP = 16: groups 2,3 shadow groups 0,1
