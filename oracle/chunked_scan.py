@@ -30,9 +30,13 @@ def scan1(B, c, lp, dtype, first_chunk, direction, zero_column_fix=True, clamp=T
     X = np.eye(S, dtype=dtype)                    # X[i] = column i (a vector over states)
     expo = np.zeros(S, dtype=np.int64)
     lp = dtype(lp)
+    e_prev = np.zeros(S, dtype=np.int64)
     for step in range(L):
-        sig = X.sum(axis=1)
-        e = _rescale_exponent(sig, dtype, clamp)
+        if direction == 0:
+            sig = X.sum(axis=1)
+            e = _rescale_exponent(sig, dtype, clamp)
+        else:
+            e = e_prev                                # backward: exponent of the previous frame's q
         expo += e
         if direction == 0:
             b = B[step]
@@ -46,6 +50,7 @@ def scan1(B, c, lp, dtype, first_chunk, direction, zero_column_fix=True, clamp=T
             U = (b[None, :] * (X * sc[:, None])).astype(dtype)
             q = (U * c[None, :]).sum(axis=1).astype(dtype)
             X = (lp * U + q[:, None]).astype(dtype)
+            e_prev = _rescale_exponent(q, dtype, clamp)
     sig = X.sum(axis=1)
     e = _rescale_exponent(sig, dtype, clamp)
     expo += e

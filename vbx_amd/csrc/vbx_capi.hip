@@ -84,6 +84,7 @@ struct vbx_batch {
     int* d_opexp = nullptr;
     double* d_tllpart = nullptr;
     void* d_sfw = nullptr;
+    void* d_dump = nullptr;
     bool use_chunked = false;
     void* d_xstage = nullptr;
     size_t xstage_bytes = 0;
@@ -108,7 +109,7 @@ struct vbx_batch {
         v.npart = (R*)d_npart; v.epart = d_epart; v.Li = d_Li; v.epsilon = epsilon;
         v.ip = d_ip ? d_ip : d_pi; v.fw_scale = (R*)d_fw_scale; v.bw_scale = (R*)d_bw_scale;
         v.op = (R*)d_op; v.opexp = d_opexp; v.fbound = (R*)d_fbound; v.gbound = (R*)d_gbound;
-        v.tllpart = use_chunked ? d_tllpart : nullptr; v.sfw = (R*)d_sfw;
+        v.tllpart = use_chunked ? d_tllpart : nullptr; v.sfw = (R*)d_sfw; v.dump = (R*)d_dump;
         return v;
     }
 };
@@ -156,7 +157,7 @@ template <typename R> void launch_mstep(vbx_batch* b, double eps) {
     }
     {
         LaunchScope ls(b, VBX_K_MSTEP_FIN);
-        hipLaunchKernelGGL((mstep_fin_kernel<R>), dim3(b->n_rec, b->Sp), dim3(128), 0, b->ctx->stream, v);
+        hipLaunchKernelGGL((mstep_fin_kernel<R>), dim3(b->n_rec, b->Sp), dim3(256), 0, b->ctx->stream, v);
     }
 }
 
@@ -172,7 +173,7 @@ template <typename R, int SP> void launch_scan(vbx_batch* b, const BatchView<R>&
     hipStream_t st = b->ctx->stream;
     {
         LaunchScope ls(b, VBX_K_FB);
-        hipLaunchKernelGGL((scan1_kernel<R, SP>), dim3(b->ntiles_total, 2), dim3(64), 0, st, v);
+        hipLaunchKernelGGL((scan1_kernel<R, SP>), dim3(b->ntiles_total, 2), dim3(SP * SP / 4), 0, st, v);
     }
     {
         LaunchScope ls(b, VBX_K_FB_AUX);
@@ -180,8 +181,7 @@ template <typename R, int SP> void launch_scan(vbx_batch* b, const BatchView<R>&
     }
     {
         LaunchScope ls(b, VBX_K_FB);
-        constexpr int kBlock = 64 * ((2 * SP + 63) / 64);
-        hipLaunchKernelGGL((scan3_kernel<R, SP>), dim3(b->ntiles_total), dim3(kBlock), 0, st, v);
+        hipLaunchKernelGGL((scan3_kernel<R, SP>), dim3((b->ntiles_total + 1) / 2), dim3(64), 0, st, v);
     }
 }
 
@@ -267,6 +267,7 @@ int choose_fb_algo(vbx_batch* b, bool step_api_logs) {
         if (rc == VBX_OK) rc = dmalloc_bytes(b->ctx, &b->d_gbound, nt * sp * rs);
         if (rc == VBX_OK) rc = dmalloc(b->ctx, &b->d_tllpart, nt);
         if (rc == VBX_OK) rc = dmalloc_bytes(b->ctx, &b->d_sfw, (size_t)b->sum_T * rs);
+        if (rc == VBX_OK) rc = dmalloc_bytes(b->ctx, &b->d_dump, 1024 * rs);
         if (rc != VBX_OK) return rc;
     }
     b->use_chunked = chunked;
@@ -368,7 +369,7 @@ int vbx_batch_destroy(vbx_batch* b) {
                     b->d_rho, b->d_gamma, b->d_bmat, b->d_mrow, b->d_ahat, b->d_bhat, b->d_alpha, b->d_invL,
                     b->d_bias, b->d_mpart, b->d_npart, b->d_lraw, b->d_emodel, b->d_pi, b->d_epart, b->d_Li,
                     b->d_xstage, b->d_ip, b->d_fw_scale, b->d_bw_scale, b->d_op, b->d_fbound, b->d_gbound,
-                    b->d_opexp, b->d_tllpart, b->d_sfw};
+                    b->d_opexp, b->d_tllpart, b->d_sfw, b->d_dump};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (b->ev_start) (void)hipEventDestroy(b->ev_start);
@@ -873,7 +874,7 @@ int vbx_loglik(vbx_ctx* ctx, int64_t T, int32_t S, int32_t D, const double* X, c
         auto go = [&](auto tag) {
             using R = decltype(tag);
             auto v = b->view<R>(0.0);
-            hipLaunchKernelGGL((mstep_fin_kernel<R>), dim3(b->n_rec, b->Sp), dim3(128), 0, ctx->stream, v);
+            hipLaunchKernelGGL((mstep_fin_kernel<R>), dim3(b->n_rec, b->Sp), dim3(256), 0, ctx->stream, v);
             launch_loglik<R>(b, 0.0, true);
         };
         if (precision == VBX_PREC_FP64) go(double{}); else go(float{});

@@ -71,6 +71,7 @@ template <typename R> struct BatchView {
     R* gbound;             // [ntiles_total][Sp]  backward vector at the chunk's last frame (any scale)
     double* tllpart;       // [ntiles_total] or null: sum over the chunk of log s_t + m_t
     R* sfw;                // [sum_T] forward scales s_t = sum(a_t) written by scan3
+    R* dump;               // [256] scratch that absorbs the stores of idle scan steps
 };
 
 // =======================================================================================
@@ -188,8 +189,9 @@ __global__ __launch_bounds__(64) void mstep_acc_kernel(BatchView<R> bt) {
 // Tile partials are combined in f64.  grid = (n_rec, Sp), block = 128.
 // =======================================================================================
 template <typename R>
-__global__ __launch_bounds__(128) void mstep_fin_kernel(BatchView<R> bt) {
+__global__ __launch_bounds__(256) void mstep_fin_kernel(BatchView<R> bt) {
     __shared__ double lds[16];
+    __shared__ double csum[256];
     const int rec = blockIdx.x, s = blockIdx.y;
     const RecState st = bt.state[rec];
     if (st.done) return;
@@ -206,36 +208,48 @@ __global__ __launch_bounds__(128) void mstep_fin_kernel(BatchView<R> bt) {
     }
     const long long sd = ((long long)rec * Sp + s) * Dp;
     double bsum = 0.0, esum = 0.0;
-    for (int d = threadIdx.x; d < Dp; d += blockDim.x) {
-        const double phi = bt.phi[(long long)rec * Dp + d];
-        double il, al;
-        if (given) {
-            il = (double)bt.invL[sd + d];
-            al = (double)bt.alpha[sd + d];
-        } else {
-            // sixteen independent loads in flight per thread (a single dependent chain of ~80 L2 round
-            // trips cost 45 us in the first version of this kernel)
-            double C = 0.0;
-            const R* __restrict__ mp = bt.mpart + ((long long)rd.tile0 * Sp + s) * Dp + d;
+    // thread = (feature d, half of the tile range); loads are clamped instead of predicated so that
+    // sixteen of them are in flight per thread
+    const int half = threadIdx.x >> 7, dl = threadIdx.x & 127;
+    for (int d0 = 0; d0 < Dp; d0 += 128) {
+        const int d = d0 + dl;
+        const bool dok = d < Dp;
+        double C = 0.0;
+        if (!given) {
+            const int nt = rd.ntiles, last = nt - 1;
+            const R* __restrict__ mp = bt.mpart + ((long long)rd.tile0 * Sp + s) * Dp + (dok ? d : 0);
             const long long stride = (long long)Sp * Dp;
-            int tl = 0;
-            for (; tl < rd.ntiles; tl += 16) {
+            const int lo = half == 0 ? 0 : (nt + 1) / 2, hi = half == 0 ? (nt + 1) / 2 : nt;
+            for (int tl = lo; tl < hi; tl += 16) {
                 R v[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = (tl + u < rd.ntiles) ? mp[(long long)(tl + u) * stride] : (R)0;
+                for (int u = 0; u < 16; ++u) v[u] = mp[(long long)min(tl + u, last) * stride];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) C += (double)v[u];
+                for (int u = 0; u < 16; ++u) C += (tl + u < hi) ? (double)v[u] : 0.0;
             }
-            il = 1.0 / (1.0 + fafb * N * phi);
-            al = fafb * il * C;
-            const R ilr = (R)il, alr = (R)al;      // the values every later kernel sees
-            bt.invL[sd + d] = ilr;
-            bt.alpha[sd + d] = alr;
-            il = (double)ilr;
-            al = (double)alr;
         }
-        bsum += (il + al * al) * phi;
-        if (s < rd.S && d < bt.D) esum += log(il) - il - al * al + 1.0;
+        csum[threadIdx.x] = C;
+        __syncthreads();
+        if (half == 0 && dok) {
+            const double phi = bt.phi[(long long)rec * Dp + d];
+            double il, al;
+            if (given) {
+                il = (double)bt.invL[sd + d];
+                al = (double)bt.alpha[sd + d];
+            } else {
+                C += csum[threadIdx.x + 128];
+                il = 1.0 / (1.0 + fafb * N * phi);
+                al = fafb * il * C;
+                const R ilr = (R)il, alr = (R)al;      // the values every later kernel sees
+                bt.invL[sd + d] = ilr;
+                bt.alpha[sd + d] = alr;
+                il = (double)ilr;
+                al = (double)alr;
+            }
+            bsum += (il + al * al) * phi;
+            if (s < rd.S && d < bt.D) esum += log(il) - il - al * al + 1.0;
+        }
+        __syncthreads();
     }
     bsum = block_sum(bsum, lds);
     esum = block_sum(esum, lds);

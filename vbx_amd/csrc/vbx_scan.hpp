@@ -34,21 +34,24 @@ __device__ __forceinline__ int rescale_exponent(double v) {
 __device__ __forceinline__ float scale2(float v, int e) { return __builtin_amdgcn_ldexpf(v, e); }
 __device__ __forceinline__ double scale2(double v, int e) { return __builtin_amdgcn_ldexp(v, e); }
 
-// sum over the PH adjacent lanes that share one operator column (PH = 1, 2 or 4)
+// sum over the PH adjacent lanes that share one operator column (PH = 1, 2, 4, 8 or 16)
 template <int PH, typename R> __device__ __forceinline__ R column_sum(R v) {
     if (PH >= 2) v += dpp_mov<0xB1>(v);
     if (PH >= 4) v += dpp_mov<0x4E>(v);
+    if (PH >= 8) v += dpp_mov<0x141>(v);
+    if (PH >= 16) v += dpp_mov<0x140>(v);
     return v;
 }
 
 // =======================================================================================
-// scan1: transfer operators of one chunk.  grid = (ntiles_total, 2 directions), block = 64.
-// lane = (column, part): PH = 64/SP lanes share a column, each holds NR = SP/PH states.
+// scan1: transfer operators of one chunk.  grid = (ntiles_total, 2 directions), block = SP*SP/4.
+// lane = (column, part): PH = SP/4 adjacent lanes share a column and hold four states each, so a
+// frame costs ~25 instructions per wave and many light waves share a SIMD (the first version
+// kept 16 states per lane in one wave per chunk and was bound by its own instruction count).
 // =======================================================================================
 template <typename R, int SP>
-__global__ __launch_bounds__(64) void scan1_kernel(BatchView<R> bt) {
-    constexpr int PH = 64 / SP;
-    constexpr int NR = SP / PH;
+__global__ __launch_bounds__(SP * SP / 4) void scan1_kernel(BatchView<R> bt) {
+    constexpr int NR = 4, PH = SP / 4, NTHR = SP * PH;
     using R4 = typename Vec<R>::v4;
     __shared__ __attribute__((aligned(16))) R btile[kTileFrames * SP];
     const int tile = blockIdx.x, dir = blockIdx.y;
@@ -57,13 +60,12 @@ __global__ __launch_bounds__(64) void scan1_kernel(BatchView<R> bt) {
     const RecDesc rd = bt.recs[rec];
     const int t0 = bt.tile_t0[tile];
     const int len = min(kTileFrames, rd.T - t0);
-    const int lane = threadIdx.x;
-    // stage the chunk's rows of b in LDS (coalesced 16-byte loads)
-    stage_to_lds<(sizeof(R) == 8 ? 8 : 16)>(reinterpret_cast<R4*>(btile),
-                                            reinterpret_cast<const R4*>(bt.bmat + (rd.row0 + t0) * SP),
-                                            len * SP / 4, lane, 64);
+    const int tid = threadIdx.x;
+    // stage the chunk's rows of b in LDS (coalesced 16-byte loads, all in flight together)
+    stage_to_lds<(kTileFrames * SP / 4 + NTHR - 1) / NTHR>(
+        reinterpret_cast<R4*>(btile), reinterpret_cast<const R4*>(bt.bmat + (rd.row0 + t0) * SP), len * SP / 4, tid, NTHR);
     __syncthreads();
-    const int col = lane / PH, j0 = (lane % PH) * NR;
+    const int col = tid / PH, j0 = (tid % PH) * NR;
     const R lp = (R)rd.lp;
     R x[NR], c[NR];
 #pragma unroll
@@ -78,48 +80,41 @@ __global__ __launch_bounds__(64) void scan1_kernel(BatchView<R> bt) {
         // applies b_0: the initial vector ip + 1e-8 of VBx.py:163 is fed in by scan2)
 #pragma unroll 4
         for (int step = 0; step < len; ++step) {
-            const R* brow = btile + step * SP + j0;
-            R sig = 0;
-#pragma unroll
-            for (int r = 0; r < NR; ++r) sig += x[r];
-            sig = column_sum<PH>(sig);
+            const R4 b = *reinterpret_cast<const R4*>(btile + step * SP + j0);
+            const R sig = column_sum<PH>((x[0] + x[1]) + (x[2] + x[3]));
             const int e = rescale_exponent(sig);
             expo += e;
             const bool first = (t0 + step == 0);
             const R lps = first ? scale2((R)1, -e) : scale2(lp, -e);
             const R sgs = first ? (R)0 : scale2(sig, -e);
 #pragma unroll
-            for (int r = 0; r < NR; ++r) x[r] = brow[r] * (lps * x[r] + c[r] * sgs);
+            for (int r = 0; r < NR; ++r) x[r] = b[r] * (lps * x[r] + c[r] * sgs);
         }
     } else {
-        // backward: x <- lp*u + sum(c*u),  u = b_t * x,  t = t0+len-1 .. t0
+        // backward: x <- lp*u + q,  u = b_t * x,  q = sum(c*u),  t = t0+len-1 .. t0.  The column is
+        // rescaled with the exponent of the previous frame's q: x = lp*u + q >= q keeps the scaled
+        // column inside [0.5, 2^26], so one reduction per frame is enough.
+        int e = 0;
 #pragma unroll 4
         for (int step = 0; step < len; ++step) {
-            const R* brow = btile + (len - 1 - step) * SP + j0;
-            R sig = 0;
-#pragma unroll
-            for (int r = 0; r < NR; ++r) sig += x[r];
-            sig = column_sum<PH>(sig);
-            const int e = rescale_exponent(sig);
+            const R4 b = *reinterpret_cast<const R4*>(btile + (len - 1 - step) * SP + j0);
             expo += e;
             const R sc = scale2((R)1, -e);
             R u[NR];
-            R q = 0;
+            R qp = 0;
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
-                u[r] = brow[r] * (x[r] * sc);
-                q += c[r] * u[r];
+                u[r] = b[r] * (x[r] * sc);
+                qp += c[r] * u[r];
             }
-            q = column_sum<PH>(q);
+            const R q = column_sum<PH>(qp);
 #pragma unroll
             for (int r = 0; r < NR; ++r) x[r] = lp * u[r] + q;
+            e = rescale_exponent(q);
         }
     }
     {   // final power-of-two normalisation: column sums end in [0.5, 1)
-        R sig = 0;
-#pragma unroll
-        for (int r = 0; r < NR; ++r) sig += x[r];
-        sig = column_sum<PH>(sig);
+        const R sig = column_sum<PH>((x[0] + x[1]) + (x[2] + x[3]));
         const int e = rescale_exponent(sig);
         expo += e;
 #pragma unroll
@@ -128,10 +123,9 @@ __global__ __launch_bounds__(64) void scan1_kernel(BatchView<R> bt) {
         // never win the exponent maximum in scan2
         if (!(sig > (R)0)) expo = -(1 << 24);
     }
-    R* __restrict__ dst = bt.op + (((long long)tile * 2 + dir) * SP + col) * SP + j0;
-#pragma unroll
-    for (int r = 0; r < NR; ++r) dst[r] = x[r];
-    if ((lane % PH) == 0) bt.opexp[((long long)tile * 2 + dir) * SP + col] = expo;
+    R4 xv = R4{x[0], x[1], x[2], x[3]};
+    *reinterpret_cast<R4*>(bt.op + (((long long)tile * 2 + dir) * SP + col) * SP + j0) = xv;
+    if ((tid % PH) == 0) bt.opexp[((long long)tile * 2 + dir) * SP + col] = expo;
 }
 
 // =======================================================================================
@@ -263,63 +257,124 @@ __global__ __launch_bounds__(256) void scan2_kernel(BatchView<R> bt) {
 }
 
 // =======================================================================================
-// scan3: re-run one chunk from its boundary vectors.  lane = speaker; a group of SP lanes runs
-// one direction, so a wavefront carries both directions of the chunk when SP <= 32.
-// grid = ntiles_total, block = 64 * max(1, 2*SP/64).  One cross-lane reduction per frame:
+// scan3: re-run chunks from their boundary vectors.  One wavefront = four tasks of 16 lanes:
+// (chunk A, fwd) (chunk A, bwd) (chunk B, fwd) (chunk B, bwd); a lane holds NREG = SP/16 adjacent
+// speakers, so the only cross-lane operation per frame is ONE 16-lane DPP all-reduce shared by
+// the four tasks (measured: a DPP stage costs ~20 cycles of a lone wave, a VALU op 4.4):
 //   fwd: u = b_t (lp*ahat + c)      r = sum u        ahat' = u / r        (s_t = r -> sfw)
 //   bwd: u = b_t * bhat             r = sum c*u      bhat' = lp*u/r + 1
-// The chunk's rows of b are staged in LDS first (every load of the tile in flight at once: a
-// block of eight rows prefetched per eight frames left the wave waiting on L2 half of the time).
+// grid = ceil(ntiles_total / 2), block = 64.  The rows of b of both chunks are staged in LDS with
+// every load in flight at once; the frame loop is unrolled in blocks of 16 and has no branches.
 // =======================================================================================
 template <typename R, int SP>
-__global__ __launch_bounds__(64 * ((2 * SP + 63) / 64)) void scan3_kernel(BatchView<R> bt) {
+__global__ __launch_bounds__(64) void scan3_kernel(BatchView<R> bt) {
+    constexpr int NREG = SP / 16;
+    constexpr int UB = 16;
     using R4 = typename Vec<R>::v4;
-    constexpr int kThreads = 64 * ((2 * SP + 63) / 64);
-    __shared__ __attribute__((aligned(16))) R btile[kTileFrames * SP];
-    const int tile = blockIdx.x;
+    __shared__ __attribute__((aligned(16))) R btile[2 * kTileFrames * SP];
+    const int lane = threadIdx.x, task = lane >> 4, i = lane & 15;
+    const int cs = task >> 1;
+    const bool fwd = (task & 1) == 0;
+    const int tileA = 2 * blockIdx.x;
+    const bool hasB = tileA + 1 < bt.ntiles_total;
+    const int tile = (cs == 1 && hasB) ? tileA + 1 : tileA;
+    const bool valid = cs == 0 || hasB;
     const int rec = bt.tile_rec[tile];
-    if (bt.state[rec].done) return;
     const RecDesc rd = bt.recs[rec];
     const int t0 = bt.tile_t0[tile];
     const int len = min(kTileFrames, rd.T - t0);
-    stage_to_lds<16>(reinterpret_cast<R4*>(btile), reinterpret_cast<const R4*>(bt.bmat + (rd.row0 + t0) * SP),
-                     len * SP / 4, (int)threadIdx.x, kThreads);
-    const int grp = threadIdx.x / SP, j = threadIdx.x % SP;
-    const bool fwd = (grp & 1) == 0;
-    const bool owner = grp < 2;                    // SP = 16: groups 2,3 shadow groups 0,1
+    // both chunks are contiguous in the frame-major arrays: stage them with one pass
+    const int recA = bt.tile_rec[tileA];
+    const RecDesc rdA = bt.recs[recA];
+    const int t0A = bt.tile_t0[tileA];
+    const int lenA = min(kTileFrames, rdA.T - t0A);
+    int lenB = 0;
+    if (hasB) {
+        const int recB = bt.tile_rec[tileA + 1];
+        lenB = min(kTileFrames, bt.recs[recB].T - bt.tile_t0[tileA + 1]);
+        if (bt.state[recA].done && bt.state[recB].done) return;
+    } else if (bt.state[recA].done) {
+        return;
+    }
+    stage_to_lds<(2 * kTileFrames * SP / 4 + 63) / 64>(
+        reinterpret_cast<R4*>(btile), reinterpret_cast<const R4*>(bt.bmat + (rdA.row0 + t0A) * SP),
+        (lenA + lenB) * SP / 4, lane, 64);
+    const R* bl = btile + (cs == 1 ? lenA * SP : 0);        // this task's rows in LDS
+    const int lenmax = max(lenA, lenB);
+
     const bool chunk0 = (t0 == 0);
     const R lp = (R)rd.lp;
-    const R cj = (j < rd.S) ? (R)((1.0 - rd.lp) * bt.pi[(long long)rec * SP + j] + 1e-8) : (R)0;
-    const R wgt = fwd ? (R)1 : cj;
-    const R m1 = fwd ? (R)1 : lp, m0 = fwd ? (R)0 : (R)1;
-    R* __restrict__ out = (fwd ? bt.ahat : bt.bhat) + rd.row0 * SP;
-    R* __restrict__ sfw = bt.sfw + rd.row0;
-
-    R x = (fwd ? bt.fbound : bt.gbound)[(long long)tile * SP + j];
+    R c[NREG], x[NREG];
+    const R* __restrict__ bnd = (fwd ? bt.fbound : bt.gbound) + (long long)tile * SP + i * NREG;
+    R ssum = 0;
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) {
+        const int j = i * NREG + r;
+        c[r] = (j < rd.S) ? (R)((1.0 - rd.lp) * bt.pi[(long long)rec * SP + j] + 1e-8) : (R)0;
+        x[r] = bnd[r];
+        ssum += x[r];
+    }
+    ssum = allreduce_sum<16>(ssum);
+    R* __restrict__ out = (fwd ? bt.ahat : bt.bhat) + rd.row0 * SP + i * NREG;
+    R* __restrict__ dump = bt.dump + lane * NREG;             // absorbs the stores of idle steps
     {
-        const R s = allreduce_sum<SP>(x);
-        if (fwd && !chunk0) x = x * fast_rcp(s);          // sum(ahat) = 1 is assumed by the step
+        const R scl = (fwd && chunk0) ? (R)1 : fast_rcp(ssum) * (fwd ? (R)1 : (R)SP);
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) x[r] *= scl;
         if (!fwd) {
-            x = x * fast_rcp(s) * (R)SP;                   // any positive scale will do
-            if (owner) out[(long long)(t0 + len - 1) * SP + j] = x;
+            R* dst = valid ? out + (long long)(t0 + len - 1) * SP : dump;
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) dst[r] = x[r];
         }
     }
     __syncthreads();
-    const int lrow0 = fwd ? 0 : len - 1, sgn = fwd ? 1 : -1;
-    R bnext = btile[lrow0 * SP + j];
-#pragma unroll 4
-    for (int i = 0; i < len; ++i) {
-        const R bcur = bnext;
-        if (i + 1 < len) bnext = btile[(lrow0 + sgn * (i + 1)) * SP + j];
-        const bool plain = !fwd || (chunk0 && i == 0);     // no transition applied before b
-        const R pre = plain ? x : lp * x + cj;
-        const R uu = bcur * pre;
-        const R r = allreduce_sum<SP>(wgt * uu);
-        const R inv = fast_rcp(r);
-        x = uu * (m1 * inv) + m0;
-        const int orow = fwd ? t0 + i : t0 + len - 2 - i;
-        if (owner && orow >= t0) out[(long long)orow * SP + j] = x;
-        if (fwd && threadIdx.x == 0) sfw[t0 + i] = r;      // log s_t is summed by post_kernel
+    // per-lane constants of the unified step  u = b*(k1*x + k0);  r = sum(w*u);  x = u*(m1/r) + m0
+    R k0[NREG], w[NREG];
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) {
+        k0[r] = fwd ? c[r] : (R)0;
+        w[r] = fwd ? (R)1 : c[r];
+    }
+    const R k1 = fwd ? lp : (R)1, m1 = fwd ? (R)1 : lp, m0 = fwd ? (R)0 : (R)1;
+    const bool plain_first = fwd && chunk0;                  // frame 0 of the recording: no transition
+    R* __restrict__ sfw = bt.sfw + rd.row0 + t0;
+#pragma unroll 1
+    for (int blk = 0; blk < lenmax; blk += UB) {
+        R bv[UB][NREG];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int st = blk + u;
+            int lrow = fwd ? st : len - 1 - st;
+            lrow = min(max(lrow, 0), kTileFrames - 1);
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) bv[u][r] = bl[lrow * SP + i * NREG + r];
+        }
+        R keep = 0;
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int st = blk + u;
+            const bool special = (u == 0) && (blk == 0) && plain_first;
+            R uu[NREG];
+            R part = 0;
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) {
+                const R pre = special ? x[r] : k1 * x[r] + k0[r];
+                uu[r] = bv[u][r] * pre;
+                part += w[r] * uu[r];
+            }
+            const R rs = allreduce_sum<16>(part);
+            const R sc = m1 * fast_rcp(rs);
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) x[r] = uu[r] * sc + m0;
+            const int orow = fwd ? t0 + st : t0 + len - 2 - st;
+            const bool ok = valid && st < len && orow >= t0;
+            R* dst = ok ? out + (long long)orow * SP : dump;
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) dst[r] = x[r];
+            keep = (i == u) ? rs : keep;
+        }
+        // forward scales of these 16 frames, one per lane (log s_t is summed by post_kernel)
+        if (fwd && valid && blk + i < len) sfw[blk + i] = keep;
     }
 }
 
