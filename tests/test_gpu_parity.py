@@ -223,7 +223,10 @@ def test_es2005a_end_to_end(es2005a, precision):
     import vbx_amd
     g = es2005a
     X = g['fea'] if precision == 'fp64' else g['fea'].astype(np.float32)
-    q, sp, L = vbx_amd.VBx(X, g['Phi'], pi=int(g['qinit'].shape[1]), gamma=g['qinit'], maxIters=40, epsilon=1e-6,
+    # fp64 runs the reference's own stopping rule (epsilon=1e-6 on an ELBO of -7e4: only float64 can
+    # resolve it); the fp32 path is compared after the same 13 iterations the reference ran.
+    iters, eps = (40, 1e-6) if precision == 'fp64' else (len(g['Li40']), -1e300)
+    q, sp, L = vbx_amd.VBx(X, g['Phi'], pi=int(g['qinit'].shape[1]), gamma=g['qinit'], maxIters=iters, epsilon=eps,
                            loopProb=float(g['loopProb']), Fa=float(g['Fa']), Fb=float(g['Fb']), precision=precision)
     assert q.dtype == np.float64 and q.shape == g['gamma40'].shape
     if precision == 'fp64':
@@ -232,8 +235,8 @@ def test_es2005a_end_to_end(es2005a, precision):
         np.testing.assert_allclose(q, g['gamma40'], rtol=0, atol=1e-7)
         np.testing.assert_allclose(sp, g['pi40'], rtol=0, atol=1e-8)
     else:
-        n = min(len(L), len(g['Li40']))
-        assert rel_err([r[0] for r in L][:n], g['Li40'][:n]) < 1e-6
+        assert len(L) == len(g['Li40'])
+        assert rel_err([r[0] for r in L], g['Li40']) < 1e-6
         assert np.abs(q - g['gamma40']).max() <= FP32_TOL
         assert np.abs(sp - g['pi40']).max() <= FP32_TOL
     labels = np.argsort(-q, axis=1)[:, 0]                                # vbhmm.py:160
