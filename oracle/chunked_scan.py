@@ -60,6 +60,17 @@ def scan1(B, c, lp, dtype, first_chunk, direction, zero_column_fix=True, clamp=T
     return X, expo
 
 
+def scan2_apply_transposed(g, cols, expo, dtype):
+    """Backward boundary step: B_k = F_k^T, so (B g)_i = 2^{E_i} <col_i, g>; outputs rescaled by the
+    largest exponent present."""
+    dots = (cols * g[None, :]).sum(axis=1).astype(dtype)
+    pos = dots > 0
+    with np.errstate(divide='ignore'):
+        tj = np.where(pos, expo + np.frexp(dots)[1], NEG_BIG * 4)
+    top = tj.max()
+    return np.where(pos, np.ldexp(dots, np.clip(expo - top, -100000, 100000)), 0).astype(dtype)
+
+
 def scan2_apply(y, cols, expo, dtype):
     pos = y > 0
     with np.errstate(divide='ignore'):
@@ -94,17 +105,16 @@ def forward_backward_chunked(lls, pi, loopProb, ip=None, chunk=128, dtype=np.flo
     ops = []
     for k, t0 in enumerate(starts):
         Bk = B[t0:t0 + chunk]
-        ops.append((scan1(Bk, c, lp, dtype, k == 0, 0, zero_column_fix, clamp),
-                    scan1(Bk, c, lp, dtype, k == 0, 1, zero_column_fix, clamp)))
+        ops.append(scan1(Bk, c, lp, dtype, k == 0, 0, zero_column_fix, clamp))
     fbound = [None] * K
     gbound = [None] * K
     fbound[0] = ip0
     gbound[K - 1] = np.concatenate([np.ones(S_true, dtype=dtype), np.zeros(S - S_true, dtype=dtype)])
     live = np.arange(S) < S_true
     for k in range(K - 1):
-        fbound[k + 1] = scan2_apply(fbound[k], *ops[k][0], dtype)
+        fbound[k + 1] = scan2_apply(fbound[k], *ops[k], dtype)
     for k in range(K - 1, 0, -1):
-        gbound[k - 1] = scan2_apply(gbound[k], *ops[k][1], dtype)
+        gbound[k - 1] = scan2_apply_transposed(gbound[k], *ops[k], dtype)
         if zero_column_fix:
             gbound[k - 1] = np.where(live, gbound[k - 1], 0).astype(dtype)
     ahat = np.empty((T, S), dtype=dtype)

@@ -20,16 +20,32 @@ def test_chunked_model_matches_reference_known_answers(fb_cases, dtype, tol):
         np.testing.assert_allclose(tll, c['tll'], rtol=1e-12 if dtype is np.float64 else 1e-6, err_msg=name)
 
 
-def test_zero_columns_and_padded_states_do_not_poison_the_boundary_chain(fb_cases):
-    """Regression: a padded state's all-zero backward column once kept a stale exponent, won the
-    exponent maximum of the boundary chain and flushed every real weight to zero (NaN gamma)."""
+def test_backward_operator_is_the_transpose_of_the_forward_operator():
+    """(lp*I + 1 c^T) D_t = (D_t (lp*I + c 1^T))^T, hence B_k = F_k^T: scan1 only builds F_k."""
+    rng = np.random.default_rng(0)
+    S, L = 7, 40
+    B = np.exp(3.0 * rng.normal(size=(L, S)))
+    B /= B.max(axis=1, keepdims=True)
+    c = 0.01 * rng.random(S) + 1e-8
+    F, Ef = cs.scan1(B, c, 0.9, np.float64, False, 0)
+    Bk, Eb = cs.scan1(B, c, 0.9, np.float64, False, 1)
+    Fm = (F * np.exp2(Ef)[:, None]).T            # Fm[j, i]: column i, row j
+    Bm = (Bk * np.exp2(Eb)[:, None]).T
+    np.testing.assert_allclose(Bm, Fm.T, rtol=1e-12, atol=0)
+
+
+def test_padded_states_and_zero_columns_are_harmless(fb_cases):
+    """Padded speakers (b = 0, c = 0) create all-zero operator columns; they carry the exponent
+    -2^24 so that they can never win the exponent maximum of the boundary chain."""
     c = fb_cases['fb_T257_S31']
     args = (c['lls'], c['pi'], float(c['loopProb']))
-    with np.errstate(all='ignore'):
-        bad, _, _ = cs.forward_backward_chunked(*args, dtype=np.float32, pad_to=32, zero_column_fix=False)
-    assert np.isnan(bad).any()                       # the model reproduces the old failure ...
     good, _, _ = cs.forward_backward_chunked(*args, dtype=np.float32, pad_to=32)
-    np.testing.assert_allclose(good, c['post'], rtol=0, atol=5e-6)   # ... and the fix removes it
+    np.testing.assert_allclose(good, c['post'], rtol=0, atol=5e-6)
+    lls = c['lls'].copy()
+    lls[0, 3] = -1e4                              # b_0[3] = 0 exactly: column 3 of chunk 0 is all zero
+    ref, _, _ = orc.fb_linear(lls, c['pi'], float(c['loopProb']))
+    got, _, _ = cs.forward_backward_chunked(lls, c['pi'], float(c['loopProb']), dtype=np.float32, pad_to=32)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=5e-6)
 
 
 def test_extreme_dynamic_range_and_short_chunks():

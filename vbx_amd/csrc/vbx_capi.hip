@@ -173,7 +173,7 @@ template <typename R, int SP> void launch_scan(vbx_batch* b, const BatchView<R>&
     hipStream_t st = b->ctx->stream;
     {
         LaunchScope ls(b, VBX_K_FB);
-        hipLaunchKernelGGL((scan1_kernel<R, SP>), dim3(b->ntiles_total, 2), dim3(SP * SP / 4), 0, st, v);
+        hipLaunchKernelGGL((scan1_kernel<R, SP>), dim3(b->ntiles_total), dim3(SP * SP / 4), 0, st, v);
     }
     {
         LaunchScope ls(b, VBX_K_FB_AUX);
@@ -261,8 +261,8 @@ int choose_fb_algo(vbx_batch* b, bool step_api_logs) {
         FAIL(b->ctx, VBX_ERR_UNSUPPORTED, "chunked scan supports S <= 64 (got padded S = %d)", b->Sp);
     if (chunked && !b->d_op) {
         const size_t rs = b->rsize, nt = (size_t)b->ntiles_total, sp = (size_t)b->Sp;
-        int rc = dmalloc_bytes(b->ctx, &b->d_op, nt * 2 * sp * sp * rs);
-        if (rc == VBX_OK) rc = dmalloc(b->ctx, &b->d_opexp, nt * 2 * sp);
+        int rc = dmalloc_bytes(b->ctx, &b->d_op, nt * sp * sp * rs);
+        if (rc == VBX_OK) rc = dmalloc(b->ctx, &b->d_opexp, nt * sp);
         if (rc == VBX_OK) rc = dmalloc_bytes(b->ctx, &b->d_fbound, nt * sp * rs);
         if (rc == VBX_OK) rc = dmalloc_bytes(b->ctx, &b->d_gbound, nt * sp * rs);
         if (rc == VBX_OK) rc = dmalloc(b->ctx, &b->d_tllpart, nt);

@@ -65,8 +65,8 @@ template <typename R> struct BatchView {
     double* Li;            // [n_rec][max_iters]
     double epsilon;
     // chunked scan (VBX_FB_CHUNKED): one chunk = one tile of kTileFrames frames
-    R* op;                 // [ntiles_total][2][Sp][Sp]  transfer-operator columns (dir 0 fwd, 1 bwd)
-    int* opexp;            // [ntiles_total][2][Sp]      power-of-two exponent of every column
+    R* op;                 // [ntiles_total][Sp][Sp]  forward transfer-operator columns (backward = transpose)
+    int* opexp;            // [ntiles_total][Sp]      power-of-two exponent of every column
     R* fbound;             // [ntiles_total][Sp]  forward vector entering the chunk (ahat[t0-1], any scale)
     R* gbound;             // [ntiles_total][Sp]  backward vector at the chunk's last frame (any scale)
     double* tllpart;       // [ntiles_total] or null: sum over the chunk of log s_t + m_t

@@ -7,8 +7,9 @@
 //     be_{t-1} = Mt_t be_t,         Mt_t = (lp*I + 1 c^T) diag(b_t)               (VBx.py:170-171)
 // Both are linear, so T frames are cut into chunks (one chunk = one tile of kTileFrames frames)
 // and the 2T-step dependency chain becomes
-//   scan1  per chunk, all chunks in parallel: the S x S transfer operators
-//             F_k = M_{t1-1} ... M_{t0}   and   B_k = Mt_{t0} ... Mt_{t1-1}
+//   scan1  per chunk, all chunks in parallel: the S x S transfer operator
+//             F_k = M_{t1-1} ... M_{t0};   the backward operator is its transpose for free:
+//             Mt_t^T = M_t  =>  B_k = Mt_{t0} ... Mt_{t1-1} = F_k^T
 //          one operator column per lane (group), the column lives in registers, every sum over
 //          states is in-lane; columns are rescaled by exact powers of two (exponent kept aside).
 //   scan2  per recording: K-1 sequential mat-vecs give the vectors at every chunk boundary.
@@ -44,24 +45,26 @@ template <int PH, typename R> __device__ __forceinline__ R column_sum(R v) {
 }
 
 // =======================================================================================
-// scan1: transfer operators of one chunk.  grid = (ntiles_total, 2 directions), block = SP*SP/4.
-// lane = (column, part): PH = SP/4 adjacent lanes share a column and hold four states each, so a
-// frame costs ~25 instructions per wave and many light waves share a SIMD (the first version
-// kept 16 states per lane in one wave per chunk and was bound by its own instruction count).
+// scan1: forward transfer operator of one chunk (the backward one is its transpose).
+// grid = ntiles_total, block = SP*SP/4.  lane = (column, part): PH = SP/4 adjacent lanes share a
+// column and hold four states each, so a frame costs ~25 instructions per wave and many light
+// waves share a SIMD (the first version kept 16 states per lane in one wave per chunk and was
+// bound by its own instruction count).
+//   x <- b_t * (lp*x + c*sum(x)),  t = t0 .. t0+len-1; frame 0 of a recording only applies b_0
+//   (the initial vector ip + 1e-8 of VBx.py:163 is fed in by scan2).
 // =======================================================================================
 template <typename R, int SP>
 __global__ __launch_bounds__(SP * SP / 4) void scan1_kernel(BatchView<R> bt) {
     constexpr int NR = 4, PH = SP / 4, NTHR = SP * PH;
     using R4 = typename Vec<R>::v4;
     __shared__ __attribute__((aligned(16))) R btile[kTileFrames * SP];
-    const int tile = blockIdx.x, dir = blockIdx.y;
+    const int tile = blockIdx.x;
     const int rec = bt.tile_rec[tile];
     if (bt.state[rec].done) return;
     const RecDesc rd = bt.recs[rec];
     const int t0 = bt.tile_t0[tile];
     const int len = min(kTileFrames, rd.T - t0);
     const int tid = threadIdx.x;
-    // stage the chunk's rows of b in LDS (coalesced 16-byte loads, all in flight together)
     stage_to_lds<(kTileFrames * SP / 4 + NTHR - 1) / NTHR>(
         reinterpret_cast<R4*>(btile), reinterpret_cast<const R4*>(bt.bmat + (rd.row0 + t0) * SP), len * SP / 4, tid, NTHR);
     __syncthreads();
@@ -74,44 +77,23 @@ __global__ __launch_bounds__(SP * SP / 4) void scan1_kernel(BatchView<R> bt) {
         x[r] = (j == col) ? (R)1 : (R)0;
         c[r] = (j < rd.S) ? (R)((1.0 - rd.lp) * bt.pi[(long long)rec * SP + j] + 1e-8) : (R)0;
     }
-    int expo = 0;
-    if (dir == 0) {
-        // forward: x <- b_t * (lp*x + c*sum(x)),  t = t0 .. t0+len-1   (frame 0 of the recording only
-        // applies b_0: the initial vector ip + 1e-8 of VBx.py:163 is fed in by scan2)
-#pragma unroll 4
-        for (int step = 0; step < len; ++step) {
-            const R4 b = *reinterpret_cast<const R4*>(btile + step * SP + j0);
-            const R sig = column_sum<PH>((x[0] + x[1]) + (x[2] + x[3]));
-            const int e = rescale_exponent(sig);
-            expo += e;
-            const bool first = (t0 + step == 0);
-            const R lps = first ? scale2((R)1, -e) : scale2(lp, -e);
-            const R sgs = first ? (R)0 : scale2(sig, -e);
+    int expo = 0, first = 0;
+    if (t0 == 0) {                       // frame 0: x <- b_0 * x
+        const R4 b = *reinterpret_cast<const R4*>(btile + j0);
 #pragma unroll
-            for (int r = 0; r < NR; ++r) x[r] = b[r] * (lps * x[r] + c[r] * sgs);
-        }
-    } else {
-        // backward: x <- lp*u + q,  u = b_t * x,  q = sum(c*u),  t = t0+len-1 .. t0.  The column is
-        // rescaled with the exponent of the previous frame's q: x = lp*u + q >= q keeps the scaled
-        // column inside [0.5, 2^26], so one reduction per frame is enough.
-        int e = 0;
-#pragma unroll 4
-        for (int step = 0; step < len; ++step) {
-            const R4 b = *reinterpret_cast<const R4*>(btile + (len - 1 - step) * SP + j0);
-            expo += e;
-            const R sc = scale2((R)1, -e);
-            R u[NR];
-            R qp = 0;
+        for (int r = 0; r < NR; ++r) x[r] *= b[r];
+        first = 1;
+    }
+#pragma unroll 2
+    for (int step = first; step < len; ++step) {
+        const R4 b = *reinterpret_cast<const R4*>(btile + step * SP + j0);
+        const R sig = column_sum<PH>((x[0] + x[1]) + (x[2] + x[3]));
+        const int e = rescale_exponent(sig);
+        expo += e;
+        const R sc = scale2((R)1, -e);
+        const R lps = lp * sc, sgs = sig * sc;
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                u[r] = b[r] * (x[r] * sc);
-                qp += c[r] * u[r];
-            }
-            const R q = column_sum<PH>(qp);
-#pragma unroll
-            for (int r = 0; r < NR; ++r) x[r] = lp * u[r] + q;
-            e = rescale_exponent(q);
-        }
+        for (int r = 0; r < NR; ++r) x[r] = b[r] * (lps * x[r] + c[r] * sgs);
     }
     {   // final power-of-two normalisation: column sums end in [0.5, 1)
         const R sig = column_sum<PH>((x[0] + x[1]) + (x[2] + x[3]));
@@ -119,13 +101,13 @@ __global__ __launch_bounds__(SP * SP / 4) void scan1_kernel(BatchView<R> bt) {
         expo += e;
 #pragma unroll
         for (int r = 0; r < NR; ++r) x[r] = scale2(x[r], -e);
-        // an all-zero column (b = 0 for its state somewhere in the chunk, or a padded state) must
-        // never win the exponent maximum in scan2
+        // an all-zero column (b = 0 for its state at frame 0, or a padded state) must never win
+        // the exponent maximum in scan2
         if (!(sig > (R)0)) expo = -(1 << 24);
     }
     R4 xv = R4{x[0], x[1], x[2], x[3]};
-    *reinterpret_cast<R4*>(bt.op + (((long long)tile * 2 + dir) * SP + col) * SP + j0) = xv;
-    if ((tid % PH) == 0) bt.opexp[((long long)tile * 2 + dir) * SP + col] = expo;
+    *reinterpret_cast<R4*>(bt.op + ((long long)tile * SP + col) * SP + j0) = xv;
+    if ((tid % PH) == 0) bt.opexp[(long long)tile * SP + col] = expo;
 }
 
 // =======================================================================================
@@ -172,7 +154,7 @@ __global__ __launch_bounds__(256) void scan2_kernel(BatchView<R> bt) {
         for (int q = 0; q < RB; ++q) {
             const int n = r * RB + q;
             const int k = dir == 0 ? n : K - 1 - n;
-            const long long base = ((long long)(rd.tile0 + (n < nops ? k : 0)) * 2 + dir) * SP;
+            const long long base = (long long)(rd.tile0 + (n < nops ? k : 0)) * SP;
             const R4* __restrict__ src = reinterpret_cast<const R4*>(bt.op + base * SP);
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
@@ -206,7 +188,8 @@ __global__ __launch_bounds__(256) void scan2_kernel(BatchView<R> bt) {
         auto fetch = [&](int q, int slot) {       // LDS -> registers, issued one chain step ahead
             const R* opl = ring + (long long)(buf * RB + q) * OPSZ;
 #pragma unroll
-            for (int ii = 0; ii < NI; ++ii) opv[slot][ii] = opl[(h * NI + ii) * SP + j];
+            for (int ii = 0; ii < NI; ++ii)       // fwd: row j of columns h*NI..; bwd: column j, rows h*NI..
+                opv[slot][ii] = dir == 0 ? opl[(h * NI + ii) * SP + j] : opl[j * SP + h * NI + ii];
             ejv[slot] = exps[(buf * RB + q) * SP + j];
         };
         fetch(0, 0);
@@ -217,10 +200,13 @@ __global__ __launch_bounds__(256) void scan2_kernel(BatchView<R> bt) {
             const int k = dir == 0 ? n : K - 1 - n;
             if (q + 1 < RB) fetch(q + 1, (q + 1) & 1);
             const int ej = ejv[q & 1];
-            const bool pos = y > (R)0;
-            const int tj = pos ? ej + exponent_of(y) : -(1 << 28);
-            const int top = allreduce_max<64>(tj);
-            const R w = pos ? scale2(y, ej - top) : (R)0;
+            R w = y;
+            if (dir == 0) {                       // weights y_i 2^{E_i}, shifted by the largest on the support
+                const bool pos = y > (R)0;
+                const int tj = pos ? ej + exponent_of(y) : -(1 << 28);
+                const int top = allreduce_max<64>(tj);
+                w = pos ? scale2(y, ej - top) : (R)0;
+            }
             if (h == 0) wl[j] = w;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -230,6 +216,12 @@ __global__ __launch_bounds__(256) void scan2_kernel(BatchView<R> bt) {
             for (int ii = 0; ii < NI; ++ii) acc[ii & 3] += wl[h * NI + ii] * opv[q & 1][ii];
             R tot = (acc[0] + acc[1]) + (acc[2] + acc[3]);
             tot = column_sum<HL>(tot);
+            if (dir == 1) {                       // (F^T g)_j = 2^{E_j} <col_j, g>: rescale the outputs
+                const bool pos = tot > (R)0;
+                const int tj = pos ? ej + exponent_of(tot) : -(1 << 28);
+                const int top = allreduce_max<64>(tj);
+                tot = pos ? scale2(tot, ej - top) : (R)0;
+            }
             y = (j < rd.S) ? tot : (R)0;          // padded speakers carry no mass in either direction
             __builtin_amdgcn_wave_barrier();
             const int kb = dir == 0 ? k + 1 : k - 1;
