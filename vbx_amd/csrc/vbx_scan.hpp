@@ -128,15 +128,12 @@ template <typename R, int SP> struct Scan2Cfg {
     static constexpr int NBUF = (2 * RB * kOpBytes <= kBudget) ? 2 : 1;
 };
 
-template <typename R, int SP>
-__global__ __launch_bounds__(256) void scan2_kernel(BatchView<R> bt) {
+template <typename R, int SP, int dir>
+__device__ __forceinline__ void scan2_body(const BatchView<R>& bt, R* ring, int* exps, R* wl) {
     using Cfg = Scan2Cfg<R, SP>;
     using R4 = typename Vec<R>::v4;
     constexpr int HL = 64 / SP, NI = SP / HL, RB = Cfg::RB, NBUF = Cfg::NBUF, OPSZ = Cfg::kOpElems;
-    __shared__ __attribute__((aligned(16))) R ring[NBUF * RB * OPSZ];
-    __shared__ int exps[NBUF * RB * SP];
-    __shared__ __attribute__((aligned(16))) R wl[SP];
-    const int rec = blockIdx.x, dir = blockIdx.y;
+    const int rec = blockIdx.x;
     if (bt.state[rec].done) return;
     const RecDesc rd = bt.recs[rec];
     const int K = rd.ntiles, nops = K - 1;
@@ -246,6 +243,16 @@ __global__ __launch_bounds__(256) void scan2_kernel(BatchView<R> bt) {
             __syncthreads();
         }
     }
+}
+
+template <typename R, int SP>
+__global__ __launch_bounds__(256) void scan2_kernel(BatchView<R> bt) {
+    using Cfg = Scan2Cfg<R, SP>;
+    __shared__ __attribute__((aligned(16))) R ring[Cfg::NBUF * Cfg::RB * Cfg::kOpElems];
+    __shared__ int exps[Cfg::NBUF * Cfg::RB * SP];
+    __shared__ __attribute__((aligned(16))) R wl[SP];
+    if (blockIdx.y == 0) scan2_body<R, SP, 0>(bt, ring, exps, wl);     // direction is a compile-time constant:
+    else scan2_body<R, SP, 1>(bt, ring, exps, wl);                     // the two chains read the operator differently
 }
 
 // =======================================================================================
