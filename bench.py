@@ -6,8 +6,9 @@
 
 Workload (config.workload): every GPU holds a batch of ``--batch`` independent synthetic
 recordings of the headline shape T=10 000 x-vectors, R=128, S=30 (vbx_amd.synth, kappa=0.05,
-random gamma init); BASELINE.json config 4 ("64 recordings over 8 GPUs") gives the default
-of 8 per GPU.  One *step* = one VB EM iteration (M-step, log-likelihoods, forward-backward,
+random gamma init).  The default of 64 per GPU is BASELINE.json config 4's batch of 64
+recordings resident on one MI355X (it needs < 1 GB of the 288 GB); under weak scaling every
+further GPU holds another 64.  One *step* = one VB EM iteration (M-step, log-likelihoods, forward-backward,
 ELBO, pi update: VBx.py:94-105) of every recording in the batch.  ``value`` counts
 recording-iterations per second over all ranks; inputs are resident in HBM before the timed
 region.  Weak scaling: per-GPU work is fixed, recordings never talk to each other, RCCL is
@@ -81,12 +82,12 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=8, help='recordings per GPU')
+    ap.add_argument('--batch', type=int, default=64, help='recordings per GPU')
     ap.add_argument('--T', type=int, default=10000)
     ap.add_argument('--S', type=int, default=30)
     ap.add_argument('--D', type=int, default=128)
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'fp64'])
-    ap.add_argument('--cpu-iters', type=int, default=6, help='oracle iterations for cpu_baseline (0 = skip)')
+    ap.add_argument('--cpu-iters', type=int, default=20, help='oracle iterations for cpu_baseline (0 = skip)')
     ap.add_argument('--no-single', action='store_true', help='skip the batch=1 latency measurement')
     args = ap.parse_args()
 
@@ -180,7 +181,7 @@ def main():
             'dtype': 'f32' if args.precision == 'fp32' else 'f64',
             'data': 'synthetic',
             'config': {'workload': f'batch of {args.batch} recordings per GPU, each T={args.T} x-vectors, '
-                                   f'R={args.D}, S={args.S} (BASELINE configs[3] shard; headline shape), '
+                                   f'R={args.D}, S={args.S} (BASELINE configs[3] batch; headline shape), '
                                    'random gamma init, Fa=0.3 Fb=17 loopProb=0.99',
                        'recordings_per_gpu': args.batch, 'T': args.T, 'R': args.D, 'S': args.S,
                        'parallelism': f'recordings sharded over {world} rank(s), no data-path collective'},

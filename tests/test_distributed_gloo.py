@@ -1,0 +1,108 @@
+"""Multi-rank path on CPU: recordings shard over the ranks of a world_size-2 ``gloo`` group.
+
+The data path has no collective: every rank runs its shard independently and one
+``all_gather_object`` merges the small per-recording results.  Here the per-shard runner is the CPU
+oracle (injected through ``run_shard``; the product default is the HIP path, which needs a GPU),
+so what is tested is exactly the host logic bench.py / VBx_batch_distributed use on 8 GPUs:
+the deterministic LPT assignment, identical RNG draws on every rank, the gather, the ordering.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _recordings():
+    from vbx_amd.synth import make_recording
+    recs = []
+    for k, (T, S) in enumerate([(300, 5), (120, 3), (450, 6), (64, 2), (200, 4)]):
+        X, Phi, _ = make_recording(T, S, D=32, seed=40 + k, kappa=0.05)
+        recs.append(dict(X=X, Phi=Phi, pi=S, loopProb=0.9 if k % 2 else 0.8))
+    return recs
+
+
+def _oracle_shard(items, maxIters, epsilon):
+    from oracle import vbx_oracle                               # checker standing in for the GPU
+    out = []
+    for it in items:
+        g, pi, Li, alpha, invL = vbx_oracle.VBx(it['X'], it['Phi'], loopProb=it['loopProb'], Fa=it['Fa'],
+                                                Fb=it['Fb'], pi=it['pi'], gamma=it['gamma'], maxIters=maxIters,
+                                                epsilon=epsilon, return_model=True, alpha=it['alpha'],
+                                                invL=it['invL'])
+        out.append({'gamma': g, 'pi': pi, 'Li': np.array([row[0] for row in Li]), 'n_iters': len(Li),
+                    'warned': False, 'alpha': alpha, 'invL': invL})
+    return out
+
+
+def _worker(rank, world, port, outdir):
+    sys.path.insert(0, REPO)
+    import torch.distributed as dist
+    from vbx_amd.batch import VBx_batch_distributed
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+    try:
+        np.random.seed(7)                                       # gamma=None draws must agree on every rank
+        res = VBx_batch_distributed(_recordings(), maxIters=4, epsilon=-np.inf, Fa=0.3, Fb=17.0,
+                                    run_shard=_oracle_shard, return_model=True)
+        np.random.seed(7)
+        local_only = VBx_batch_distributed(_recordings(), maxIters=4, epsilon=-np.inf, Fa=0.3, Fb=17.0,
+                                           run_shard=_oracle_shard, gather=False)
+        mine = [b for b, r in enumerate(local_only) if r is not None]
+        np.savez(os.path.join(outdir, f'rank{rank}.npz'), mine=np.array(mine),
+                 **{f'g{b}': r[0] for b, r in enumerate(res)}, **{f'pi{b}': r[1] for b, r in enumerate(res)},
+                 **{f'L{b}': np.array(r[2]) for b, r in enumerate(res)},
+                 **{f'a{b}': r[3] for b, r in enumerate(res)})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sharding_matches_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    from vbx_amd.batch import VBx_batch_distributed, shard_recordings
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    np.random.seed(7)
+    single = VBx_batch_distributed(_recordings(), maxIters=4, epsilon=-np.inf, Fa=0.3, Fb=17.0,
+                                   run_shard=_oracle_shard, return_model=True)     # no group: world = 1
+    ranks = [np.load(tmp_path / f'rank{r}.npz') for r in range(world)]
+    recs = _recordings()
+    assign = shard_recordings([r['X'].shape[0] * r['pi'] for r in recs], world)
+    for r in range(world):
+        assert sorted(ranks[r]['mine'].tolist()) == [b for b in range(len(recs)) if assign[b] == r]
+        for b, ref in enumerate(single):
+            assert np.array_equal(ranks[r][f'g{b}'], ref[0])
+            assert np.array_equal(ranks[r][f'pi{b}'], ref[1])
+            assert np.array_equal(ranks[r][f'L{b}'], np.array(ref[2]))
+            assert np.array_equal(ranks[r][f'a{b}'], ref[3])
+    assert set(ranks[0]['mine'].tolist()) | set(ranks[1]['mine'].tolist()) == set(range(len(recs)))
+    assert not set(ranks[0]['mine'].tolist()) & set(ranks[1]['mine'].tolist())
+
+
+def test_lpt_assignment_is_balanced_and_deterministic():
+    from vbx_amd.batch import shard_recordings
+    costs = [10_000 * 30] * 64
+    a = shard_recordings(costs, 8)
+    assert np.bincount(a, minlength=8).tolist() == [8] * 8              # BASELINE config 4: 64 recordings / 8 GPUs
+    ragged = np.random.default_rng(0).integers(1_000, 200_000, 37) * 30
+    a1, a2 = shard_recordings(ragged, 4), shard_recordings(ragged, 4)
+    assert np.array_equal(a1, a2)
+    load = np.bincount(a1, weights=ragged, minlength=4)
+    assert load.max() <= ragged.sum() / 4 + ragged.max()                # LPT bound
+    assert shard_recordings([5, 1], 4).tolist() == [0, 1]
+
+
+def test_bench_rejects_mismatched_world_size():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0')
+    res = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '4'], env=env,
+                         capture_output=True, text=True)
+    assert res.returncode != 0 and 'WORLD_SIZE' in (res.stderr + res.stdout)

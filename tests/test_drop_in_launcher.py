@@ -1,0 +1,57 @@
+"""The unchanged reference driver vbhmm.py, launched by tools/run_vbhmm.py, imports this
+repository's VBx module (vbhmm.py:45) and calls it exactly as vbhmm.py:154-158 does.
+
+Runs only where a checkout of the reference exists (the authoring container); the device call is
+replaced by the CPU oracle here because the container has no GPU -- what is under test is the
+import redirection and the call contract, not the kernels (tests/test_gpu_parity.py::
+test_es2005a_end_to_end covers the same call on the MI355X from the committed fixture)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get('VBX_REFERENCE', '/root/reference')
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, 'VBx', 'vbhmm.py')), reason='reference checkout not present')
+def test_unchanged_vbhmm_runs_on_the_drop_in_module(tmp_path, monkeypatch, es2005a):
+    from oracle import vbx_oracle
+    import vbx_amd                                              # noqa: F401
+    product = sys.modules['vbx_amd.VBx']                        # the submodule (vbx_amd.VBx the attribute is the function)
+    calls = []
+
+    def recording_vbx(X, Phi, **kw):
+        calls.append((np.array(X), np.array(Phi), dict(kw)))
+        return vbx_oracle.VBx(X, Phi, **kw)
+
+    monkeypatch.setattr(product, 'VBx', recording_vbx)
+    for name in ('VBx', 'kaldi_io', 'kaldi_io.kaldi_io', 'h5py', 'fastcluster', 'diarization_lib', 'kaldi_utils'):
+        monkeypatch.delitem(sys.modules, name, raising=False)
+    sys.path.insert(0, os.path.join(REPO, 'tools'))
+    try:
+        import run_vbhmm
+        run_vbhmm.main(['--reference', REF, '--allow-shims', '--',
+                        '--init', 'AHC+VB', '--out-rttm-dir', str(tmp_path),
+                        '--xvec-ark-file', f'{REF}/exp/ES2005a.ark', '--segments-file', f'{REF}/exp/ES2005a.seg',
+                        '--xvec-transform', f'{REF}/VBx/models/ResNet101_16kHz/transform.h5',
+                        '--plda-file', f'{REF}/VBx/models/ResNet101_16kHz/plda',
+                        '--threshold', '-0.015', '--lda-dim', '128', '--Fa', '0.3', '--Fb', '17', '--loopP', '0.99'])
+        drop_in = sys.modules['VBx']
+        assert os.path.samefile(drop_in.__file__, os.path.join(REPO, 'vbx_drop_in', 'VBx.py'))
+    finally:
+        sys.path.remove(os.path.join(REPO, 'tools'))
+        for name in ('VBx', 'run_vbhmm', 'kaldi_io', 'kaldi_io.kaldi_io', 'h5py', 'fastcluster', 'diarization_lib',
+                     'kaldi_utils'):
+            sys.modules.pop(name, None)
+    assert len(calls) == 1
+    X, Phi, kw = calls[0]
+    assert np.array_equal(X, es2005a['fea']) and np.array_equal(Phi, es2005a['Phi'])
+    assert np.array_equal(kw['gamma'], es2005a['qinit'])
+    assert (kw['pi'], kw['maxIters'], kw['epsilon']) == (31, 40, 1e-6)             # vbhmm.py:154-158
+    rows = []
+    for line in open(tmp_path / 'ES2005a.rttm'):
+        f = line.split()
+        rows.append((float(f[3]), float(f[4]), int(f[7])))
+    assert np.array_equal(np.array(rows), es2005a['rttm_produced'])

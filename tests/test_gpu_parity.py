@@ -2,6 +2,7 @@
 golden fixtures generated from the reference.  Tolerances: fp64 device path ~1e-7; fp32 device
 path 1e-4 (BASELINE.json north_star: "within 1e-4 relative on fp32")."""
 import contextlib
+import os
 import io
 
 import numpy as np
@@ -363,3 +364,21 @@ def test_headline_size_properties_and_oracle_agreement(ctx):
         batch.close()
     assert np.abs(outs['fp32']['gamma'] - outs['fp64']['gamma']).max() <= FP32_TOL
     assert rel_err(outs['fp32']['Li'], outs['fp64']['Li']) <= 1e-6
+
+
+@pytest.mark.gpu
+def test_integration_md_ctypes_stub_runs_as_written(synth_cases, monkeypatch):
+    """The binding INTEGRATION.md shows a reference maintainer is executable as printed."""
+    import re
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'INTEGRATION.md')).read()
+    block = [b for b in re.findall(r'```python\n(.*?)```', text, flags=re.S) if 'class Problem' in b][0]
+    monkeypatch.chdir(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    ns = {}
+    exec(block, ns)
+    c = synth_cases['soft_T600_S12']
+    X, Phi, kw = case_inputs(c)
+    kw = {k: v for k, v in kw.items() if k in ('loopProb', 'Fa', 'Fb', 'pi', 'gamma', 'maxIters', 'epsilon')}
+    kw['epsilon'] = -1e300
+    g, pi, Li = ns['VBx'](X, Phi, **kw)
+    assert np.abs(g - c['gamma']).max() < 1e-8 and np.abs(pi - c['pi']).max() < 1e-8
+    assert np.allclose([r[0] for r in Li], c['Li'], rtol=1e-10)
