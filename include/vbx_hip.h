@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VBX_ABI_VERSION 1
+#define VBX_ABI_VERSION 2
 
 /* error codes */
 #define VBX_OK 0
@@ -59,6 +59,7 @@ extern "C" {
 #define VBX_OPT_CHECK_EVERY 2   /* iterations launched between two convergence polls (default 4) */
 #define VBX_OPT_PROFILE 3       /* 1: bracket every kernel launch with HIP events              */
 #define VBX_OPT_CHUNK_FRAMES 4  /* frames per scan chunk for VBX_FB_CHUNKED (0 = auto)         */
+#define VBX_OPT_FUSE 5          /* 1 (default): per-chunk fused kernels when the lattices fit in LDS */
 
 typedef struct vbx_ctx vbx_ctx;
 typedef struct vbx_batch vbx_batch;
@@ -73,7 +74,9 @@ enum {
     VBX_K_FB_AUX = 5,     /* chunk-boundary propagation (chunked scan only)         */
     VBX_K_POST = 6,       /* gamma, pi statistics                    VBx.py:101-103,174 */
     VBX_K_ITER_FIN = 7,   /* ELBO, pi update, convergence test       VBx.py:100-105,122-125 */
-    VBX_K_COUNT = 8
+    VBX_K_CHUNK_LOGLIK = 8, /* fused: log-likelihoods + chunk transfer operator  VBx.py:97,167-171 */
+    VBX_K_CHUNK_POST = 9, /* fused: chunk re-run + gamma + pi statistics + next gamma^T rho  VBx.py:96,101-103,167-174 */
+    VBX_K_COUNT = 10
 };
 
 int vbx_abi_version(void);

@@ -12,8 +12,9 @@ from . import build as _build
 VBX_F32, VBX_F64 = 0, 1
 PREC_FP32, PREC_FP64 = 0, 1
 FB_AUTO, FB_SEQUENTIAL, FB_CHUNKED = 0, 1, 2
-OPT_FB_ALGO, OPT_CHECK_EVERY, OPT_PROFILE, OPT_CHUNK_FRAMES = 1, 2, 3, 4
-K_NAMES = ['prep', 'mstep_acc', 'mstep_fin', 'loglik', 'fb', 'fb_aux', 'post', 'iter_fin']
+OPT_FB_ALGO, OPT_CHECK_EVERY, OPT_PROFILE, OPT_CHUNK_FRAMES, OPT_FUSE = 1, 2, 3, 4, 5
+K_NAMES = ['prep', 'mstep_acc', 'mstep_fin', 'loglik', 'fb', 'fb_aux', 'post', 'iter_fin', 'chunk_loglik',
+           'chunk_post']
 MAX_SPEAKERS = 256
 
 ABI_SYMBOLS = [
@@ -186,6 +187,9 @@ class Batch:
         if algo:
             self.set_option(OPT_FB_ALGO, {'auto': FB_AUTO, 'sequential': FB_SEQUENTIAL,
                                           'chunked': FB_CHUNKED}[algo])
+        fuse = os.environ.get('VBX_AMD_FUSE')             # '0' keeps every stage in its own kernel
+        if fuse is not None:
+            self.set_option(OPT_FUSE, int(fuse))
 
     def set_option(self, option: int, value: int):
         self.ctx.check(self._lib.vbx_batch_set_option(self._h, int(option), int(value)), 'vbx_batch_set_option')

@@ -7,6 +7,7 @@
 #include "../../include/vbx_hip.h"
 #include "vbx_kernels.hpp"
 #include "vbx_scan.hpp"
+#include "vbx_fused.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -67,7 +68,8 @@ struct vbx_batch {
     std::vector<char> is_set;
     bool recs_dirty = true;
     // options
-    int fb_algo = VBX_FB_AUTO, check_every = 4, profile = 0, chunk_frames = 0;
+    int fb_algo = VBX_FB_AUTO, check_every = 4, profile = 0, chunk_frames = 0, fuse = 1;
+    bool mpart_valid = false;                     // mpart/npart hold gamma^T rho of the current gamma (fused path)
     // device memory
     RecDesc* d_recs = nullptr;
     RecState* d_state = nullptr;
@@ -148,17 +150,22 @@ struct LaunchScope {   // brackets one kernel launch with events when profiling 
         default: break;                                        \
     }
 
-template <typename R> void launch_mstep(vbx_batch* b, double eps) {
+template <typename R> void launch_mstep_acc(vbx_batch* b, double eps) {
     auto v = b->view<R>(eps);
-    {
-        LaunchScope ls(b, VBX_K_MSTEP_ACC);
-        dim3 grid(b->ntiles_total, b->Dp / 32);
-        NT_SWITCH(b->NT, hipLaunchKernelGGL((mstep_acc_kernel<R, kNT>), grid, dim3(64), 0, b->ctx->stream, v);)
-    }
-    {
-        LaunchScope ls(b, VBX_K_MSTEP_FIN);
-        hipLaunchKernelGGL((mstep_fin_kernel<R>), dim3(b->n_rec, b->Sp), dim3(256), 0, b->ctx->stream, v);
-    }
+    LaunchScope ls(b, VBX_K_MSTEP_ACC);
+    dim3 grid(b->ntiles_total, b->Dp / 32);
+    NT_SWITCH(b->NT, hipLaunchKernelGGL((mstep_acc_kernel<R, kNT>), grid, dim3(64), 0, b->ctx->stream, v);)
+}
+
+template <typename R> void launch_mstep_fin(vbx_batch* b, double eps) {
+    auto v = b->view<R>(eps);
+    LaunchScope ls(b, VBX_K_MSTEP_FIN);
+    hipLaunchKernelGGL((mstep_fin_kernel<R>), dim3(b->n_rec, b->Sp), dim3(256), 0, b->ctx->stream, v);
+}
+
+template <typename R> void launch_mstep(vbx_batch* b, double eps) {
+    launch_mstep_acc<R>(b, eps);
+    launch_mstep_fin<R>(b, eps);
 }
 
 template <typename R> void launch_loglik(vbx_batch* b, double eps, bool raw) {
@@ -169,7 +176,7 @@ template <typename R> void launch_loglik(vbx_batch* b, double eps, bool raw) {
                                         b->ctx->stream, v, lraw);)
 }
 
-template <typename R, int SP> void launch_scan(vbx_batch* b, const BatchView<R>& v) {
+template <typename R, int SP> void launch_scan(vbx_batch* b, const BatchView<R>& v, bool fused_post) {
     hipStream_t st = b->ctx->stream;
     {
         LaunchScope ls(b, VBX_K_FB);
@@ -179,19 +186,37 @@ template <typename R, int SP> void launch_scan(vbx_batch* b, const BatchView<R>&
         LaunchScope ls(b, VBX_K_FB_AUX);
         hipLaunchKernelGGL((scan2_kernel<R, SP>), dim3(b->n_rec, 2), dim3(256), 0, st, v);
     }
+    if constexpr (ChunkPostCfg<R, SP>::kFits) {
+        if (fused_post) {
+            LaunchScope ls(b, VBX_K_CHUNK_POST);
+            hipLaunchKernelGGL((chunk_post_kernel<R, SP>), dim3(b->ntiles_total), dim3(256), 0, st, v);
+            return;
+        }
+    }
     {
         LaunchScope ls(b, VBX_K_FB);
         hipLaunchKernelGGL((scan3_kernel<R, SP>), dim3((b->ntiles_total + 1) / 2), dim3(64), 0, st, v);
     }
 }
 
-template <typename R> void launch_fb(vbx_batch* b, double eps) {
+// Can this batch run the fused per-chunk kernels?  (chunked scan + the lattices fit in LDS)
+template <typename R> bool fused_available(const vbx_batch* b) {
+    if (!b->use_chunked || !b->fuse) return false;
+    switch (b->Sp) {
+        case 16: return ChunkPostCfg<R, 16>::kFits;
+        case 32: return ChunkPostCfg<R, 32>::kFits;
+        case 64: return ChunkPostCfg<R, 64>::kFits;
+        default: return false;
+    }
+}
+
+template <typename R> void launch_fb(vbx_batch* b, double eps, bool fused_post = false) {
     auto v = b->view<R>(eps);
     if (b->use_chunked) {
         switch (b->Sp) {
-            case 16: launch_scan<R, 16>(b, v); return;
-            case 32: launch_scan<R, 32>(b, v); return;
-            case 64: launch_scan<R, 64>(b, v); return;
+            case 16: launch_scan<R, 16>(b, v, fused_post); return;
+            case 32: launch_scan<R, 32>(b, v, fused_post); return;
+            case 64: launch_scan<R, 64>(b, v, fused_post); return;
             default: break;
         }
     }
@@ -226,11 +251,23 @@ template <typename R> void launch_iter_fin(vbx_batch* b, double eps) {
 }
 
 template <typename R> void launch_iteration(vbx_batch* b, double eps) {
+    if (fused_available<R>(b)) {
+        // chunk_post leaves gamma^T rho of the gamma it has just written in mpart/npart, so only the
+        // first iteration after an upload needs the stand-alone accumulation
+        if (!b->mpart_valid) launch_mstep_acc<R>(b, eps);
+        launch_mstep_fin<R>(b, eps);
+        launch_loglik<R>(b, eps, false);
+        launch_fb<R>(b, eps, true);
+        launch_iter_fin<R>(b, eps);
+        b->mpart_valid = true;
+        return;
+    }
     launch_mstep<R>(b, eps);
     launch_loglik<R>(b, eps, false);
     launch_fb<R>(b, eps);
     launch_post<R>(b, eps);
     launch_iter_fin<R>(b, eps);
+    b->mpart_valid = false;
 }
 
 template <typename R, typename XT>
@@ -493,6 +530,10 @@ int vbx_batch_set_option(vbx_batch* b, int option, int64_t value) {
         case VBX_OPT_PROFILE:
             b->profile = value ? 1 : 0;
             return VBX_OK;
+        case VBX_OPT_FUSE:
+            b->fuse = value ? 1 : 0;
+            b->mpart_valid = false;
+            return VBX_OK;
         case VBX_OPT_CHUNK_FRAMES:
             if (value < 0) FAIL(b->ctx, VBX_ERR_INVALID, "chunk_frames must be >= 0");
             b->chunk_frames = (int)value;
@@ -582,6 +623,7 @@ int vbx_batch_set_recording(vbx_batch* b, int rec, const void* X, int x_dtype, c
     if (rc != VBX_OK) return rc;
     b->is_set[rec] = 1;
     b->recs_dirty = true;
+    b->mpart_valid = false;
     return VBX_OK;
 }
 

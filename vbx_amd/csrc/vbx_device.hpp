@@ -100,6 +100,17 @@ template <int CTRL> __device__ __forceinline__ int dpp_mov(int v) {
     return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
 }
 
+// value held by one lane, as a wave-uniform scalar (v_readlane_b32 -> SGPR)
+__device__ __forceinline__ float read_lane(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ double read_lane(double v, int lane) {
+    const unsigned long long bits = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bits, lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), lane);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 template <typename R> __device__ __forceinline__ R vmax(R a, R b) { return a > b ? a : b; }
 
 // Butterfly all-reduce over aligned groups of W lanes (W = 16, 32 or 64): every lane of a

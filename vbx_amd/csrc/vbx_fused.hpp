@@ -1,0 +1,348 @@
+// vbx_fused.hpp -- per-chunk kernels that keep a chunk's lattice in LDS.
+//
+// chunk_post_kernel (one workgroup = one chunk of kTileFrames frames):
+//     re-run of the chunk from its boundary vectors (scan3 of vbx_scan.hpp), posteriors and prior
+//     statistics (VBx.py:101-103, 173-174) and the NEXT iteration's M-step accumulation gamma^T rho
+//     (VBx.py:96) -- the forward / backward vectors never leave the CU.
+//
+#pragma once
+#include "vbx_scan.hpp"
+
+namespace vbx {
+
+// Does the chunk_post kernel's LDS footprint fit the CU?  (3 lattices of kTileFrames x SP)
+template <typename R, int SP> struct ChunkPostCfg {
+    static constexpr int kLattice = kTileFrames * SP;
+    static constexpr int kBytes = 3 * kLattice * (int)sizeof(R) + 8192;
+    static constexpr bool kFits = kBytes <= 160 * 1024;
+};
+
+template <typename R, int SP>
+__global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 3 : 1)) void chunk_post_kernel(BatchView<R> bt) {
+    using M = Mfma16<R>;
+    using acc_t = typename M::acc_t;
+    using R2 = typename Vec<R>::v2;
+    using R4 = typename Vec<R>::v4;
+    constexpr int NREG = SP / 16;                      // states per lane in the re-run
+    constexpr int NT = SP / 16;                        // M-tiles (speakers) of the accumulation
+    constexpr int LAT = kTileFrames * SP;
+    constexpr int KS = kTileFrames / 4;                // MFMA k-steps per chunk
+    __shared__ __attribute__((aligned(16))) R btile[LAT];
+    __shared__ __attribute__((aligned(16))) R af[LAT];
+    __shared__ __attribute__((aligned(16))) R bf[LAT];
+    __shared__ R sfl[kTileFrames];                     // sig_t = sum(a_t) of the row stored in af
+    __shared__ R qfl[kTileFrames];                     // q_t: every element of the row stored in bf is >= q_t > 0
+    __shared__ R tl_sig[2];
+    __shared__ int tl_expo;
+    __shared__ __attribute__((aligned(16))) R c_l[SP];
+    __shared__ __attribute__((aligned(16))) R aprev0[SP];
+    __shared__ double ent_w[4][SP];
+    __shared__ double red[16];
+
+    const int tile = blockIdx.x;
+    const int rec = bt.tile_rec[tile];
+    if (bt.state[rec].done) return;
+    const RecDesc rd = bt.recs[rec];
+    const int Dp = bt.Dp;
+    const int t0 = bt.tile_t0[tile];
+    const int len = min(kTileFrames, rd.T - t0);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int i16 = lane & 15, g4 = lane >> 4;
+    const R lp = (R)rd.lp;
+    const R* __restrict__ rho = bt.rho + rd.row0 * Dp;
+
+#ifdef VBX_PHASE_CLOCKS
+    long long clk[8];
+    int nclk = 0;
+#define VBX_STAMP() clk[nclk++] = clock64()
+#else
+#define VBX_STAMP()
+#endif
+    VBX_STAMP();
+    // ---- phase 0: the chunk's shifted likelihoods go to LDS --------------------------------------
+    stage_to_lds<(kTileFrames * SP / 4 + 255) / 256>(reinterpret_cast<R4*>(btile),
+                                                     reinterpret_cast<const R4*>(bt.bmat + (rd.row0 + t0) * SP),
+                                                     len * SP / 4, tid, 256);
+    if (tid < SP)
+        c_l[tid] = (tid < rd.S) ? (R)((1.0 - rd.lp) * bt.pi[(long long)rec * SP + tid] + 1e-8) : (R)0;
+    const bool chunk0 = (t0 == 0);
+    const int r0 = chunk0 ? 1 : 0;                     // first row the forward groups consume
+    __syncthreads();
+    VBX_STAMP();
+
+    // rho fragments of d-slab `wave` (B operand of the accumulation at the end).  Waves 2-3 issue the
+    // loads now and wait for the re-run; waves 0-1 issue theirs after it, so that the 2*KS registers are
+    // not live across their loops.
+    R2 bv[KS];
+    auto load_slab = [&](int slab) {
+        // rows past the end of the recording are clamped, not predicated: their gamma is zero, so the value
+        // does not matter, and unconditional loads all stay in flight together
+        const R* __restrict__ src = rho + (long long)t0 * Dp + 32 * slab + 2 * i16;
+        if (slab * 32 < Dp) {
+#pragma unroll
+            for (int u = 0; u < KS; ++u) bv[u] = *reinterpret_cast<const R2*>(src + min(4 * u + g4, len - 1) * Dp);
+        }
+    };
+
+    // ---- re-run of the chunk from its boundary vectors (VBx.py:167-171 in the linear domain):
+    // wave 0 walks forward, wave 1 backward.  A lone wavefront on a dependent instruction stream pays
+    // ~8-10 cycles per instruction (measured: 16 issue slots per frame = 160 cycles), so the loops are written
+    // for instruction count.  They carry UNNORMALISED vectors (no reciprocal on the chain),
+    //     forward :  a_t = b_t (lp a_{t-1} + c s_{t-1}),   s_t = sum a_t              (af, sfl)
+    //     backward:  x_{t-1} = lp b_t x_t + q_t,           q_t = sum c b_t x_t        (bf, qfl)
+    // rescaled by an exact power of two every four frames (worst case a frame shrinks the scale by
+    // min c = 1e-8).  A lane holds NREG adjacent states, 16 lanes a vector (the four 16-lane rows of the
+    // wave do the same work and store the same values); rows of b are fetched four frames ahead.
+    R c[NREG];
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) c[r] = c_l[i16 * NREG + r];
+    auto load_rows = [&](R (&dst)[4][NREG], int f, int dir) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) dst[k][r] = btile[(f + dir * k) * SP + i16 * NREG + r];
+    };
+    if (wave == 0) {
+        R a[NREG];
+        const R* __restrict__ bnd = bt.fbound + (long long)tile * SP + i16 * NREG;
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) {
+            a[r] = bnd[r];
+            if (!chunk0) aprev0[i16 * NREG + r] = a[r];      // a[t0-1] (any scale) for the statistics of frame t0
+            if (chunk0) a[r] *= btile[i16 * NREG + r];       // frame 0: a_0 = b_0 (ip + 1e-8), VBx.py:163
+        }
+        R sig = a[0];
+#pragma unroll
+        for (int r = 1; r < NREG; ++r) sig += a[r];
+        sig = allreduce_sum<16>(sig);
+        if (chunk0) {
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) af[i16 * NREG + r] = a[r];
+            sfl[0] = sig;
+        }
+        int expo = 0;                                        // power-of-two bookkeeping of the total log-likelihood
+        const R sig_in = sig;
+        auto renorm = [&]() {                                // (rows already stored keep their own scale: a row
+            const int e = rescale_exponent(sig);             //  of af is only ever used together with its sfl)
+            expo += e;
+            sig = scale2(sig, -e);
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) a[r] = scale2(a[r], -e);
+        };
+        auto step = [&](const R (&b)[NREG], int f) {
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) a[r] = b[r] * (lp * a[r] + c[r] * sig);
+            R sm = a[0];
+#pragma unroll
+            for (int r = 1; r < NREG; ++r) sm += a[r];
+            sig = allreduce_sum<16>(sm);
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) af[f * SP + i16 * NREG + r] = a[r];
+            sfl[f] = sig;
+        };
+        int f = r0;
+        R cur[4][NREG], nxt[4][NREG];
+        if (f + 4 <= len) load_rows(cur, f, 1);
+        for (; f + 4 <= len; f += 4) {
+            if (f + 8 <= len) load_rows(nxt, f + 4, 1);
+            renorm();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) step(cur[k], f + k);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int r = 0; r < NREG; ++r) cur[k][r] = nxt[k][r];
+        }
+        renorm();
+        for (; f < len; ++f) {                               // up to three left-over frames
+            R b[NREG];
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) b[r] = btile[f * SP + i16 * NREG + r];
+            step(b, f);
+        }
+        if (lane == 0) {                                     // log of the product of the chunk's forward scales
+            tl_sig[0] = sig;
+            tl_sig[1] = chunk0 ? (R)1 : sig_in;
+            tl_expo = expo;
+        }
+        load_slab(0);
+    } else if (wave == 1) {
+        R x[NREG];
+        const R* __restrict__ bnd = bt.gbound + (long long)tile * SP + i16 * NREG;
+        R part = 0;
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) {
+            x[r] = bnd[r];
+            part += x[r];
+        }
+        part = allreduce_sum<16>(part);
+        {
+            const int e = rescale_exponent(part);
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) {
+                x[r] = scale2(x[r], -e);
+                bf[(len - 1) * SP + i16 * NREG + r] = x[r];
+            }
+            qfl[len - 1] = scale2(part, -e) * (R)(1.0 / SP);  // a positive scale of the row, like q below
+        }
+        R q = 1;
+        auto step = [&](const R (&b)[NREG], int f) {         // consumes row f, produces x_{f-1}
+            R u[NREG];
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) u[r] = b[r] * x[r];
+            R qs = c[0] * u[0];
+#pragma unroll
+            for (int r = 1; r < NREG; ++r) qs += c[r] * u[r];
+            q = allreduce_sum<16>(qs);
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) {
+                x[r] = lp * u[r] + q;
+                bf[(f - 1) * SP + i16 * NREG + r] = x[r];
+            }
+            qfl[f - 1] = q;
+        };
+        int f = len - 1;
+        R cur[4][NREG], nxt[4][NREG];
+        if (f - 4 >= 0) load_rows(cur, f, -1);
+        for (; f - 4 >= 0; f -= 4) {
+            if (f - 8 >= 0) load_rows(nxt, f - 4, -1);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) step(cur[k], f - k);
+            const int e = rescale_exponent(q);               // (rows already stored keep their own scale)
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) x[r] = scale2(x[r], -e);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int r = 0; r < NREG; ++r) cur[k][r] = nxt[k][r];
+        }
+        for (; f >= 1; --f) {                                // up to three left-over frames
+            R b[NREG];
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) b[r] = btile[f * SP + i16 * NREG + r];
+            step(b, f);
+        }
+        load_slab(1);
+    } else {
+        load_slab(wave);
+    }
+    VBX_STAMP();
+    __syncthreads();
+    VBX_STAMP();
+
+    // ---- posteriors and the "entered" statistic                               (VBx.py:101-103,174) --
+    //   gamma_t = a_t x_t / sum;   entered_j += gamma_t[j] s_{t-1} / (lp a_{t-1}[j] + c_j s_{t-1}),  t >= 1
+    // rows are brought to scale 1 first (a/s sums to 1, x/q >= 1 elementwise): no product can underflow.
+    // Same lane layout as the re-run: 16 lanes x NREG states per frame, four frames per wavefront pass.
+    {
+        R* __restrict__ G = bt.gamma + (rd.row0 + t0) * SP;
+        R ent[NREG];
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) ent[r] = 0;
+#pragma unroll
+        for (int it = 0; it < kTileFrames / 16; ++it) {
+            const int f = 16 * it + 4 * wave + g4;
+            const bool ok = f < len;
+            const int fr = ok ? f : 0;
+            const R isig = fast_rcp(sfl[fr]), iq = fast_rcp(qfl[fr]);
+            const R sp = fr > 0 ? sfl[fr - 1] : tl_sig[1];
+            const R* app = fr > 0 ? af + (fr - 1) * SP : aprev0;
+            R g[NREG], ap[NREG];
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) {
+                g[r] = (af[fr * SP + i16 * NREG + r] * isig) * (bf[fr * SP + i16 * NREG + r] * iq);
+                ap[r] = app[i16 * NREG + r];
+            }
+            R sum = g[0];
+#pragma unroll
+            for (int r = 1; r < NREG; ++r) sum += g[r];
+            sum = allreduce_sum<16>(sum);
+            const R inv = ok ? fast_rcp(sum) : (R)0;
+            const bool stat = ok && t0 + f >= 1;
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) {
+                g[r] *= inv;
+                bf[f * SP + i16 * NREG + r] = g[r];         // A operand of the accumulation below (0 past the end)
+                if (ok) G[(long long)f * SP + i16 * NREG + r] = g[r];
+                if (stat) ent[r] += g[r] * sp * fast_rcp(lp * ap[r] + c[r] * sp);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) {
+            double e = (double)ent[r];                     // <= 8 terms per lane in working precision
+            e += __shfl_xor(e, 16, 64);
+            e += __shfl_xor(e, 32, 64);
+            if (g4 == 0) ent_w[wave][i16 * NREG + r] = e;
+        }
+        // this chunk's share of the total log-likelihood (VBx.py:173): log of the product of its forward
+        // scales = log(s_end 2^expo / s_in), plus the row maxima taken out of the likelihoods
+        double mpartial = 0.0;
+        if (tid < len) mpartial = (double)bt.mrow[rd.row0 + t0 + tid];
+        if (tid == 128)
+            mpartial += log((double)tl_sig[0]) - log((double)tl_sig[1]) + (double)tl_expo * 0.69314718055994530942;
+        mpartial = block_sum(mpartial, red);               // (contains the barrier ent_w needs)
+        if (tid < SP) {
+            const double e = (ent_w[0][tid] + ent_w[1][tid]) + (ent_w[2][tid] + ent_w[3][tid]);
+            bt.epart[(long long)tile * SP + tid] = tid < rd.S ? e : 0.0;
+        }
+        if (tid == 0) bt.tllpart[tile] = mpartial;
+    }
+    __syncthreads();
+    VBX_STAMP();
+
+    // ---- next M-step: C[s][d] = sum_t gamma[t][s] rho[t][d] on MFMA 16x16x4        (VBx.py:96) --
+    // M index i of tile mu <-> speaker NT*i + mu (one vector LDS read feeds every tile);
+    // N index j of half h <-> feature 32*slab + 2j + h (one 8/16-byte global load feeds both).
+    for (int slab = wave; slab * 32 < Dp; slab += 4) {
+        acc_t acc[NT][2];
+        R nsum[NT];
+#pragma unroll
+        for (int mu = 0; mu < NT; ++mu) {
+            acc[mu][0] = acc_t{0, 0, 0, 0};
+            acc[mu][1] = acc_t{0, 0, 0, 0};
+            nsum[mu] = 0;
+        }
+        const bool first = slab == wave;
+#pragma unroll
+        for (int u = 0; u < KS; ++u) {
+            const int f = 4 * u + g4;
+            R2 b2 = bv[u];
+            if (!first) b2 = *reinterpret_cast<const R2*>(rho + (long long)(t0 + min(f, len - 1)) * Dp + 32 * slab + 2 * i16);
+            R av[NT];
+#pragma unroll
+            for (int mu = 0; mu < NT; ++mu) av[mu] = bf[f * SP + NT * i16 + mu];
+#pragma unroll
+            for (int mu = 0; mu < NT; ++mu) {
+                nsum[mu] += av[mu];
+                acc[mu][0] = M::mma(av[mu], b2.x, acc[mu][0]);
+                acc[mu][1] = M::mma(av[mu], b2.y, acc[mu][1]);
+            }
+        }
+        R* __restrict__ part = bt.mpart + (long long)tile * SP * Dp;
+#pragma unroll
+        for (int mu = 0; mu < NT; ++mu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int s = NT * M::row(lane, r) + mu;
+                *reinterpret_cast<R2*>(part + (long long)s * Dp + 32 * slab + 2 * i16) = R2{acc[mu][0][r], acc[mu][1][r]};
+            }
+        }
+        if (slab == 0) {
+#pragma unroll
+            for (int mu = 0; mu < NT; ++mu) {
+                R v = nsum[mu];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                if (g4 == 0) bt.npart[(long long)tile * SP + NT * i16 + mu] = v;
+            }
+        }
+    }
+    VBX_STAMP();
+#ifdef VBX_PHASE_CLOCKS
+    if (blockIdx.x == 1 && (lane == 0) && bt.state[rec].n_iters == 3)
+        printf("chunk_post wave %d: stage %lld  rerun %lld  wait %lld  post %lld  mfma %lld cycles\n", wave,
+               clk[1] - clk[0], clk[2] - clk[1], clk[3] - clk[2], clk[4] - clk[3], clk[5] - clk[4]);
+#endif
+}
+
+}  // namespace vbx
