@@ -42,6 +42,8 @@ ALGO_PASSES = {            # kernel -> (passes over T x R, passes over T x S)
     'loglik': (1, 1),      # rho read, b write
     'fb': (0, 3),          # b read by forward and by backward, ahat write
     'post': (0, 2),        # ahat read, gamma write
+    'chunk_loglik': (1, 1),   # fused loglik + chunk operator: rho read, b write
+    'chunk_post': (1, 2),     # fused re-run + posteriors + next gamma^T rho: rho read, b read, gamma write
 }
 
 

@@ -59,7 +59,8 @@ extern "C" {
 #define VBX_OPT_CHECK_EVERY 2   /* iterations launched between two convergence polls (default 4) */
 #define VBX_OPT_PROFILE 3       /* 1: bracket every kernel launch with HIP events              */
 #define VBX_OPT_CHUNK_FRAMES 4  /* frames per scan chunk for VBX_FB_CHUNKED (0 = auto)         */
-#define VBX_OPT_FUSE 5          /* 1 (default): per-chunk fused kernels when the lattices fit in LDS */
+#define VBX_OPT_FUSE 5          /* per-chunk fused kernels when the lattices fit in LDS: 0 none, 1 chunk_post,
+                                   2 (default) chunk_post + chunk_loglik                                */
 
 typedef struct vbx_ctx vbx_ctx;
 typedef struct vbx_batch vbx_batch;

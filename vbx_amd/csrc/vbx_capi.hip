@@ -68,7 +68,7 @@ struct vbx_batch {
     std::vector<char> is_set;
     bool recs_dirty = true;
     // options
-    int fb_algo = VBX_FB_AUTO, check_every = 4, profile = 0, chunk_frames = 0, fuse = 1;
+    int fb_algo = VBX_FB_AUTO, check_every = 4, profile = 0, chunk_frames = 0, fuse = 2;
     bool mpart_valid = false;                     // mpart/npart hold gamma^T rho of the current gamma (fused path)
     // device memory
     RecDesc* d_recs = nullptr;
@@ -176,9 +176,17 @@ template <typename R> void launch_loglik(vbx_batch* b, double eps, bool raw) {
                                         b->ctx->stream, v, lraw);)
 }
 
-template <typename R, int SP> void launch_scan(vbx_batch* b, const BatchView<R>& v, bool fused_post) {
+template <typename R, int SP> void launch_scan(vbx_batch* b, const BatchView<R>& v, bool fused_post, bool fused_loglik) {
     hipStream_t st = b->ctx->stream;
-    {
+    bool have_op = false;
+    if constexpr (ChunkLoglikCfg<R, SP>::kFits) {
+        if (fused_loglik) {      // log-likelihoods and the chunk operators in one pass over rho
+            LaunchScope ls(b, VBX_K_CHUNK_LOGLIK);
+            hipLaunchKernelGGL((chunk_loglik_kernel<R, SP>), dim3(b->ntiles_total), dim3(256), 0, st, v);
+            have_op = true;
+        }
+    }
+    if (!have_op) {
         LaunchScope ls(b, VBX_K_FB);
         hipLaunchKernelGGL((scan1_kernel<R, SP>), dim3(b->ntiles_total), dim3(SP * SP / 4), 0, st, v);
     }
@@ -199,6 +207,16 @@ template <typename R, int SP> void launch_scan(vbx_batch* b, const BatchView<R>&
     }
 }
 
+template <typename R> bool fused_loglik_available(const vbx_batch* b) {
+    if (!b->use_chunked || b->fuse < 2) return false;
+    switch (b->Sp) {
+        case 16: return ChunkLoglikCfg<R, 16>::kFits;
+        case 32: return ChunkLoglikCfg<R, 32>::kFits;
+        case 64: return ChunkLoglikCfg<R, 64>::kFits;
+        default: return false;
+    }
+}
+
 // Can this batch run the fused per-chunk kernels?  (chunked scan + the lattices fit in LDS)
 template <typename R> bool fused_available(const vbx_batch* b) {
     if (!b->use_chunked || !b->fuse) return false;
@@ -210,13 +228,13 @@ template <typename R> bool fused_available(const vbx_batch* b) {
     }
 }
 
-template <typename R> void launch_fb(vbx_batch* b, double eps, bool fused_post = false) {
+template <typename R> void launch_fb(vbx_batch* b, double eps, bool fused_post = false, bool fused_loglik = false) {
     auto v = b->view<R>(eps);
     if (b->use_chunked) {
         switch (b->Sp) {
-            case 16: launch_scan<R, 16>(b, v, fused_post); return;
-            case 32: launch_scan<R, 32>(b, v, fused_post); return;
-            case 64: launch_scan<R, 64>(b, v, fused_post); return;
+            case 16: launch_scan<R, 16>(b, v, fused_post, fused_loglik); return;
+            case 32: launch_scan<R, 32>(b, v, fused_post, fused_loglik); return;
+            case 64: launch_scan<R, 64>(b, v, fused_post, fused_loglik); return;
             default: break;
         }
     }
@@ -256,8 +274,9 @@ template <typename R> void launch_iteration(vbx_batch* b, double eps) {
         // first iteration after an upload needs the stand-alone accumulation
         if (!b->mpart_valid) launch_mstep_acc<R>(b, eps);
         launch_mstep_fin<R>(b, eps);
-        launch_loglik<R>(b, eps, false);
-        launch_fb<R>(b, eps, true);
+        const bool fl = fused_loglik_available<R>(b);
+        if (!fl) launch_loglik<R>(b, eps, false);
+        launch_fb<R>(b, eps, true, fl);
         launch_iter_fin<R>(b, eps);
         b->mpart_valid = true;
         return;
@@ -531,7 +550,8 @@ int vbx_batch_set_option(vbx_batch* b, int option, int64_t value) {
             b->profile = value ? 1 : 0;
             return VBX_OK;
         case VBX_OPT_FUSE:
-            b->fuse = value ? 1 : 0;
+            if (value < 0 || value > 2) FAIL(b->ctx, VBX_ERR_INVALID, "fuse must be 0, 1 or 2");
+            b->fuse = (int)value;
             b->mpart_valid = false;
             return VBX_OK;
         case VBX_OPT_CHUNK_FRAMES:

@@ -345,4 +345,183 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 3 : 1)) void chu
 #endif
 }
 
+// =======================================================================================
+// chunk_loglik_kernel (one workgroup = one chunk of kTileFrames frames):
+//   phase 1  per-frame speaker log-likelihoods on MFMA 16x16x4 (loglik_kernel):          VBx.py:97
+//            l = Fa (rho alpha^T + bias),  m_t = max_s l,  b = exp(l - m_t)  -> bmat, mrow (HBM)
+//            and, for phase 2, lp*b and c*b -> LDS
+//   phase 2  the chunk's forward transfer operator (scan1_kernel), straight from LDS:   VBx.py:167-171
+//            x <- (lp b_t) x + (c b_t) sum(x)   for every operator column, t = t0 .. t0+len-1
+// Phase 2 differs from scan1_kernel in instruction count only: the products lp*b and c*b are shared by
+// all columns and made once in phase 1, and columns are rescaled (exact powers of two) every four frames
+// instead of every frame -- a frame shrinks a column sum by at least min c = 1e-8, so four frames stay
+// inside the f32 range.
+// lane = (column, part): PH = 256/SP lanes share a column and hold NR = SP/PH states each.
+// =======================================================================================
+template <typename R, int SP> struct ChunkLoglikCfg {
+    static constexpr int kBytes = 2 * kTileFrames * SP * (int)sizeof(R) + 4096;
+    static constexpr bool kFits = kBytes <= 160 * 1024 && SP * SP / 4 <= 1024;
+};
+
+template <typename R, int SP>
+__global__ __launch_bounds__(256) void chunk_loglik_kernel(BatchView<R> bt) {
+    using M = Mfma16<R>;
+    using acc_t = typename M::acc_t;
+    using R4 = typename Vec<R>::v4;
+    constexpr int NT = SP / 16;
+    constexpr int PH = 256 / SP, NR = SP / PH;         // operator build: lanes per column, states per lane
+    __shared__ __attribute__((aligned(16))) R blp[kTileFrames * SP];   // lp * b
+    __shared__ __attribute__((aligned(16))) R bct[kTileFrames * SP];   // c  * b
+    __shared__ __attribute__((aligned(16))) R b0row[SP];               // b of frame 0 of the recording
+    const int tile = blockIdx.x;
+    const int rec = bt.tile_rec[tile];
+    if (bt.state[rec].done) return;
+    const RecDesc rd = bt.recs[rec];
+    const int Dp = bt.Dp;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, g = lane >> 4;
+    const int t0 = bt.tile_t0[tile];
+    const int len = min(kTileFrames, rd.T - t0);
+    const R lp = (R)rd.lp;
+
+    // ---- phase 1: wave w owns frames [32w, 32w+32) of the chunk = 2 M-tiles ----------------------
+    {
+        const int f0 = t0 + 32 * wave;
+        const R* __restrict__ rho = bt.rho + rd.row0 * Dp;
+        const R* __restrict__ alpha = bt.alpha + (long long)rec * SP * Dp;
+        acc_t acc[2][NT];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = acc_t{0, 0, 0, 0};
+        // rows past the end of the recording are clamped (their results are never stored)
+        const int rowA0 = min(f0 + i, rd.T - 1), rowA1 = min(f0 + 16 + i, rd.T - 1);
+        constexpr int QB = sizeof(R) == 8 ? 2 : 4;     // K blocks of 16 loaded together
+        const int nq = Dp / 16;
+#pragma unroll 1
+        for (int q0 = 0; q0 < nq; q0 += QB) {
+            R4 a0[QB], a1[QB];
+#pragma unroll
+            for (int u = 0; u < QB; ++u) {
+                const int kk = 16 * min(q0 + u, nq - 1) + 4 * g;
+                a0[u] = *reinterpret_cast<const R4*>(rho + (long long)rowA0 * Dp + kk);
+                a1[u] = *reinterpret_cast<const R4*>(rho + (long long)rowA1 * Dp + kk);
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                R4 bfr[QB];
+#pragma unroll
+                for (int u = 0; u < QB; ++u) {
+                    const int kk = 16 * min(q0 + u, nq - 1) + 4 * g;
+                    bfr[u] = *reinterpret_cast<const R4*>(alpha + (long long)(16 * n + i) * Dp + kk);
+                }
+#pragma unroll
+                for (int u = 0; u < QB; ++u) {
+                    if (q0 + u < nq) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            acc[0][n] = M::mma(a0[u][r], bfr[u][r], acc[0][n]);
+                            acc[1][n] = M::mma(a1[u][r], bfr[u][r], acc[1][n]);
+                        }
+                    }
+                }
+            }
+        }
+        const R Fa = (R)rd.Fa;
+        R biasv[NT], cv[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int s = 16 * n + i;
+            biasv[n] = bt.bias[(long long)rec * SP + s];
+            cv[n] = (s < rd.S) ? (R)((1.0 - rd.lp) * bt.pi[(long long)rec * SP + s] + 1e-8) : (R)0;
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int fl = 32 * wave + 16 * m + M::row(lane, r);     // frame within the chunk
+                R v[NT];
+                R mx = neg_inf<R>();
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int s = 16 * n + i;
+                    v[n] = (s < rd.S) ? Fa * (acc[m][n][r] + biasv[n]) : neg_inf<R>();
+                    mx = vmax(mx, v[n]);
+                }
+                mx = allreduce_max<16>(mx);
+                const bool ok = fl < len;
+                const long long cell = (rd.row0 + t0 + fl) * SP;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const R b = exp_r(v[n] - mx);
+                    blp[fl * SP + 16 * n + i] = lp * b;
+                    bct[fl * SP + 16 * n + i] = cv[n] * b;
+                    if (ok) bt.bmat[cell + 16 * n + i] = b;
+                    if (t0 + fl == 0) b0row[16 * n + i] = b;
+                }
+                if (ok && i == 0) bt.mrow[rd.row0 + t0 + fl] = mx;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: transfer operator of the chunk ---------------------------------------------------
+    {
+        const int col = tid / PH, part = tid % PH, j0 = part * NR;
+        R x[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) x[r] = (j0 + r == col) ? (R)1 : (R)0;
+        int expo = 0, first = 0;
+        if (t0 == 0) {                       // frame 0 of the recording: x <- b_0 * x (VBx.py:163, no transition)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) x[r] *= b0row[j0 + r];
+            first = 1;
+        }
+        auto colsum = [&]() {
+            R sm = x[0];
+#pragma unroll
+            for (int r = 1; r < NR; ++r) sm += x[r];
+            return column_sum<PH>(sm);
+        };
+        auto frame = [&](int step, R sig) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) x[r] = blp[step * SP + j0 + r] * x[r] + bct[step * SP + j0 + r] * sig;
+        };
+        int step = first;
+        for (; step + 4 <= len; step += 4) {
+            R sig = colsum();
+            const int e = rescale_exponent(sig);
+            expo += e;
+            sig = scale2(sig, -e);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) x[r] = scale2(x[r], -e);
+            frame(step, sig);
+#pragma unroll
+            for (int k = 1; k < 4; ++k) frame(step + k, colsum());
+        }
+        for (; step < len; ++step) {
+            R sig = colsum();
+            const int e = rescale_exponent(sig);
+            expo += e;
+            sig = scale2(sig, -e);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) x[r] = scale2(x[r], -e);
+            frame(step, sig);
+        }
+        {   // final power-of-two normalisation: column sums end in [0.5, 1)
+            const R sig = colsum();
+            const int e = rescale_exponent(sig);
+            expo += e;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) x[r] = scale2(x[r], -e);
+            // an all-zero column (b = 0 for its state at frame 0, or a padded state) must never win the
+            // exponent maximum in scan2
+            if (!(sig > (R)0)) expo = -(1 << 24);
+        }
+        R* __restrict__ dst = bt.op + ((long long)tile * SP + col) * SP + j0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) dst[r] = x[r];
+        if (part == 0) bt.opexp[(long long)tile * SP + col] = expo;
+    }
+}
+
 }  // namespace vbx
