@@ -161,7 +161,9 @@ template <int W, typename R> __device__ __forceinline__ R allreduce_max(R v) {
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }   // 1 ulp
 __device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
-__device__ __forceinline__ float exp_r(float x) { return expf(x); }
+// exp of a non-positive argument: v_exp_f32 on x*log2(e).  The multiplication costs |x| * 2^-24 of relative
+// accuracy, i.e. 1e-6 for likelihoods 1e-7 times the row maximum -- far inside the 1e-4 budget of the f32 path.
+__device__ __forceinline__ float exp_r(float x) { return __expf(x); }
 __device__ __forceinline__ double exp_r(double x) { return exp(x); }
 template <typename R> __device__ __forceinline__ R neg_inf() { return -(R)INFINITY; }
 

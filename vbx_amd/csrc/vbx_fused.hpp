@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 3 : 1)) void chu
     }
     VBX_STAMP();
 #ifdef VBX_PHASE_CLOCKS
-    if (blockIdx.x == 1 && (lane == 0) && bt.state[rec].n_iters == 3)
+    if ((blockIdx.x % 1000) == 1 && (lane == 0) && bt.state[rec].n_iters == 3)
         printf("chunk_post wave %d: stage %lld  rerun %lld  wait %lld  post %lld  mfma %lld cycles\n", wave,
                clk[1] - clk[0], clk[2] - clk[1], clk[3] - clk[2], clk[4] - clk[3], clk[5] - clk[4]);
 #endif
@@ -348,31 +348,40 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 3 : 1)) void chu
 // =======================================================================================
 // chunk_loglik_kernel (one workgroup = one chunk of kTileFrames frames):
 //   phase 1  per-frame speaker log-likelihoods on MFMA 16x16x4 (loglik_kernel):          VBx.py:97
-//            l = Fa (rho alpha^T + bias),  m_t = max_s l,  b = exp(l - m_t)  -> bmat, mrow (HBM)
-//            and, for phase 2, lp*b and c*b -> LDS
+//            l = Fa (rho alpha^T + bias),  m_t = max_s l,  b = exp(l - m_t)  -> bmat, mrow (HBM) and LDS
 //   phase 2  the chunk's forward transfer operator (scan1_kernel), straight from LDS:   VBx.py:167-171
-//            x <- (lp b_t) x + (c b_t) sum(x)   for every operator column, t = t0 .. t0+len-1
-// Phase 2 differs from scan1_kernel in instruction count only: the products lp*b and c*b are shared by
-// all columns and made once in phase 1, and columns are rescaled (exact powers of two) every four frames
-// instead of every frame -- a frame shrinks a column sum by at least min c = 1e-8, so four frames stay
-// inside the f32 range.
-// lane = (column, part): PH = 256/SP lanes share a column and hold NR = SP/PH states each.
+//            x <- b_t (lp x + c sum(x))   for every operator column, t = t0 .. t0+len-1
+// Phase 2 differs from scan1_kernel in instruction count only: columns are rescaled (exact powers of two)
+// every four frames instead of every frame -- a frame shrinks a column sum by at least min c = 1e-8, so
+// four frames stay inside the f32 range.
 // =======================================================================================
+constexpr int kAlphaSlice = 128;
 template <typename R, int SP> struct ChunkLoglikCfg {
-    static constexpr int kBytes = 2 * kTileFrames * SP * (int)sizeof(R) + 4096;
-    static constexpr bool kFits = kBytes <= 160 * 1024 && SP * SP / 4 <= 1024;
+    static constexpr int kBytes = (kTileFrames > kAlphaSlice + 4 ? kTileFrames : kAlphaSlice + 4) * SP * (int)sizeof(R) + 1024;
+    static constexpr bool kFits = kBytes <= 160 * 1024;
 };
 
 template <typename R, int SP>
-__global__ __launch_bounds__(256) void chunk_loglik_kernel(BatchView<R> bt) {
+__global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)sizeof(R) <= 256 ? 4 : 2)) void chunk_loglik_kernel(BatchView<R> bt) {
     using M = Mfma16<R>;
     using acc_t = typename M::acc_t;
     using R4 = typename Vec<R>::v4;
     constexpr int NT = SP / 16;
-    constexpr int PH = 256 / SP, NR = SP / PH;         // operator build: lanes per column, states per lane
-    __shared__ __attribute__((aligned(16))) R blp[kTileFrames * SP];   // lp * b
-    __shared__ __attribute__((aligned(16))) R bct[kTileFrames * SP];   // c  * b
-    __shared__ __attribute__((aligned(16))) R b0row[SP];               // b of frame 0 of the recording
+    // operator build: PH lanes share a column and hold NR states each.  Fewer lanes per column = fewer issue
+    // slots per frame (the column sum needs log2(PH) DPP stages with their wait states): 72 / 46 / 39 slots per
+    // chunk-frame for PH = 8 / 4 / 2 at SP = 32, but also fewer wavefronts to hide each other's latency.
+    // Measured on 64 recordings of T = 10 000: 171 / 163 / 176 us per launch, so PH = 4 (two wavefronts build
+    // the operator, the other two retire after phase 1).
+#ifndef VBX_OP_LANES
+#define VBX_OP_LANES 4
+#endif
+    constexpr int PH = (SP * VBX_OP_LANES <= 256) ? VBX_OP_LANES : 256 / SP, NR = SP / PH;
+    constexpr int AST = kAlphaSlice + 4;               // padded row of the alpha slice: conflict-free fragment reads
+    // one LDS region, two lives: the alpha slice during the MFMA pass, then b of the chunk
+    constexpr int kLds = kTileFrames * SP > SP * AST ? kTileFrames * SP : SP * AST;
+    __shared__ __attribute__((aligned(16))) R lds[kLds];
+    R* const al = lds;                                 // alpha[:, k0 : k0 + kAlphaSlice], rows padded to AST
+    R* const btile = lds;                              // b[kTileFrames][SP]
     const int tile = blockIdx.x;
     const int rec = bt.tile_rec[tile];
     if (bt.state[rec].done) return;
@@ -383,6 +392,11 @@ __global__ __launch_bounds__(256) void chunk_loglik_kernel(BatchView<R> bt) {
     const int len = min(kTileFrames, rd.T - t0);
     const R lp = (R)rd.lp;
 
+#ifdef VBX_PHASE_CLOCKS
+    long long clk[8];
+    int nclk = 0;
+#endif
+    VBX_STAMP();
     // ---- phase 1: wave w owns frames [32w, 32w+32) of the chunk = 2 M-tiles ----------------------
     {
         const int f0 = t0 + 32 * wave;
@@ -395,45 +409,62 @@ __global__ __launch_bounds__(256) void chunk_loglik_kernel(BatchView<R> bt) {
             for (int n = 0; n < NT; ++n) acc[m][n] = acc_t{0, 0, 0, 0};
         // rows past the end of the recording are clamped (their results are never stored)
         const int rowA0 = min(f0 + i, rd.T - 1), rowA1 = min(f0 + 16 + i, rd.T - 1);
-        constexpr int QB = sizeof(R) == 8 ? 2 : 4;     // K blocks of 16 loaded together
-        const int nq = Dp / 16;
+        constexpr int QB = 2;                          // K blocks of 16 whose rho fragments are loaded together
+        // The speaker means (B operand) are staged in LDS once per workgroup, kAlphaSlice feature dims at a
+        // time: every wave needs all of alpha, and fetching it per wave from L2 cost as much as streaming rho
+        // (a CU sustains ~10 B/clk of global loads whether they hit L2 or HBM).
 #pragma unroll 1
-        for (int q0 = 0; q0 < nq; q0 += QB) {
-            R4 a0[QB], a1[QB];
-#pragma unroll
-            for (int u = 0; u < QB; ++u) {
-                const int kk = 16 * min(q0 + u, nq - 1) + 4 * g;
-                a0[u] = *reinterpret_cast<const R4*>(rho + (long long)rowA0 * Dp + kk);
-                a1[u] = *reinterpret_cast<const R4*>(rho + (long long)rowA1 * Dp + kk);
-            }
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                R4 bfr[QB];
-#pragma unroll
-                for (int u = 0; u < QB; ++u) {
-                    const int kk = 16 * min(q0 + u, nq - 1) + 4 * g;
-                    bfr[u] = *reinterpret_cast<const R4*>(alpha + (long long)(16 * n + i) * Dp + kk);
+        for (int k0 = 0; k0 < Dp; k0 += kAlphaSlice) {
+            const int kw = min(kAlphaSlice, Dp - k0);          // multiple of 32
+            if (k0 > 0) __syncthreads();
+            {
+                const int vpr = kw / 4;                        // 16-byte vectors per speaker row
+                for (int idx = tid; idx < SP * vpr; idx += 256) {
+                    const int row = idx / vpr, c4 = idx - row * vpr;
+                    *reinterpret_cast<R4*>(al + row * AST + 4 * c4) =
+                        *reinterpret_cast<const R4*>(alpha + (long long)row * Dp + k0 + 4 * c4);
                 }
+            }
+            const int nq = kw / 16;
+            R4 a0[QB], a1[QB];
+            auto load_a = [&](int q0) {
 #pragma unroll
                 for (int u = 0; u < QB; ++u) {
-                    if (q0 + u < nq) {
+                    const int kk = k0 + 16 * min(q0 + u, nq - 1) + 4 * g;
+                    a0[u] = *reinterpret_cast<const R4*>(rho + (long long)rowA0 * Dp + kk);
+                    a1[u] = *reinterpret_cast<const R4*>(rho + (long long)rowA1 * Dp + kk);
+                }
+            };
+            load_a(0);
+            __syncthreads();
+#pragma unroll 1
+            for (int q0 = 0; q0 < nq; q0 += QB) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            acc[0][n] = M::mma(a0[u][r], bfr[u][r], acc[0][n]);
-                            acc[1][n] = M::mma(a1[u][r], bfr[u][r], acc[1][n]);
+                for (int n = 0; n < NT; ++n) {
+                    R4 bfr[QB];
+#pragma unroll
+                    for (int u = 0; u < QB; ++u)
+                        bfr[u] = *reinterpret_cast<const R4*>(al + (16 * n + i) * AST + 16 * min(q0 + u, nq - 1) + 4 * g);
+#pragma unroll
+                    for (int u = 0; u < QB; ++u) {
+                        if (q0 + u < nq) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                acc[0][n] = M::mma(a0[u][r], bfr[u][r], acc[0][n]);
+                                acc[1][n] = M::mma(a1[u][r], bfr[u][r], acc[1][n]);
+                            }
                         }
                     }
                 }
+                if (q0 + QB < nq) load_a(q0 + QB);
             }
         }
+        VBX_STAMP();
+        __syncthreads();                               // every wave is done with the alpha slice: b may overwrite it
         const R Fa = (R)rd.Fa;
-        R biasv[NT], cv[NT];
+        R biasv[NT];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int s = 16 * n + i;
-            biasv[n] = bt.bias[(long long)rec * SP + s];
-            cv[n] = (s < rd.S) ? (R)((1.0 - rd.lp) * bt.pi[(long long)rec * SP + s] + 1e-8) : (R)0;
-        }
+        for (int n = 0; n < NT; ++n) biasv[n] = bt.bias[(long long)rec * SP + 16 * n + i];
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -453,27 +484,30 @@ __global__ __launch_bounds__(256) void chunk_loglik_kernel(BatchView<R> bt) {
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     const R b = exp_r(v[n] - mx);
-                    blp[fl * SP + 16 * n + i] = lp * b;
-                    bct[fl * SP + 16 * n + i] = cv[n] * b;
+                    btile[fl * SP + 16 * n + i] = b;
                     if (ok) bt.bmat[cell + 16 * n + i] = b;
-                    if (t0 + fl == 0) b0row[16 * n + i] = b;
                 }
                 if (ok && i == 0) bt.mrow[rd.row0 + t0 + fl] = mx;
             }
         }
     }
+    VBX_STAMP();
     __syncthreads();
+    VBX_STAMP();
 
     // ---- phase 2: transfer operator of the chunk ---------------------------------------------------
-    {
+    if (tid < SP * PH) {
         const int col = tid / PH, part = tid % PH, j0 = part * NR;
-        R x[NR];
+        R x[NR], c[NR];
 #pragma unroll
-        for (int r = 0; r < NR; ++r) x[r] = (j0 + r == col) ? (R)1 : (R)0;
+        for (int r = 0; r < NR; ++r) {
+            x[r] = (j0 + r == col) ? (R)1 : (R)0;
+            c[r] = (j0 + r < rd.S) ? (R)((1.0 - rd.lp) * bt.pi[(long long)rec * SP + j0 + r] + 1e-8) : (R)0;
+        }
         int expo = 0, first = 0;
         if (t0 == 0) {                       // frame 0 of the recording: x <- b_0 * x (VBx.py:163, no transition)
 #pragma unroll
-            for (int r = 0; r < NR; ++r) x[r] *= b0row[j0 + r];
+            for (int r = 0; r < NR; ++r) x[r] *= btile[j0 + r];
             first = 1;
         }
         auto colsum = [&]() {
@@ -484,7 +518,7 @@ __global__ __launch_bounds__(256) void chunk_loglik_kernel(BatchView<R> bt) {
         };
         auto frame = [&](int step, R sig) {
 #pragma unroll
-            for (int r = 0; r < NR; ++r) x[r] = blp[step * SP + j0 + r] * x[r] + bct[step * SP + j0 + r] * sig;
+            for (int r = 0; r < NR; ++r) x[r] = btile[step * SP + j0 + r] * (lp * x[r] + c[r] * sig);
         };
         int step = first;
         for (; step + 4 <= len; step += 4) {
@@ -522,6 +556,12 @@ __global__ __launch_bounds__(256) void chunk_loglik_kernel(BatchView<R> bt) {
         for (int r = 0; r < NR; ++r) dst[r] = x[r];
         if (part == 0) bt.opexp[(long long)tile * SP + col] = expo;
     }
+    VBX_STAMP();
+#ifdef VBX_PHASE_CLOCKS
+    if ((blockIdx.x % 1000) == 1 && (lane == 0) && bt.state[rec].n_iters == 3)
+        printf("chunk_loglik wave %d: mfma %lld  epilogue %lld  wait %lld  operator %lld cycles\n", wave,
+               clk[1] - clk[0], clk[2] - clk[1], clk[3] - clk[2], clk[4] - clk[3]);
+#endif
 }
 
 }  // namespace vbx
