@@ -47,6 +47,21 @@ ALGO_PASSES = {            # kernel -> (passes over T x R, passes over T x S)
 }
 
 
+def pmc_traffic(kernel, workload):
+    """HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes (tools/pmc_traffic.py),
+    or None when no profile of exactly this workload is on file.  The newest matching file wins."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(REPO, 'profiles', '*_pmc_traffic.json'))):
+        try:
+            doc = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if doc.get('workload') == workload and kernel in doc.get('kernels', {}):
+            best = (doc['kernels'][kernel]['hbm_bytes_per_launch'], os.path.relpath(path, REPO))
+    return best
+
+
 def algo_bytes(kernel, T, R, S, esize):
     pr, ps = ALGO_PASSES[kernel]
     return esize * (pr * T * R + ps * T * S)
@@ -169,6 +184,8 @@ def main():
         dom = max((k for k in per_kernel if k in ALGO_PASSES), key=lambda k: per_kernel[k]['avg_us'])
         dom_bytes = args.batch * algo_bytes(dom, args.T, args.D, args.S, esize)
         achieved = dom_bytes / (per_kernel[dom]['avg_us'] * 1e-6) / 1e9
+        traffic = pmc_traffic(dom, {'batch': args.batch, 'T': args.T, 'S': args.S, 'D': args.D,
+                                    'precision': args.precision})
         out = {
             'metric': 'VB EM iterations/sec (T=10k xvecs, R=128, S=30)',
             'value': total_units / elapsed,
@@ -192,7 +209,9 @@ def main():
             'device': info['name'],
             'kernels_avg_us': {k: round(v['avg_us'], 2) for k, v in per_kernel.items()},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': traffic[0] if traffic else None,
+                         'traffic_source': traffic[1] if traffic else None,
                          'algorithmic_bytes_per_launch': dom_bytes,
                          'avg_launch_us': per_kernel[dom]['avg_us']},
             'gamma_checks': {'row_sum_max_dev': float(np.abs(res0['gamma'].sum(1) - 1).max()),

@@ -11,4 +11,6 @@ common="python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --cpu-iters 0 --n
 timeout 600 rocprofv3 --kernel-trace --stats -d $out/trace -o trace -- $common > $out/trace.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/fetch -o fetch -- $common > $out/fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/write -o write -- $common > $out/write.log 2>&1
-ls -R $out | head -40
+cd $GRAFT_REPO_ROOT
+python tools/rocpd_stats.py $out/trace/trace_results.db $out/kernel_stats.txt > /dev/null
+cat $out/kernel_stats.txt
