@@ -97,8 +97,8 @@ def cpu_baseline(T, S, D, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=64, help='recordings per GPU')
     ap.add_argument('--T', type=int, default=10000)
     ap.add_argument('--S', type=int, default=30)
