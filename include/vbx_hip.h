@@ -57,7 +57,8 @@ extern "C" {
 /* options for vbx_batch_set_option */
 #define VBX_OPT_FB_ALGO 1
 #define VBX_OPT_CHECK_EVERY 2   /* iterations launched between two convergence polls (default 4) */
-#define VBX_OPT_PROFILE 3       /* 1: bracket every kernel launch with HIP events              */
+#define VBX_OPT_PROFILE 3       /* 0: off; 1: bracket every kernel launch with HIP events;
+                                   2*mask: only the kernel classes whose bit (1 << VBX_K_*) is set in mask */
 #define VBX_OPT_CHUNK_FRAMES 4  /* frames per scan chunk for VBX_FB_CHUNKED (0 = auto)         */
 #define VBX_OPT_FUSE 5          /* per-chunk fused kernels when the lattices fit in LDS: 0 none, 1 chunk_post,
                                    2 (default) chunk_post + chunk_loglik                                */

@@ -191,6 +191,13 @@ class Batch:
         if fuse is not None:
             self.set_option(OPT_FUSE, int(fuse))
 
+    def profile_kernels(self, names=None):
+        """HIP events around every launch (names=None), around the given kernel classes only, or off ([])."""
+        if names is None:
+            self.set_option(OPT_PROFILE, 1)
+        else:
+            self.set_option(OPT_PROFILE, 2 * sum(1 << K_NAMES.index(n) for n in names))
+
     def set_option(self, option: int, value: int):
         self.ctx.check(self._lib.vbx_batch_set_option(self._h, int(option), int(value)), 'vbx_batch_set_option')
 

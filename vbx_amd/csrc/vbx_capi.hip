@@ -68,7 +68,8 @@ struct vbx_batch {
     std::vector<char> is_set;
     bool recs_dirty = true;
     // options
-    int fb_algo = VBX_FB_AUTO, check_every = 4, profile = 0, chunk_frames = 0, fuse = 2;
+    int fb_algo = VBX_FB_AUTO, check_every = 4, chunk_frames = 0, fuse = 2;
+    int64_t profile = 0;                          // bit k: bracket launches of kernel class k with HIP events
     bool mpart_valid = false;                     // mpart/npart hold gamma^T rho of the current gamma (fused path)
     // device memory
     RecDesc* d_recs = nullptr;
@@ -125,7 +126,7 @@ struct LaunchScope {   // brackets one kernel launch with events when profiling 
     vbx_batch* b;
     EventPair* ep = nullptr;
     LaunchScope(vbx_batch* b_, int klass) : b(b_) {
-        if (!b->profile) return;
+        if (!((b->profile >> klass) & 1)) return;
         if (b->ev_used == b->ev_pool.size()) {
             EventPair p{klass, nullptr, nullptr};
             if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
@@ -547,7 +548,7 @@ int vbx_batch_set_option(vbx_batch* b, int option, int64_t value) {
             b->check_every = (int)value;
             return VBX_OK;
         case VBX_OPT_PROFILE:
-            b->profile = value ? 1 : 0;
+            b->profile = value == 1 ? ((int64_t)1 << VBX_K_COUNT) - 1 : value < 0 ? 0 : (value >> 1);
             return VBX_OK;
         case VBX_OPT_FUSE:
             if (value < 0 || value > 2) FAIL(b->ctx, VBX_ERR_INVALID, "fuse must be 0, 1 or 2");
