@@ -60,6 +60,8 @@ extern "C" {
 #define VBX_OPT_PROFILE 3       /* 0: off; 1: bracket every kernel launch with HIP events;
                                    2*mask: only the kernel classes whose bit (1 << VBX_K_*) is set in mask */
 #define VBX_OPT_CHUNK_FRAMES 4  /* frames per scan chunk for VBX_FB_CHUNKED (0 = auto)         */
+#define VBX_OPT_SCAN_GROUP 6    /* chunks per group of the two-level boundary walk: 0 auto (sqrt of the chunk count
+                                   once a recording has >= 160 chunks), 1 flat chain, >= 2 explicit              */
 #define VBX_OPT_FUSE 5          /* per-chunk fused kernels when the lattices fit in LDS: 0 none, 1 chunk_post,
                                    2 (default) chunk_post + chunk_loglik                                */
 

@@ -79,12 +79,44 @@ def scan2_apply(y, cols, expo, dtype):
     w = np.where(pos, np.ldexp(y, np.clip(expo - top, -100000, 100000)), 0).astype(dtype)
     return (w[:, None] * cols).sum(axis=0).astype(dtype)
 
+def compose(op_next, op_prev, dtype):
+    """Operator of two consecutive chunk ranges: (cols, expo) of F_next F_prev (scan_compose kernel).
+    Every column of F_prev is pushed through F_next exactly like a boundary vector in scan2_apply, but its
+    scale is kept: column i of the product = 2^(expo_prev[i] + top_i) * sum_j w_j col_next_j, renormalised so
+    that the column sum lies in [0.5, 1)."""
+    cols_n, expo_n = op_next
+    cols_p, expo_p = op_prev
+    S = cols_p.shape[0]
+    out = np.zeros_like(cols_p)
+    eo = np.full(S, NEG_BIG, dtype=np.int64)
+    for i in range(S):
+        y = cols_p[i]
+        pos = y > 0
+        if not pos.any() or expo_p[i] <= NEG_BIG // 2:
+            continue
+        with np.errstate(divide='ignore'):
+            tj = np.where(pos, expo_n + np.frexp(y)[1], NEG_BIG * 4)
+        top = tj.max()
+        if top <= NEG_BIG:                      # the support of the column meets only zero columns of F_next
+            continue
+        w = np.where(pos, np.ldexp(y, np.clip(expo_n - top, -100000, 100000)), 0).astype(dtype)
+        v = (w[:, None] * cols_n).sum(axis=0).astype(dtype)
+        sig = v.sum(dtype=dtype)
+        if not sig > 0:
+            continue
+        e = int(_rescale_exponent(np.asarray(sig), dtype))
+        out[i] = np.ldexp(v, -e).astype(dtype)
+        eo[i] = expo_p[i] + top + e
+    return out, eo
+
 
 def forward_backward_chunked(lls, pi, loopProb, ip=None, chunk=128, dtype=np.float64, pad_to=None,
-                             zero_column_fix=True, clamp=True):
+                             zero_column_fix=True, clamp=True, super_group=1):
     """gamma, tll, entered -- same contract as vbx_oracle.fb_linear, computed the chunked way.
     ``pad_to`` appends padded speakers exactly as the device layout does (b = 0, c = 0, no initial
-    mass); ``zero_column_fix=False`` reproduces the bug the first device version had."""
+    mass); ``zero_column_fix=False`` reproduces the bug the first device version had.  ``super_group`` > 1 walks
+    the chunk boundaries in two levels (compose groups of that many chunk operators, walk the groups, then walk
+    inside every group), as the device does for long recordings."""
     lls = np.asarray(lls, dtype=np.float64)
     T, S_true = lls.shape
     pi = np.asarray(pi, dtype=np.float64)
@@ -111,12 +143,36 @@ def forward_backward_chunked(lls, pi, loopProb, ip=None, chunk=128, dtype=np.flo
     fbound[0] = ip0
     gbound[K - 1] = np.concatenate([np.ones(S_true, dtype=dtype), np.zeros(S - S_true, dtype=dtype)])
     live = np.arange(S) < S_true
-    for k in range(K - 1):
-        fbound[k + 1] = scan2_apply(fbound[k], *ops[k], dtype)
-    for k in range(K - 1, 0, -1):
-        gbound[k - 1] = scan2_apply_transposed(gbound[k], *ops[k], dtype)
-        if zero_column_fix:
-            gbound[k - 1] = np.where(live, gbound[k - 1], 0).astype(dtype)
+    def mask(v):
+        return np.where(live, v, 0).astype(dtype) if zero_column_fix else v
+
+    if super_group <= 1:
+        for k in range(K - 1):
+            fbound[k + 1] = scan2_apply(fbound[k], *ops[k], dtype)
+        for k in range(K - 1, 0, -1):
+            gbound[k - 1] = mask(scan2_apply_transposed(gbound[k], *ops[k], dtype))
+    else:
+        G = super_group
+        starts_s = list(range(0, K, G))
+        sops = []
+        for a in starts_s:                            # level 1: one operator per group of G chunks
+            b = min(a + G, K)
+            acc = ops[a]
+            for k in range(a + 1, b):
+                acc = compose(ops[k], acc, dtype)
+            sops.append(acc)
+        for s_i, a in enumerate(starts_s[:-1]):       # level 2: boundaries at the group starts / ends
+            fbound[starts_s[s_i + 1]] = scan2_apply(fbound[a], *sops[s_i], dtype)
+        for s_i in range(len(starts_s) - 1, 0, -1):
+            a = starts_s[s_i]
+            b = min(a + G, K)
+            gbound[a - 1] = mask(scan2_apply_transposed(gbound[b - 1], *sops[s_i], dtype))
+        for a in starts_s:                            # level 3: inside every group
+            b = min(a + G, K)
+            for k in range(a, b - 1):
+                fbound[k + 1] = scan2_apply(fbound[k], *ops[k], dtype)
+            for k in range(b - 1, a, -1):
+                gbound[k - 1] = mask(scan2_apply_transposed(gbound[k], *ops[k], dtype))
     ahat = np.empty((T, S), dtype=dtype)
     bhat = np.empty((T, S), dtype=dtype)
     tll = 0.0

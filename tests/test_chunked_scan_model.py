@@ -87,3 +87,17 @@ def test_subnormal_likelihoods_do_not_overflow_the_rescaling():
     assert np.all(np.isfinite(good))
     np.testing.assert_allclose(good, ref, rtol=0, atol=5e-6)
     np.testing.assert_allclose(tll, tll_ref, rtol=1e-6)
+
+
+@pytest.mark.parametrize('dtype,tol', [(np.float64, 1e-12), (np.float32, 5e-6)])
+@pytest.mark.parametrize('group', [2, 3, 8])
+def test_two_level_boundary_walk_model(dtype, tol, group):
+    """compose() + group-level walk + in-group walks reproduce the flat chain of mat-vecs (exponents and all)."""
+    lls, pi = make_lls(1500, 9, seed=4, scale=5.0)
+    lls[0, 2] = -1e4                              # a zero operator column in the very first chunk
+    for lp in (0.9, 0.0):
+        ref, tll_ref, ent_ref = orc.fb_linear(lls, pi, lp)
+        g, tll, ent = cs.forward_backward_chunked(lls, pi, lp, chunk=64, dtype=dtype, pad_to=16, super_group=group)
+        np.testing.assert_allclose(g, ref, rtol=0, atol=tol)
+        np.testing.assert_allclose(tll, tll_ref, rtol=1e-6)
+        np.testing.assert_allclose(ent, ent_ref, rtol=1e-4, atol=1e-6)

@@ -12,7 +12,7 @@ from . import build as _build
 VBX_F32, VBX_F64 = 0, 1
 PREC_FP32, PREC_FP64 = 0, 1
 FB_AUTO, FB_SEQUENTIAL, FB_CHUNKED = 0, 1, 2
-OPT_FB_ALGO, OPT_CHECK_EVERY, OPT_PROFILE, OPT_CHUNK_FRAMES, OPT_FUSE = 1, 2, 3, 4, 5
+OPT_FB_ALGO, OPT_CHECK_EVERY, OPT_PROFILE, OPT_CHUNK_FRAMES, OPT_FUSE, OPT_SCAN_GROUP = 1, 2, 3, 4, 5, 6
 K_NAMES = ['prep', 'mstep_acc', 'mstep_fin', 'loglik', 'fb', 'fb_aux', 'post', 'iter_fin', 'chunk_loglik',
            'chunk_post']
 MAX_SPEAKERS = 256
@@ -187,6 +187,9 @@ class Batch:
         if algo:
             self.set_option(OPT_FB_ALGO, {'auto': FB_AUTO, 'sequential': FB_SEQUENTIAL,
                                           'chunked': FB_CHUNKED}[algo])
+        group = os.environ.get('VBX_AMD_SCAN_GROUP')      # chunks per group of the two-level boundary walk
+        if group is not None:
+            self.set_option(OPT_SCAN_GROUP, int(group))
         fuse = os.environ.get('VBX_AMD_FUSE')             # '0' keeps every stage in its own kernel
         if fuse is not None:
             self.set_option(OPT_FUSE, int(fuse))

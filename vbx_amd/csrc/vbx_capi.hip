@@ -89,6 +89,11 @@ struct vbx_batch {
     void* d_sfw = nullptr;
     void* d_dump = nullptr;
     bool use_chunked = false;
+    // two-level boundary walk
+    int scan_group = 0;                           // option: 0 auto, 1 flat, >= 2 chunks per group
+    int sgroup = 1, nsup_total = 0;               // in effect
+    void* d_sop = nullptr;
+    int *d_sopexp = nullptr, *d_sup_rec = nullptr, *d_sup_idx = nullptr;
     void* d_xstage = nullptr;
     size_t xstage_bytes = 0;
     // timing
@@ -113,6 +118,8 @@ struct vbx_batch {
         v.ip = d_ip ? d_ip : d_pi; v.fw_scale = (R*)d_fw_scale; v.bw_scale = (R*)d_bw_scale;
         v.op = (R*)d_op; v.opexp = d_opexp; v.fbound = (R*)d_fbound; v.gbound = (R*)d_gbound;
         v.tllpart = use_chunked ? d_tllpart : nullptr; v.sfw = (R*)d_sfw; v.dump = (R*)d_dump;
+        v.sop = (R*)d_sop; v.sopexp = d_sopexp; v.sup_rec = d_sup_rec; v.sup_idx = d_sup_idx;
+        v.sgroup = sgroup; v.nsup_total = nsup_total;
         return v;
     }
 };
@@ -193,7 +200,13 @@ template <typename R, int SP> void launch_scan(vbx_batch* b, const BatchView<R>&
     }
     {
         LaunchScope ls(b, VBX_K_FB_AUX);
-        hipLaunchKernelGGL((scan2_kernel<R, SP>), dim3(b->n_rec, 2), dim3(256), 0, st, v);
+        if (b->sgroup > 1) {     // long recordings: group operators, boundaries at the group edges, then inside the groups
+            hipLaunchKernelGGL((scan_compose_kernel<R, SP>), dim3(b->nsup_total), dim3(256), 0, st, v);
+            hipLaunchKernelGGL((scan2_kernel<R, SP>), dim3(b->n_rec, 2), dim3(256), 0, st, v, 2);
+            hipLaunchKernelGGL((scan2_kernel<R, SP>), dim3(b->nsup_total, 2), dim3(256), 0, st, v, 3);
+        } else {
+            hipLaunchKernelGGL((scan2_kernel<R, SP>), dim3(b->n_rec, 2), dim3(256), 0, st, v, 0);
+        }
     }
     if constexpr (ChunkPostCfg<R, SP>::kFits) {
         if (fused_post) {
@@ -328,6 +341,40 @@ int choose_fb_algo(vbx_batch* b, bool step_api_logs) {
         if (rc != VBX_OK) return rc;
     }
     b->use_chunked = chunked;
+    // two-level walk over the chunk boundaries: groups of ~sqrt(K) chunks once the flat chain gets long
+    int group = 1;
+    if (chunked) {
+        if (b->scan_group >= 2) group = b->scan_group;
+        else if (b->scan_group == 0 && maxtiles >= 160) group = std::max(4, (int)std::lround(std::sqrt((double)maxtiles)));
+    }
+    if (group != b->sgroup || (group > 1 && !b->d_sop)) {
+        for (void* p : {(void*)b->d_sop, (void*)b->d_sopexp, (void*)b->d_sup_rec, (void*)b->d_sup_idx})
+            if (p) (void)hipFree(p);
+        b->d_sop = nullptr; b->d_sopexp = nullptr; b->d_sup_rec = nullptr; b->d_sup_idx = nullptr;
+        b->sgroup = group;
+        b->nsup_total = 0;
+        if (group > 1) {
+            std::vector<int> sup_rec, sup_idx;
+            for (int i = 0; i < b->n_rec; ++i) {
+                b->recs[i].sup0 = (int)sup_rec.size();
+                const int ns = (b->recs[i].ntiles + group - 1) / group;
+                for (int s = 0; s < ns; ++s) {
+                    sup_rec.push_back(i);
+                    sup_idx.push_back(s);
+                }
+            }
+            b->nsup_total = (int)sup_rec.size();
+            const size_t sp = (size_t)b->Sp;
+            int rc = dmalloc_bytes(b->ctx, &b->d_sop, (size_t)b->nsup_total * sp * sp * b->rsize);
+            if (rc == VBX_OK) rc = dmalloc(b->ctx, &b->d_sopexp, (size_t)b->nsup_total * sp);
+            if (rc == VBX_OK) rc = dmalloc(b->ctx, &b->d_sup_rec, sup_rec.size());
+            if (rc == VBX_OK) rc = dmalloc(b->ctx, &b->d_sup_idx, sup_idx.size());
+            if (rc != VBX_OK) return rc;
+            HIPCHK(b->ctx, hipMemcpy(b->d_sup_rec, sup_rec.data(), sizeof(int) * sup_rec.size(), hipMemcpyHostToDevice));
+            HIPCHK(b->ctx, hipMemcpy(b->d_sup_idx, sup_idx.data(), sizeof(int) * sup_idx.size(), hipMemcpyHostToDevice));
+            b->recs_dirty = true;        // sup0 changed
+        }
+    }
     return VBX_OK;
 }
 
@@ -426,7 +473,7 @@ int vbx_batch_destroy(vbx_batch* b) {
                     b->d_rho, b->d_gamma, b->d_bmat, b->d_mrow, b->d_ahat, b->d_bhat, b->d_alpha, b->d_invL,
                     b->d_bias, b->d_mpart, b->d_npart, b->d_lraw, b->d_emodel, b->d_pi, b->d_epart, b->d_Li,
                     b->d_xstage, b->d_ip, b->d_fw_scale, b->d_bw_scale, b->d_op, b->d_fbound, b->d_gbound,
-                    b->d_opexp, b->d_tllpart, b->d_sfw, b->d_dump};
+                    b->d_opexp, b->d_tllpart, b->d_sfw, b->d_dump, b->d_sop, b->d_sopexp, b->d_sup_rec, b->d_sup_idx};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (b->ev_start) (void)hipEventDestroy(b->ev_start);
@@ -554,6 +601,10 @@ int vbx_batch_set_option(vbx_batch* b, int option, int64_t value) {
             if (value < 0 || value > 2) FAIL(b->ctx, VBX_ERR_INVALID, "fuse must be 0, 1 or 2");
             b->fuse = (int)value;
             b->mpart_valid = false;
+            return VBX_OK;
+        case VBX_OPT_SCAN_GROUP:
+            if (value < 0 || value > 4096) FAIL(b->ctx, VBX_ERR_INVALID, "scan group must be in [0, 4096]");
+            b->scan_group = (int)value;
             return VBX_OK;
         case VBX_OPT_CHUNK_FRAMES:
             if (value < 0) FAIL(b->ctx, VBX_ERR_INVALID, "chunk_frames must be >= 0");

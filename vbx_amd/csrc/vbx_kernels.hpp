@@ -23,7 +23,7 @@ struct RecDesc {
     int tile0;        // first workgroup tile
     int ntiles;       // tiles of kTileFrames frames
     int has_model;    // alpha/invL supplied by the caller: skip the first M-step (VBx.py:94)
-    int pad_;
+    int sup0;         // first group operator of this recording (two-level boundary walk)
     double lp, Fa, Fb;
     double gsum;      // sum_t G_t (VBx.py:87)
 };
@@ -72,6 +72,12 @@ template <typename R> struct BatchView {
     double* tllpart;       // [ntiles_total] or null: sum over the chunk of log s_t + m_t
     R* sfw;                // [sum_T] forward scales s_t = sum(a_t) written by scan3
     R* dump;               // [256] scratch that absorbs the stores of idle scan steps
+    // two-level boundary walk (long recordings): operators of groups of `sgroup` consecutive chunks
+    R* sop;                // [nsup_total][Sp][Sp]
+    int* sopexp;           // [nsup_total][Sp]
+    const int* sup_rec;    // [nsup_total] recording of a group
+    const int* sup_idx;    // [nsup_total] index of the group within its recording
+    int sgroup, nsup_total;
 };
 
 // =======================================================================================

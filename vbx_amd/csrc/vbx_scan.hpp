@@ -128,15 +128,41 @@ template <typename R, int SP> struct Scan2Cfg {
     static constexpr int NBUF = (2 * RB * kOpBytes <= kBudget) ? 2 : 1;
 };
 
+// The walk is used at three levels (`level` argument of scan2_kernel):
+//   0  flat: every chunk operator of a recording, from the initial vector          (grid.x = recording)
+//   2  the group operators of scan_compose_kernel: boundaries at the group edges     (grid.x = recording)
+//   3  inside one group, from the boundary level 2 left at its edge                  (grid.x = group)
+// A chain of K-1 dependent mat-vecs costs 0.3-0.9 us each; with groups of G ~ sqrt(K) chunks the critical
+// path is G products + K/G + G mat-vecs instead.
 template <typename R, int SP, int dir>
-__device__ __forceinline__ void scan2_body(const BatchView<R>& bt, R* ring, int* exps, R* wl) {
+__device__ __forceinline__ void scan2_body(const BatchView<R>& bt, int level, R* ring, int* exps, R* wl) {
     using Cfg = Scan2Cfg<R, SP>;
     using R4 = typename Vec<R>::v4;
     constexpr int HL = 64 / SP, NI = SP / HL, RB = Cfg::RB, NBUF = Cfg::NBUF, OPSZ = Cfg::kOpElems;
-    const int rec = blockIdx.x;
+    const int rec = level == 3 ? bt.sup_rec[blockIdx.x] : blockIdx.x;
     if (bt.state[rec].done) return;
     const RecDesc rd = bt.recs[rec];
-    const int K = rd.ntiles, nops = K - 1;
+    const int K = rd.ntiles, G = bt.sgroup;
+    // chain step n uses operator op0 + n*os and writes the boundary b0 + (n+1)*bs; the chain starts from
+    // bound[binit] (level 3) or from the initial vector, which it also stores at bound[binit]
+    const R* __restrict__ ops = bt.op;
+    const int* __restrict__ oexp = bt.opexp;
+    int nops = K - 1, os = dir == 0 ? 1 : -1, bs = os;
+    long long op0 = dir == 0 ? rd.tile0 : rd.tile0 + K - 1, b0 = op0, binit = op0;
+    if (level == 2) {
+        const int ns = (K + G - 1) / G;
+        ops = bt.sop;
+        oexp = bt.sopexp;
+        nops = ns - 1;
+        op0 = dir == 0 ? rd.sup0 : rd.sup0 + ns - 1;
+        bs = dir == 0 ? G : -G;
+        b0 = dir == 0 ? rd.tile0 : rd.tile0 + (long long)ns * G - 1;
+    } else if (level == 3) {
+        const int a = rd.tile0 + bt.sup_idx[blockIdx.x] * G, b = min(a + G, rd.tile0 + K);
+        nops = b - 1 - a;
+        op0 = b0 = binit = dir == 0 ? a : b - 1;
+        if (nops <= 0) return;
+    }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = lane / HL, h = lane % HL;
     R* __restrict__ bound = dir == 0 ? bt.fbound : bt.gbound;
@@ -150,15 +176,14 @@ __device__ __forceinline__ void scan2_body(const BatchView<R>& bt, R* ring, int*
 #pragma unroll
         for (int q = 0; q < RB; ++q) {
             const int n = r * RB + q;
-            const int k = dir == 0 ? n : K - 1 - n;
-            const long long base = (long long)(rd.tile0 + (n < nops ? k : 0)) * SP;
-            const R4* __restrict__ src = reinterpret_cast<const R4*>(bt.op + base * SP);
+            const long long base = (op0 + (n < nops ? (long long)n * os : 0)) * SP;
+            const R4* __restrict__ src = reinterpret_cast<const R4*>(ops + base * SP);
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
                 const int e = u * nthreads + tid;
                 if (n < nops && e < OPSZ / 4) tmp[q][u] = src[e];
             }
-            etmp[q] = (n < nops && tid < SP) ? bt.opexp[base + tid] : 0;
+            etmp[q] = (n < nops && tid < SP) ? oexp[base + tid] : 0;
         }
 #pragma unroll
         for (int q = 0; q < RB; ++q) {
@@ -175,9 +200,13 @@ __device__ __forceinline__ void scan2_body(const BatchView<R>& bt, R* ring, int*
 
     R y = 0;
     if (wave == 0) {
-        if (dir == 0) y = (j < rd.S) ? (R)(bt.ip[(long long)rec * SP + j] + 1e-8) : (R)0;
-        else y = (j < rd.S) ? (R)1 : (R)0;
-        if (h == 0) bound[(long long)(rd.tile0 + (dir == 0 ? 0 : K - 1)) * SP + j] = y;
+        if (level == 3) {
+            y = bound[binit * SP + j];
+        } else {
+            if (dir == 0) y = (j < rd.S) ? (R)(bt.ip[(long long)rec * SP + j] + 1e-8) : (R)0;
+            else y = (j < rd.S) ? (R)1 : (R)0;
+            if (h == 0) bound[binit * SP + j] = y;
+        }
     }
     auto compute_round = [&](int r, int buf) {
         R opv[2][NI];
@@ -194,7 +223,6 @@ __device__ __forceinline__ void scan2_body(const BatchView<R>& bt, R* ring, int*
         for (int q = 0; q < RB; ++q) {
             const int n = r * RB + q;
             if (n >= nops) break;
-            const int k = dir == 0 ? n : K - 1 - n;
             if (q + 1 < RB) fetch(q + 1, (q + 1) & 1);
             const int ej = ejv[q & 1];
             R w = y;
@@ -221,8 +249,7 @@ __device__ __forceinline__ void scan2_body(const BatchView<R>& bt, R* ring, int*
             }
             y = (j < rd.S) ? tot : (R)0;          // padded speakers carry no mass in either direction
             __builtin_amdgcn_wave_barrier();
-            const int kb = dir == 0 ? k + 1 : k - 1;
-            if (h == 0) bound[(long long)(rd.tile0 + kb) * SP + j] = y;
+            if (h == 0) bound[(b0 + (long long)(n + 1) * bs) * SP + j] = y;
         }
     };
 
@@ -246,13 +273,113 @@ __device__ __forceinline__ void scan2_body(const BatchView<R>& bt, R* ring, int*
 }
 
 template <typename R, int SP>
-__global__ __launch_bounds__(256) void scan2_kernel(BatchView<R> bt) {
+__global__ __launch_bounds__(256) void scan2_kernel(BatchView<R> bt, int level) {
     using Cfg = Scan2Cfg<R, SP>;
     __shared__ __attribute__((aligned(16))) R ring[Cfg::NBUF * Cfg::RB * Cfg::kOpElems];
     __shared__ int exps[Cfg::NBUF * Cfg::RB * SP];
     __shared__ __attribute__((aligned(16))) R wl[SP];
-    if (blockIdx.y == 0) scan2_body<R, SP, 0>(bt, ring, exps, wl);     // direction is a compile-time constant:
-    else scan2_body<R, SP, 1>(bt, ring, exps, wl);                     // the two chains read the operator differently
+    if (blockIdx.y == 0) scan2_body<R, SP, 0>(bt, level, ring, exps, wl);     // direction is a compile-time constant:
+    else scan2_body<R, SP, 1>(bt, level, ring, exps, wl);                     // the two chains read the operator differently
+}
+
+// max / sum over the W adjacent lanes of a group (W = 4, 8 or 16)
+template <int W> __device__ __forceinline__ int group_max(int v) {
+    v = max(v, dpp_mov<0xB1>(v));
+    v = max(v, dpp_mov<0x4E>(v));
+    if (W >= 8) v = max(v, dpp_mov<0x141>(v));
+    if (W >= 16) v = max(v, dpp_mov<0x140>(v));
+    return v;
+}
+
+// =======================================================================================
+// scan_compose: the operator of a group of `sgroup` consecutive chunks, P = F_(b-1) ... F_(a+1) F_a.
+// grid = nsup_total, block = 256.  thread = (column i of P, row group rg): RG = 256/SP threads share a
+// column, each keeps RPT = SP/RG of its entries in registers.  One product pushes every column of P through
+// the next chunk operator exactly like scan2 pushes a boundary vector (weights 2^E shifted by the largest
+// exponent on the column's support) but keeps the column's scale as an integer exponent:
+//     P'[:, i] = 2^(e_i + top_i) sum_j (P[j, i] 2^(E_j - top_i)) F[:, j],   renormalised to a sum in [0.5, 1).
+// F and the scaled copy of P (transposed: conflict-free) live in LDS; model: oracle/chunked_scan.py::compose.
+// =======================================================================================
+template <typename R, int SP>
+__global__ __launch_bounds__(256) void scan_compose_kernel(BatchView<R> bt) {
+    using R4 = typename Vec<R>::v4;
+    constexpr int RG = 256 / SP, RPT = SP / RG;        // SP = 16 / 32 / 64: RG = 16 / 8 / 4, RPT = 1 / 4 / 16
+    constexpr int VPT = SP * SP / 4 / 256 > 0 ? SP * SP / 4 / 256 : 1;   // 16-byte vectors of an operator per thread
+    constexpr int kNoMass = -(1 << 24);
+    __shared__ __attribute__((aligned(16))) R Fl[SP * SP];
+    __shared__ __attribute__((aligned(16))) R Wt[SP * SP];
+    __shared__ int eF[SP];
+    const int sup = blockIdx.x;
+    const int rec = bt.sup_rec[sup];
+    if (bt.state[rec].done) return;
+    const RecDesc rd = bt.recs[rec];
+    const int G = bt.sgroup;
+    const int a = rd.tile0 + bt.sup_idx[sup] * G, b = min(a + G, rd.tile0 + rd.ntiles);
+    const int tid = threadIdx.x, i = tid / RG, rg = tid % RG, r0 = rg * RPT;
+    R pv[RPT];
+    int eP = bt.opexp[(long long)a * SP + i];
+#pragma unroll
+    for (int rr = 0; rr < RPT; ++rr) pv[rr] = bt.op[((long long)a * SP + i) * SP + r0 + rr];
+    R4 fr[VPT];
+    int efr = 0;
+    auto fetch = [&](int k) {                              // chunk operator k: global -> registers
+        const R4* __restrict__ src = reinterpret_cast<const R4*>(bt.op + (long long)k * SP * SP);
+#pragma unroll
+        for (int u = 0; u < VPT; ++u)
+            if (u * 256 + tid < SP * SP / 4) fr[u] = src[u * 256 + tid];
+        if (tid < SP) efr = bt.opexp[(long long)k * SP + tid];
+    };
+    if (a + 1 < b) fetch(a + 1);
+    for (int k = a + 1; k < b; ++k) {
+#pragma unroll
+        for (int u = 0; u < VPT; ++u)
+            if (u * 256 + tid < SP * SP / 4) reinterpret_cast<R4*>(Fl)[u * 256 + tid] = fr[u];
+        if (tid < SP) eF[tid] = efr;
+        __syncthreads();
+        if (k + 1 < b) fetch(k + 1);                       // next operator in flight during this product
+        // weights of my column, shifted by the largest exponent on its support
+        int tj[RPT], top = -(1 << 28);
+#pragma unroll
+        for (int rr = 0; rr < RPT; ++rr) {
+            const int e = eF[r0 + rr];
+            tj[rr] = (pv[rr] > (R)0 && e > kNoMass / 2) ? e + exponent_of(pv[rr]) : -(1 << 28);
+            top = max(top, tj[rr]);
+        }
+        top = group_max<RG>(top);
+        const bool alive = top > -(1 << 27) && eP > kNoMass / 2;
+#pragma unroll
+        for (int rr = 0; rr < RPT; ++rr)
+            Wt[(r0 + rr) * SP + i] = (alive && tj[rr] > -(1 << 27)) ? scale2(pv[rr], eF[r0 + rr] - top) : (R)0;
+        __syncthreads();
+        R acc[RPT];
+#pragma unroll
+        for (int rr = 0; rr < RPT; ++rr) acc[rr] = 0;
+#pragma unroll 4
+        for (int j = 0; j < SP; ++j) {
+            const R w = Wt[j * SP + i];
+#pragma unroll
+            for (int rr = 0; rr < RPT; ++rr) acc[rr] += Fl[j * SP + r0 + rr] * w;
+        }
+        R sig = acc[0];
+#pragma unroll
+        for (int rr = 1; rr < RPT; ++rr) sig += acc[rr];
+        sig = column_sum<RG>(sig);
+        if (alive && sig > (R)0) {
+            const int e = rescale_exponent(sig);
+#pragma unroll
+            for (int rr = 0; rr < RPT; ++rr) pv[rr] = scale2(acc[rr], -e);
+            eP += top + e;
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < RPT; ++rr) pv[rr] = 0;
+            eP = kNoMass;
+        }
+        __syncthreads();                                   // Fl / Wt are rewritten by the next product
+    }
+    R* __restrict__ dst = bt.sop + ((long long)sup * SP + i) * SP + r0;
+#pragma unroll
+    for (int rr = 0; rr < RPT; ++rr) dst[rr] = pv[rr];
+    if (rg == 0) bt.sopexp[(long long)sup * SP + i] = eP;
 }
 
 // =======================================================================================
