@@ -24,6 +24,31 @@ template <> struct Vec<double> {
     using v4 = double __attribute__((ext_vector_type(4)));
 };
 
+// N adjacent values of one lane (N = 1, 2 or 4) moved as ONE LDS / global access of 4N or 8N bytes
+template <typename R, int N> struct Pack;
+template <typename R> struct Pack<R, 1> { using type = R; };
+template <typename R> struct Pack<R, 2> { using type = typename Vec<R>::v2; };
+template <typename R> struct Pack<R, 4> { using type = typename Vec<R>::v4; };
+template <int N, typename R> __device__ __forceinline__ void load_pack(R (&dst)[N], const R* src) {
+    using P = typename Pack<R, N>::type;
+    const P v = *reinterpret_cast<const P*>(src);
+    if constexpr (N == 1) dst[0] = v;
+    else {
+#pragma unroll
+        for (int r = 0; r < N; ++r) dst[r] = v[r];
+    }
+}
+template <int N, typename R> __device__ __forceinline__ void store_pack(R* dst, const R (&src)[N]) {
+    using P = typename Pack<R, N>::type;
+    P v;
+    if constexpr (N == 1) v = src[0];
+    else {
+#pragma unroll
+        for (int r = 0; r < N; ++r) v[r] = src[r];
+    }
+    *reinterpret_cast<P*>(dst) = v;
+}
+
 // ---------------------------------------------------------------------------------------
 // MFMA 16x16x4, f32 and f64.  One A value and one B value per lane:
 //   A[i = lane & 15][k = lane >> 4],  B[k = lane >> 4][j = lane & 15]

@@ -244,28 +244,28 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 3 : 1)) void chu
             const int f = 16 * it + 4 * wave + g4;
             const bool ok = f < len;
             const int fr = ok ? f : 0;
-            const R isig = fast_rcp(sfl[fr]), iq = fast_rcp(qfl[fr]);
+            const R isig = fast_rcp(sfl[fr]), iq = fast_rcp(qfl[fr]);   // (applied one after the other: their product may overflow)
             const R sp = fr > 0 ? sfl[fr - 1] : tl_sig[1];
-            const R* app = fr > 0 ? af + (fr - 1) * SP : aprev0;
-            R g[NREG], ap[NREG];
+            R a[NREG], x[NREG], ap[NREG], g[NREG];
+            load_pack<NREG>(a, af + fr * SP + i16 * NREG);
+            load_pack<NREG>(x, bf + fr * SP + i16 * NREG);
+            load_pack<NREG>(ap, (fr > 0 ? af + (fr - 1) * SP : aprev0) + i16 * NREG);
 #pragma unroll
-            for (int r = 0; r < NREG; ++r) {
-                g[r] = (af[fr * SP + i16 * NREG + r] * isig) * (bf[fr * SP + i16 * NREG + r] * iq);
-                ap[r] = app[i16 * NREG + r];
-            }
+            for (int r = 0; r < NREG; ++r) g[r] = (a[r] * isig) * (x[r] * iq);
             R sum = g[0];
 #pragma unroll
             for (int r = 1; r < NREG; ++r) sum += g[r];
             sum = allreduce_sum<16>(sum);
             const R inv = ok ? fast_rcp(sum) : (R)0;
-            const bool stat = ok && t0 + f >= 1;
+            const bool stat = ok && t0 + f >= 1;               // frame 0 of the recording has no "entered" term
 #pragma unroll
             for (int r = 0; r < NREG; ++r) {
                 g[r] *= inv;
-                bf[f * SP + i16 * NREG + r] = g[r];         // A operand of the accumulation below (0 past the end)
-                if (ok) G[(long long)f * SP + i16 * NREG + r] = g[r];
-                if (stat) ent[r] += g[r] * sp * fast_rcp(lp * ap[r] + c[r] * sp);
+                const R term = g[r] * sp * fast_rcp(lp * ap[r] + c[r] * sp);
+                ent[r] += stat ? term : (R)0;                  // (select, not multiply: ap is undefined for frame 0)
             }
+            store_pack<NREG>(bf + f * SP + i16 * NREG, g);     // A operand of the accumulation below (0 past the end)
+            if (ok) store_pack<NREG>(G + f * SP + i16 * NREG, g);
         }
 #pragma unroll
         for (int r = 0; r < NREG; ++r) {
