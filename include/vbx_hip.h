@@ -181,6 +181,25 @@ int vbx_mstep(vbx_ctx* ctx, int64_t T, int32_t S, int32_t D, const double* X, co
 int vbx_loglik(vbx_ctx* ctx, int64_t T, int32_t S, int32_t D, const double* X, const double* Phi,
                const double* alpha, const double* invL, double Fa, int precision, double* log_p);
 
+/* ---- score stage of the AHC initialisation (next row upstream of VBx(): vbhmm.py:135-138) -------------
+ * cos_similarity(x)            /root/reference/VBx/diarization_lib.py:190-213
+ * twoGMMcalib_lin(s, niters)   /root/reference/VBx/diarization_lib.py:13-31
+ * The T x T score matrix stays resident in HBM between the two calls (vbx_scores). */
+typedef struct vbx_scores vbx_scores;
+
+/* x [T][D] f64 (rows need not be normalised) -> device-resident matrix of cosine similarities. */
+int vbx_cos_similarity(vbx_ctx* ctx, int64_t T, int32_t D, const double* x, vbx_scores** out);
+/* A device-resident copy of n host scores (for callers that bring their own scores). */
+int vbx_scores_upload(vbx_ctx* ctx, int64_t n, const double* s, vbx_scores** out);
+/* Number of scores held (T*T after vbx_cos_similarity). */
+int64_t vbx_scores_count(const vbx_scores* sc);
+/* Copy count scores starting at offset to the host (out [count]). */
+int vbx_scores_get(vbx_scores* sc, int64_t offset, int64_t count, double* out);
+/* Two-Gaussian shared-variance EM over all the scores: threshold, and (llr != NULL) the linearly calibrated
+ * log-odds of every score, [vbx_scores_count]. */
+int vbx_scores_two_gmm_calib(vbx_scores* sc, int32_t niters, double* threshold, double* llr);
+int vbx_scores_destroy(vbx_scores* sc);
+
 #ifdef __cplusplus
 }
 #endif

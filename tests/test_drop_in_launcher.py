@@ -27,6 +27,21 @@ def test_unchanged_vbhmm_runs_on_the_drop_in_module(tmp_path, monkeypatch, es200
         return vbx_oracle.VBx(X, Phi, **kw)
 
     monkeypatch.setattr(product, 'VBx', recording_vbx)
+    # the AHC score stage is redirected too (vbx_drop_in/diarization_lib.py): oracle stand-ins, calls recorded
+    from oracle import ahc_oracle
+    import vbx_amd.diarization_lib as product_ahc
+    ahc_calls = []
+
+    def recording_cos(x):
+        ahc_calls.append(('cos_similarity', np.shape(x)))
+        return ahc_oracle.cos_similarity(x)
+
+    def recording_gmm(s, niters=20):
+        ahc_calls.append(('twoGMMcalib_lin', np.shape(s)))
+        return ahc_oracle.twoGMMcalib_lin(s, niters)
+
+    monkeypatch.setattr(product_ahc, 'cos_similarity', recording_cos)
+    monkeypatch.setattr(product_ahc, 'twoGMMcalib_lin', recording_gmm)
     for name in ('VBx', 'kaldi_io', 'kaldi_io.kaldi_io', 'h5py', 'fastcluster', 'diarization_lib', 'kaldi_utils'):
         monkeypatch.delitem(sys.modules, name, raising=False)
     sys.path.insert(0, os.path.join(REPO, 'tools'))
@@ -40,11 +55,15 @@ def test_unchanged_vbhmm_runs_on_the_drop_in_module(tmp_path, monkeypatch, es200
                         '--threshold', '-0.015', '--lda-dim', '128', '--Fa', '0.3', '--Fb', '17', '--loopP', '0.99'])
         drop_in = sys.modules['VBx']
         assert os.path.samefile(drop_in.__file__, os.path.join(REPO, 'vbx_drop_in', 'VBx.py'))
+        dlib = sys.modules['diarization_lib']
+        assert os.path.samefile(dlib.__file__, os.path.join(REPO, 'vbx_drop_in', 'diarization_lib.py'))
+        assert callable(dlib.merge_adjacent_labels) and callable(dlib.read_xvector_timing_dict)   # reference names
     finally:
         sys.path.remove(os.path.join(REPO, 'tools'))
         for name in ('VBx', 'run_vbhmm', 'kaldi_io', 'kaldi_io.kaldi_io', 'h5py', 'fastcluster', 'diarization_lib',
-                     'kaldi_utils'):
+                     '_reference_diarization_lib', 'kaldi_utils'):
             sys.modules.pop(name, None)
+    assert ahc_calls == [('cos_similarity', (1025, 128)), ('twoGMMcalib_lin', (1025 * 1025,))]   # vbhmm.py:135-138
     assert len(calls) == 1
     X, Phi, kw = calls[0]
     assert np.array_equal(X, es2005a['fea']) and np.array_equal(Phi, es2005a['Phi'])

@@ -22,6 +22,8 @@ ABI_SYMBOLS = [
     'vbx_batch_create', 'vbx_batch_destroy', 'vbx_batch_set_option', 'vbx_batch_set_recording',
     'vbx_batch_run', 'vbx_batch_get_result', 'vbx_batch_last_run_ms', 'vbx_batch_kernel_times',
     'vbx_run', 'vbx_forward_backward', 'vbx_mstep', 'vbx_loglik',
+    'vbx_cos_similarity', 'vbx_scores_upload', 'vbx_scores_count', 'vbx_scores_get', 'vbx_scores_two_gmm_calib',
+    'vbx_scores_destroy',
 ]
 
 
@@ -71,9 +73,17 @@ def load():
                                          vp, vp, vp]
     lib.vbx_mstep.argtypes = [vp, i64, i32, i32, vp, vp, vp, dbl, dbl, C.c_int, vp, vp]
     lib.vbx_loglik.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, dbl, C.c_int, vp]
+    lib.vbx_cos_similarity.argtypes = [vp, i64, i32, vp, C.POINTER(vp)]
+    lib.vbx_scores_upload.argtypes = [vp, i64, vp, C.POINTER(vp)]
+    lib.vbx_scores_count.argtypes = [vp]
+    lib.vbx_scores_get.argtypes = [vp, i64, i64, vp]
+    lib.vbx_scores_two_gmm_calib.argtypes = [vp, i32, C.POINTER(dbl), vp]
+    lib.vbx_scores_destroy.argtypes = [vp]
     for name in ABI_SYMBOLS:
         fn = getattr(lib, name)          # AttributeError here = the .so does not export the ABI
-        if name not in ('vbx_last_error', 'vbx_abi_version'):
+        if name == 'vbx_scores_count':
+            fn.restype = C.c_int64
+        elif name not in ('vbx_last_error', 'vbx_abi_version'):
             fn.restype = C.c_int
     _lib = lib
     return lib
@@ -163,6 +173,57 @@ class Context:
         self.check(self._lib.vbx_loglik(self._h, T, S, D, _ptr(X), _ptr(Phi), _ptr(alpha), _ptr(invL), float(Fa),
                                         precision_code(precision), _ptr(out)), 'vbx_loglik')
         return out
+
+
+class Scores:
+    """A vector of float64 scores resident in HBM (vbx_scores): the T x T cosine similarities of the AHC
+    initialisation, or any scores handed to the two-Gaussian calibration."""
+
+    def __init__(self, ctx: Context, handle):
+        self.ctx, self._lib, self._h = ctx, ctx._lib, handle
+
+    @classmethod
+    def cos_similarity(cls, ctx: Context, x):
+        x = _f64(x)
+        h = C.c_void_p()
+        ctx.check(ctx._lib.vbx_cos_similarity(ctx._h, x.shape[0], x.shape[1], _ptr(x), C.byref(h)), 'vbx_cos_similarity')
+        return cls(ctx, h)
+
+    @classmethod
+    def upload(cls, ctx: Context, s):
+        s = _f64(s).reshape(-1)
+        h = C.c_void_p()
+        ctx.check(ctx._lib.vbx_scores_upload(ctx._h, s.size, _ptr(s), C.byref(h)), 'vbx_scores_upload')
+        return cls(ctx, h)
+
+    def __len__(self):
+        return int(self._lib.vbx_scores_count(self._h))
+
+    def get(self, offset=0, count=None, out=None):
+        count = len(self) - offset if count is None else count
+        if out is None:
+            out = np.empty(count)
+        assert out.dtype == np.float64 and out.flags.c_contiguous and out.size == count
+        self.ctx.check(self._lib.vbx_scores_get(self._h, int(offset), int(count), _ptr(out)), 'vbx_scores_get')
+        return out
+
+    def two_gmm_calib(self, niters=20, want_llr=True):
+        thr = C.c_double()
+        llr = np.empty(len(self)) if want_llr else None
+        self.ctx.check(self._lib.vbx_scores_two_gmm_calib(self._h, int(niters), C.byref(thr), _ptr(llr)),
+                       'vbx_scores_two_gmm_calib')
+        return thr.value, llr
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.vbx_scores_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Batch:

@@ -1,0 +1,180 @@
+// vbx_ahc.hpp -- score stage of the AHC initialisation that runs right before VBx() in vbhmm.py:135-138
+// (SURVEY.md section 8f, rank 1): the T x T cosine-similarity matrix and the two-Gaussian calibration of
+// its T*T entries.  Everything is float64, as in the reference (diarization_lib.py).
+//
+//   cos_similarity  (diarization_lib.py:190-213)   xn = x / (|x| + 1e-32);  C = xn xn^T   on v_mfma_f64_16x16x4
+//   twoGMMcalib_lin (diarization_lib.py:13-31)     20 EM passes over the scores resident in HBM: one
+//                                                  streaming kernel per pass (6 sums), parameters stay on the device
+#pragma once
+#include "vbx_device.hpp"
+
+namespace vbx {
+
+// rows of x scaled to unit length, feature dim padded with zeros to Dp (multiple of 16)
+__global__ __launch_bounds__(256) void cos_norm_kernel(const double* __restrict__ x, double* __restrict__ xn,
+                                                        long long T, int D, int Dp) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long t = (long long)blockIdx.x * 4 + wave;
+    if (t >= T) return;
+    double ss = 0.0;
+    for (int d = lane; d < D; d += 64) {
+        const double v = x[t * D + d];
+        ss += v * v;
+    }
+    ss = allreduce_sum<64>(ss);
+    const double inv = 1.0 / (sqrt(ss) + 1.0e-32);          // diarization_lib.py:201
+    for (int d = lane; d < Dp; d += 64) xn[t * Dp + d] = d < D ? x[t * D + d] * inv : 0.0;
+}
+
+// C[i][j] = <xn_i, xn_j>.  grid = (ceil(T/64), ceil(T/64)), block = 256: wave w owns the 32 x 32 sub-tile
+// (w>>1, w&1) = 2 x 2 MFMA tiles.  K is relabelled so that lane group g supplies k = 16q + 4g + r for MFMA r
+// of block q: one 32-byte load per lane and operand feeds four MFMAs.  xn (T x Dp doubles) lives in L2.
+__global__ __launch_bounds__(256) void cos_gemm_kernel(const double* __restrict__ xn, double* __restrict__ C,
+                                                        long long T, int Dp) {
+    using M = Mfma16<double>;
+    using acc_t = M::acc_t;
+    using D4 = Vec<double>::v4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    const long long r0 = (long long)blockIdx.y * 64 + 32 * (wave >> 1), c0 = (long long)blockIdx.x * 64 + 32 * (wave & 1);
+    acc_t acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = acc_t{0, 0, 0, 0};
+    const double* __restrict__ pa[2];
+    const double* __restrict__ pb[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        pa[m] = xn + min(r0 + 16 * m + i, T - 1) * Dp + 4 * g;     // rows past the end are clamped, never stored
+        pb[m] = xn + min(c0 + 16 * m + i, T - 1) * Dp + 4 * g;
+    }
+    for (int q = 0; q < Dp; q += 16) {
+        D4 a[2], b[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            a[m] = *reinterpret_cast<const D4*>(pa[m] + q);
+            b[m] = *reinterpret_cast<const D4*>(pb[m] + q);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[m][n] = M::mma(a[m][r], b[n][r], acc[m][n]);
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long row = r0 + 16 * m + M::row(lane, r), col = c0 + 16 * n + i;
+                if (row < T && col < T) C[row * T + col] = acc[m][n][r];
+            }
+}
+
+// ---- two-Gaussian calibration ---------------------------------------------------------------------
+// parameter block on the device: [0,1] weights  [2,3] means  [4] var  [5..9] the same before the last update
+constexpr int kGmmPartials = 1024;         // workgroups of a streaming pass (fixed: deterministic summation order)
+
+// pass 0: sum s;  pass 1: sum (s - mean)^2          (np.mean, np.std / np.var: diarization_lib.py:20-21)
+template <int PASS>
+__global__ __launch_bounds__(256) void gmm_moment_kernel(const double* __restrict__ s, long long n, const double* par,
+                                                          double* __restrict__ part) {
+    __shared__ double lds[16];
+    const double mean = PASS == 1 ? par[10] : 0.0;
+    double acc = 0.0;
+    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long long)gridDim.x * 256) {
+        const double v = s[k] - mean;
+        acc += PASS == 1 ? v * v : v;
+    }
+    acc = block_sum(acc, lds);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+
+__global__ __launch_bounds__(256) void gmm_init_kernel(const double* __restrict__ part, int npart, long long n, double* par,
+                                                        int pass) {
+    __shared__ double lds[16];
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < npart; k += 256) acc += part[k];
+    acc = block_sum(acc, lds);
+    if (threadIdx.x == 0) {
+        if (pass == 0) {
+            par[10] = acc / (double)n;                      // mean
+        } else {
+            const double var = acc / (double)n, sd = sqrt(var);
+            par[0] = par[1] = 0.5;                          // diarization_lib.py:19-21
+            par[2] = par[10] - sd;
+            par[3] = par[10] + sd;
+            par[4] = var;
+        }
+    }
+}
+
+// one EM pass: responsibilities of the two Gaussians and the six sums of diarization_lib.py:24-29
+__global__ __launch_bounds__(256) void gmm_pass_kernel(const double* __restrict__ s, long long n, const double* __restrict__ par,
+                                                        double* __restrict__ part) {
+    __shared__ double lds[16];
+    const double lw0 = log(par[0]), lw1 = log(par[1]), m0 = par[2], m1 = par[3], var = par[4];
+    const double hl = 0.5 * log(var), hv = 0.5 / var;
+    double c0 = 0, c1 = 0, s0 = 0, s1 = 0, q0 = 0, q1 = 0;
+    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long long)gridDim.x * 256) {
+        const double v = s[k];
+        const double l0 = lw0 - hl - (v - m0) * (v - m0) * hv, l1 = lw1 - hl - (v - m1) * (v - m1) * hv;
+        const double mx = fmax(l0, l1);
+        const double e0 = exp(l0 - mx), e1 = exp(l1 - mx), inv = 1.0 / (e0 + e1);     // scipy.special.softmax
+        const double g0 = e0 * inv, g1 = e1 * inv;
+        c0 += g0;
+        c1 += g1;
+        s0 += v * g0;
+        s1 += v * g1;
+        q0 += v * v * g0;
+        q1 += v * v * g1;
+    }
+    double* dst = part + (long long)blockIdx.x * 6;
+    double v6[6] = {c0, c1, s0, s1, q0, q1};
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+        const double tot = block_sum(v6[e], lds);
+        if (threadIdx.x == 0) dst[e] = tot;
+    }
+}
+
+// M-step of the calibration (diarization_lib.py:26-29); keeps the parameters the pass started with
+__global__ __launch_bounds__(256) void gmm_update_kernel(const double* __restrict__ part, int npart, double* par) {
+    __shared__ double lds[16];
+    double tot[6];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+        double acc = 0.0;
+        for (int k = threadIdx.x; k < npart; k += 256) acc += part[(long long)k * 6 + e];
+        tot[e] = block_sum(acc, lds);
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int e = 0; e < 5; ++e) par[5 + e] = par[e];
+        const double c0 = tot[0], c1 = tot[1];
+        const double w0 = c0 / (c0 + c1), w1 = c1 / (c0 + c1);
+        const double m0 = tot[2] / c0, m1 = tot[3] / c1;
+        par[0] = w0;
+        par[1] = w1;
+        par[2] = m0;
+        par[3] = m1;
+        par[4] = (tot[4] / c0 - m0 * m0) * w0 + (tot[5] / c1 - m1 * m1) * w1;
+    }
+}
+
+// calibrated log-odds: lls of the LAST pass (parameters par[5..9]), columns picked by the FINAL means
+__global__ __launch_bounds__(256) void gmm_llr_kernel(const double* __restrict__ s, long long n, const double* __restrict__ par,
+                                                       double* __restrict__ llr) {
+    const double lw0 = log(par[5]), lw1 = log(par[6]), m0 = par[7], m1 = par[8], var = par[9];
+    const double hl = 0.5 * log(var), hv = 0.5 / var;
+    const bool hi1 = par[3] > par[2], lo1 = par[3] < par[2];      // means.argmax() / means.argmin() (first extremum wins)
+    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long long)gridDim.x * 256) {
+        const double v = s[k];
+        const double l0 = lw0 - hl - (v - m0) * (v - m0) * hv, l1 = lw1 - hl - (v - m1) * (v - m1) * hv;
+        llr[k] = (hi1 ? l1 : l0) - (lo1 ? l1 : l0);
+    }
+}
+
+}  // namespace vbx

@@ -8,6 +8,7 @@
 #include "vbx_kernels.hpp"
 #include "vbx_scan.hpp"
 #include "vbx_fused.hpp"
+#include "vbx_ahc.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -1019,4 +1020,143 @@ int vbx_loglik(vbx_ctx* ctx, int64_t T, int32_t S, int32_t D, const double* X, c
     return rc;
 }
 
+// ---------------------------------------------------------------------------------------
+// score stage of the AHC initialisation (vbhmm.py:135-138)
+// ---------------------------------------------------------------------------------------
 }  // extern "C"
+
+struct vbx_scores {
+    vbx_ctx* ctx = nullptr;
+    long long n = 0;
+    double* d_s = nullptr;
+};
+
+extern "C" {
+
+int vbx_scores_destroy(vbx_scores* sc) {
+    if (!sc) return VBX_OK;
+    (void)hipSetDevice(sc->ctx->device);
+    if (sc->d_s) (void)hipFree(sc->d_s);
+    delete sc;
+    return VBX_OK;
+}
+
+int64_t vbx_scores_count(const vbx_scores* sc) { return sc ? sc->n : 0; }
+
+int vbx_cos_similarity(vbx_ctx* ctx, int64_t T, int32_t D, const double* x, vbx_scores** out) {
+    if (!ctx) return VBX_ERR_INVALID;
+    if (!x || !out || T <= 0 || D <= 0) FAIL(ctx, VBX_ERR_INVALID, "vbx_cos_similarity: bad argument");
+    if (T > 200000) FAIL(ctx, VBX_ERR_UNSUPPORTED, "T=%lld: the T x T score matrix would not fit the device", (long long)T);
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int Dp = round_up(D, 16);
+    double *d_x = nullptr, *d_xn = nullptr;
+    vbx_scores* sc = new vbx_scores();
+    sc->ctx = ctx;
+    sc->n = (long long)T * T;
+    int rc = dmalloc(ctx, &d_x, (size_t)T * D);
+    if (rc == VBX_OK) rc = dmalloc(ctx, &d_xn, (size_t)T * Dp);
+    if (rc == VBX_OK) rc = dmalloc(ctx, &sc->d_s, (size_t)sc->n);
+    hipError_t e = hipSuccess;
+    if (rc == VBX_OK) {
+        e = hipMemcpyAsync(d_x, x, sizeof(double) * (size_t)T * D, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(vbx::cos_norm_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, ctx->stream, d_x, d_xn,
+                               (long long)T, (int)D, Dp);
+            const unsigned nb = (unsigned)((T + 63) / 64);
+            hipLaunchKernelGGL(vbx::cos_gemm_kernel, dim3(nb, nb), dim3(256), 0, ctx->stream, d_xn, sc->d_s, (long long)T, Dp);
+            e = hipStreamSynchronize(ctx->stream);
+        }
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) {
+            ctx->err = std::string("cos_similarity kernels failed: ") + hipGetErrorString(e);
+            rc = VBX_ERR_HIP;
+        }
+    }
+    if (d_x) (void)hipFree(d_x);
+    if (d_xn) (void)hipFree(d_xn);
+    if (rc != VBX_OK) {
+        vbx_scores_destroy(sc);
+        return rc;
+    }
+    *out = sc;
+    return VBX_OK;
+}
+
+int vbx_scores_upload(vbx_ctx* ctx, int64_t n, const double* s, vbx_scores** out) {
+    if (!ctx) return VBX_ERR_INVALID;
+    if (!s || !out || n <= 0) FAIL(ctx, VBX_ERR_INVALID, "vbx_scores_upload: bad argument");
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    vbx_scores* sc = new vbx_scores();
+    sc->ctx = ctx;
+    sc->n = n;
+    int rc = dmalloc(ctx, &sc->d_s, (size_t)n);
+    if (rc == VBX_OK) {
+        hipError_t e = hipMemcpy(sc->d_s, s, sizeof(double) * (size_t)n, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            ctx->err = std::string("score upload failed: ") + hipGetErrorString(e);
+            rc = VBX_ERR_HIP;
+        }
+    }
+    if (rc != VBX_OK) {
+        vbx_scores_destroy(sc);
+        return rc;
+    }
+    *out = sc;
+    return VBX_OK;
+}
+
+int vbx_scores_get(vbx_scores* sc, int64_t offset, int64_t count, double* out) {
+    if (!sc) return VBX_ERR_INVALID;
+    if (!out || offset < 0 || count < 0 || offset + count > sc->n) FAIL(sc->ctx, VBX_ERR_INVALID, "vbx_scores_get: bad range");
+    HIPCHK(sc->ctx, hipSetDevice(sc->ctx->device));
+    if (count) HIPCHK(sc->ctx, hipMemcpy(out, sc->d_s + offset, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost));
+    return VBX_OK;
+}
+
+int vbx_scores_two_gmm_calib(vbx_scores* sc, int32_t niters, double* threshold, double* llr) {
+    if (!sc) return VBX_ERR_INVALID;
+    vbx_ctx* ctx = sc->ctx;
+    if (niters < 1 || !threshold) FAIL(ctx, VBX_ERR_INVALID, "vbx_scores_two_gmm_calib: niters must be >= 1");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int nb = (int)std::min<long long>(vbx::kGmmPartials, (sc->n + 255) / 256);
+    double *d_par = nullptr, *d_part = nullptr, *d_llr = nullptr;
+    int rc = dmalloc(ctx, &d_par, 16);
+    if (rc == VBX_OK) rc = dmalloc(ctx, &d_part, (size_t)nb * 6);
+    if (rc == VBX_OK && llr) rc = dmalloc(ctx, &d_llr, (size_t)sc->n);
+    double par[16];
+    hipError_t e = hipSuccess;
+    if (rc == VBX_OK) {
+        hipLaunchKernelGGL((vbx::gmm_moment_kernel<0>), dim3(nb), dim3(256), 0, st, sc->d_s, sc->n, d_par, d_part);
+        hipLaunchKernelGGL(vbx::gmm_init_kernel, dim3(1), dim3(256), 0, st, d_part, nb, sc->n, d_par, 0);
+        hipLaunchKernelGGL((vbx::gmm_moment_kernel<1>), dim3(nb), dim3(256), 0, st, sc->d_s, sc->n, d_par, d_part);
+        hipLaunchKernelGGL(vbx::gmm_init_kernel, dim3(1), dim3(256), 0, st, d_part, nb, sc->n, d_par, 1);
+        for (int it = 0; it < niters; ++it) {
+            hipLaunchKernelGGL(vbx::gmm_pass_kernel, dim3(nb), dim3(256), 0, st, sc->d_s, sc->n, d_par, d_part);
+            hipLaunchKernelGGL(vbx::gmm_update_kernel, dim3(1), dim3(256), 0, st, d_part, nb, d_par);
+        }
+        if (llr) hipLaunchKernelGGL(vbx::gmm_llr_kernel, dim3(nb), dim3(256), 0, st, sc->d_s, sc->n, d_par, d_llr);
+        e = hipMemcpyAsync(par, d_par, sizeof(double) * 16, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e == hipSuccess && llr) e = hipMemcpy(llr, d_llr, sizeof(double) * (size_t)sc->n, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) {
+            ctx->err = std::string("twoGMMcalib kernels failed: ") + hipGetErrorString(e);
+            rc = VBX_ERR_HIP;
+        }
+    }
+    if (rc == VBX_OK) {
+        // diarization_lib.py:30 with the final weights / means / var
+        const double w0 = par[0], w1 = par[1], m0 = par[2], m1 = par[3], var = par[4];
+        const double t0 = std::log(w0 * w0 / var) - m0 * m0 / var, t1 = std::log(w1 * w1 / var) - m1 * m1 / var;
+        *threshold = -0.5 * (t0 - t1) / (m0 / var - m1 / var);
+    }
+    for (double* p : {d_par, d_part, d_llr})
+        if (p) (void)hipFree(p);
+    return rc;
+}
+
+}  // extern "C"
+

@@ -1,0 +1,89 @@
+"""Host-side mirror of the score stage of the reference's AHC initialisation on top of libvbx_hip.so.
+
+``vbhmm.py:135-138`` computes, right before it calls ``VBx()``::
+
+    scr_mx = cos_similarity(x)                       # diarization_lib.py:190-213, T x T float64
+    thr, _ = twoGMMcalib_lin(scr_mx.ravel())         # diarization_lib.py:13-31, 20 EM passes over T*T scores
+
+Both functions keep the reference's signatures, return types and error behaviour; the work runs in HIP
+kernels (f64 MFMA for the similarity matrix, one streaming kernel per EM pass).  The score matrix stays
+resident in HBM between the two calls: ``cos_similarity`` remembers the device copy of the array it
+returns, and ``twoGMMcalib_lin`` recognises that array (or a flat view of it, as ``.ravel()`` gives)
+and calibrates the resident copy instead of uploading 8*T*T bytes again.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import weakref
+
+import numpy as np
+
+from . import _capi
+
+__all__ = ['cos_similarity', 'twoGMMcalib_lin']
+
+_resident = {}      # id(host array) -> (weakref to it, device copy)
+
+
+def _remember(arr, scores):
+    key = id(arr)
+
+    def _drop(_ref, key=key):
+        entry = _resident.pop(key, None)
+        if entry is not None:
+            entry[1].close()
+    _resident[key] = (weakref.ref(arr, _drop), scores)
+
+
+def _find_resident(s):
+    """The device copy of ``s`` if ``s`` is an array returned by cos_similarity() or a full flat / reshaped
+    view of one, and a spot check says the host copy has not been modified since."""
+    base = s
+    while isinstance(base, np.ndarray):
+        entry = _resident.get(id(base))
+        if entry is not None and entry[0]() is base:
+            scores = entry[1]
+            if (s.size == len(scores) and s.flags.c_contiguous and s.dtype == np.float64
+                    and s.__array_interface__['data'][0] == base.__array_interface__['data'][0]):
+                flat = s.reshape(-1)
+                probe = np.unique(np.linspace(0, flat.size - 1, 64).astype(np.int64))
+                if all(scores.get(int(k), 1)[0] == flat[k] for k in probe[:8]) and \
+                        np.array_equal(scores.get(int(probe[-1]), 1), flat[probe[-1]:probe[-1] + 1]):
+                    return scores
+            return None
+        base = base.base
+    return None
+
+
+def cos_similarity(x, *, device=None):
+    """Cosine similarity matrix of the rows of ``x`` (T x D) -> T x T float64.  diarization_lib.py:190-213."""
+    x = np.asarray(x)
+    assert x.ndim == 2, f'x has {x.ndim} dimensions, it must be matrix'
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    # the reference asserts that every row normalises to unit length (diarization_lib.py:201-202)
+    norm = np.sqrt(np.sum(np.square(x), axis=1, keepdims=True))
+    xn_sq = np.sum(np.square(x / (norm + 1.0e-32)), axis=1)
+    assert np.allclose(np.ones_like(xn_sq), xn_sq)
+    ctx = _capi.default_context(device)
+    scores = _capi.Scores.cos_similarity(ctx, x)
+    out = np.empty((x.shape[0], x.shape[0]))        # owns its memory: views of it (ravel) have it as .base
+    scores.get(out=out)
+    _remember(out, scores)
+    return out
+
+
+def twoGMMcalib_lin(s, niters=20, *, device=None):
+    """Two-Gaussian GMM with shared variance over the scores ``s``: returns the threshold that separates
+    the two Gaussians and the linearly calibrated log-odds of every score.  diarization_lib.py:13-31."""
+    s = np.asarray(s)
+    scores = _find_resident(s) if s.dtype == np.float64 else None
+    owned = scores is None
+    if owned:
+        if s.ndim != 1:
+            raise ValueError('twoGMMcalib_lin expects a vector of scores')     # the reference's s[:, np.newaxis] needs 1-D
+        scores = _capi.Scores.upload(_capi.default_context(device), s)
+    try:
+        threshold, llr = scores.two_gmm_calib(niters)
+    finally:
+        if owned:
+            scores.close()
+    return np.float64(threshold), llr
