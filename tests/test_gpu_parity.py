@@ -501,3 +501,25 @@ def test_two_level_boundary_walk_equals_flat_chain(ctx, precision, tol):
             assert np.abs(a['gamma'] - b['gamma']).max() <= tol, (group, i, np.abs(a['gamma'] - b['gamma']).max())
             assert np.abs(a['pi'] - b['pi']).max() <= tol, (group, i)
             assert rel_err(a['Li'], b['Li']) <= tol, (group, i)
+
+
+@pytest.mark.parametrize('S,D', [(1, 128), (16, 40), (17, 200), (33, 128), (64, 96), (65, 128), (5, 300)])
+def test_vbx_shapes_sweep_against_the_oracle(S, D):
+    """Speaker counts across the padded widths (16 / 32 / 64 / 128: fused kernels up to 64, the sequential
+    path beyond) and feature dims that need padding or more than one alpha slice of the log-likelihood kernel."""
+    import vbx_amd
+    from vbx_amd.synth import make_recording
+    T = 700
+    X, Phi, _ = make_recording(T, S, D=D, seed=S + D, kappa=0.1)
+    g0 = np.random.default_rng(S * 7 + D).gamma(1.0, size=(T, S))
+    g0 /= g0.sum(1, keepdims=True)
+    kw = dict(loopProb=0.9, Fa=0.3, Fb=17.0, pi=S, gamma=g0, maxIters=3, epsilon=-1e300, return_model=True)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        gr, pr, Lr, ar, ir = _orc().VBx(X, Phi, **kw)
+    for precision, tol in (('fp64', 1e-8), ('fp32', FP32_TOL)):
+        with contextlib.redirect_stdout(buf):
+            g, p, L, a, il = vbx_amd.VBx(X, Phi, precision=precision, **kw)
+        assert np.abs(g - gr).max() <= tol, (precision, np.abs(g - gr).max())
+        assert np.abs(p - pr).max() <= tol and rel_err([r[0] for r in L], [r[0] for r in Lr]) <= tol
+        assert np.abs(a - ar).max() <= tol * max(1.0, np.abs(ar).max()) and np.abs(il - ir).max() <= tol

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void cos_gemm_kernel(const double* __restrict_
 
 // ---- two-Gaussian calibration ---------------------------------------------------------------------
 // parameter block on the device: [0,1] weights  [2,3] means  [4] var  [5..9] the same before the last update
-constexpr int kGmmPartials = 1024;         // workgroups of a streaming pass (fixed: deterministic summation order)
+constexpr int kGmmPartials = 2048;         // workgroups of a streaming pass (fixed: deterministic summation order)
 
 // pass 0: sum s;  pass 1: sum (s - mean)^2          (np.mean, np.std / np.var: diarization_lib.py:20-21)
 template <int PASS>
@@ -121,9 +121,10 @@ __global__ __launch_bounds__(256) void gmm_pass_kernel(const double* __restrict_
     for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long long)gridDim.x * 256) {
         const double v = s[k];
         const double l0 = lw0 - hl - (v - m0) * (v - m0) * hv, l1 = lw1 - hl - (v - m1) * (v - m1) * hv;
-        const double mx = fmax(l0, l1);
-        const double e0 = exp(l0 - mx), e1 = exp(l1 - mx), inv = 1.0 / (e0 + e1);     // scipy.special.softmax
-        const double g0 = e0 * inv, g1 = e1 * inv;
+        // scipy.special.softmax over the two classes: exp(l - max) / sum.  The larger class is exp(0) = 1 exactly,
+        // so one exponential gives the same bits as two.
+        const double d = l1 - l0, em = exp(-fabs(d)), inv = 1.0 / (1.0 + em);
+        const double g0 = d > 0.0 ? em * inv : inv, g1 = d > 0.0 ? inv : em * inv;
         c0 += g0;
         c1 += g1;
         s0 += v * g0;
