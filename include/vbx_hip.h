@@ -62,6 +62,10 @@ extern "C" {
 #define VBX_OPT_CHUNK_FRAMES 4  /* frames per scan chunk for VBX_FB_CHUNKED (0 = auto)         */
 #define VBX_OPT_SCAN_GROUP 6    /* chunks per group of the two-level boundary walk: 0 auto (sqrt of the chunk count
                                    once a recording has >= 160 chunks), 1 flat chain, >= 2 explicit              */
+#define VBX_OPT_HALF_CHUNKS 7   /* 1: the fused kernels use one transfer operator / boundary pair per HALF tile (64
+                                   frames) and re-run the halves on separate waves; 0 (default): per tile.  Halves
+                                   the chunk kernels' dependent chains, doubles the boundary walk: a wash overall */
+#define VBX_OPT_TWO_LEVEL_FROM 8 /* chunk count from which VBX_OPT_SCAN_GROUP = 0 picks the two-level walk           */
 #define VBX_OPT_FUSE 5          /* per-chunk fused kernels when the lattices fit in LDS: 0 none, 1 chunk_post,
                                    2 (default) chunk_post + chunk_loglik                                */
 

@@ -523,3 +523,33 @@ def test_vbx_shapes_sweep_against_the_oracle(S, D):
         assert np.abs(g - gr).max() <= tol, (precision, np.abs(g - gr).max())
         assert np.abs(p - pr).max() <= tol and rel_err([r[0] for r in L], [r[0] for r in Lr]) <= tol
         assert np.abs(a - ar).max() <= tol * max(1.0, np.abs(ar).max()) and np.abs(il - ir).max() <= tol
+
+
+@pytest.mark.parametrize('precision,tol', [('fp64', 1e-11), ('fp32', 2e-5)])
+def test_half_tile_scan_chunks_equal_whole_tile_chunks(ctx, precision, tol):
+    """VBX_OPT_HALF_CHUNKS: the fused kernels build one operator per 64 frames and re-run a tile as four tasks
+    (two halves x two directions).  Same results as one operator per tile, for lengths that end in the first
+    half of a tile, exactly at a half, and in the second half, with and without the two-level walk."""
+    from vbx_amd import _capi
+    from vbx_amd.synth import make_recording
+    Ts, S = [1000, 1088, 1153, 64, 65, 3], 12
+    recs = []
+    for k, T in enumerate(Ts):
+        X, Phi, _ = make_recording(T, S, seed=50 + k, kappa=0.05)
+        g0 = np.random.default_rng(60 + k).gamma(1.0, size=(T, S))
+        recs.append((X, Phi, g0 / g0.sum(1, keepdims=True)))
+    out = {}
+    for half, group in ((0, 1), (1, 1), (1, 3)):
+        batch = _capi.Batch(ctx, Ts, [S] * len(Ts), 128, precision=precision, max_iters=4)
+        batch.set_option(_capi.OPT_HALF_CHUNKS, half)
+        batch.set_option(_capi.OPT_SCAN_GROUP, group)
+        for j, (X, Phi, g0) in enumerate(recs):
+            batch.set_recording(j, X, Phi, np.ones(S) / S, g0, 0.95, 0.3, 17.0)
+        batch.run(4, -np.inf)
+        out[half, group] = [batch.result(j, want_model=False) for j in range(len(Ts))]
+        batch.close()
+    for key in ((1, 1), (1, 3)):
+        for j in range(len(Ts)):
+            a, b = out[key][j], out[0, 1][j]
+            assert np.abs(a['gamma'] - b['gamma']).max() <= tol, (key, Ts[j], np.abs(a['gamma'] - b['gamma']).max())
+            assert np.abs(a['pi'] - b['pi']).max() <= tol and rel_err(a['Li'], b['Li']) <= tol, (key, Ts[j])

@@ -92,7 +92,9 @@ struct vbx_batch {
     bool use_chunked = false;
     // two-level boundary walk
     int scan_group = 0;                           // option: 0 auto, 1 flat, >= 2 chunks per group
+    int half_chunks = 0, two_level_from = 160;    // options: half-tile scan chunks in the fused path; auto two-level threshold
     int sgroup = 1, nsup_total = 0;               // in effect
+    int spt = 1;                                  // scan chunks per tile in effect (2: fused kernels, half-tile operators)
     void* d_sop = nullptr;
     int *d_sopexp = nullptr, *d_sup_rec = nullptr, *d_sup_idx = nullptr;
     void* d_xstage = nullptr;
@@ -120,7 +122,7 @@ struct vbx_batch {
         v.op = (R*)d_op; v.opexp = d_opexp; v.fbound = (R*)d_fbound; v.gbound = (R*)d_gbound;
         v.tllpart = use_chunked ? d_tllpart : nullptr; v.sfw = (R*)d_sfw; v.dump = (R*)d_dump;
         v.sop = (R*)d_sop; v.sopexp = d_sopexp; v.sup_rec = d_sup_rec; v.sup_idx = d_sup_idx;
-        v.sgroup = sgroup; v.nsup_total = nsup_total;
+        v.sgroup = sgroup; v.nsup_total = nsup_total; v.spt = spt;
         return v;
     }
 };
@@ -332,33 +334,45 @@ int choose_fb_algo(vbx_batch* b, bool step_api_logs) {
         FAIL(b->ctx, VBX_ERR_UNSUPPORTED, "chunked scan supports S <= 64 (got padded S = %d)", b->Sp);
     if (chunked && !b->d_op) {
         const size_t rs = b->rsize, nt = (size_t)b->ntiles_total, sp = (size_t)b->Sp;
-        int rc = dmalloc_bytes(b->ctx, &b->d_op, nt * sp * sp * rs);
-        if (rc == VBX_OK) rc = dmalloc(b->ctx, &b->d_opexp, nt * sp);
-        if (rc == VBX_OK) rc = dmalloc_bytes(b->ctx, &b->d_fbound, nt * sp * rs);
-        if (rc == VBX_OK) rc = dmalloc_bytes(b->ctx, &b->d_gbound, nt * sp * rs);
+        int rc = dmalloc_bytes(b->ctx, &b->d_op, 2 * nt * sp * sp * rs);          // two scan chunks per tile
+        if (rc == VBX_OK) rc = dmalloc(b->ctx, &b->d_opexp, 2 * nt * sp);
+        if (rc == VBX_OK) rc = dmalloc_bytes(b->ctx, &b->d_fbound, 2 * nt * sp * rs);
+        if (rc == VBX_OK) rc = dmalloc_bytes(b->ctx, &b->d_gbound, 2 * nt * sp * rs);
         if (rc == VBX_OK) rc = dmalloc(b->ctx, &b->d_tllpart, nt);
         if (rc == VBX_OK) rc = dmalloc_bytes(b->ctx, &b->d_sfw, (size_t)b->sum_T * rs);
         if (rc == VBX_OK) rc = dmalloc_bytes(b->ctx, &b->d_dump, 1024 * rs);
         if (rc != VBX_OK) return rc;
     }
     b->use_chunked = chunked;
+    // the fused kernels work on half-tile scan chunks (two re-run tasks per half: half the dependent chain)
+    const bool fused2 = b->precision == VBX_PREC_FP64 ? (fused_available<double>(b) && fused_loglik_available<double>(b))
+                                                       : (fused_available<float>(b) && fused_loglik_available<float>(b));
+    const int spt = (chunked && fused2 && b->half_chunks) ? 2 : 1;
+    int maxchunks = maxtiles;
+    if (spt == 2) {
+        maxchunks = 0;
+        for (auto& rd : b->recs) maxchunks = std::max(maxchunks, (rd.T + kTileFrames / 2 - 1) / (kTileFrames / 2));
+    }
     // two-level walk over the chunk boundaries: groups of ~sqrt(K) chunks once the flat chain gets long
     int group = 1;
     if (chunked) {
         if (b->scan_group >= 2) group = b->scan_group;
-        else if (b->scan_group == 0 && maxtiles >= 160) group = std::max(4, (int)std::lround(std::sqrt((double)maxtiles)));
+        else if (b->scan_group == 0 && maxchunks >= b->two_level_from)
+            group = std::max(4, (int)std::lround(std::sqrt((double)maxchunks)));
     }
-    if (group != b->sgroup || (group > 1 && !b->d_sop)) {
+    if (group != b->sgroup || spt != b->spt || (group > 1 && !b->d_sop)) {
         for (void* p : {(void*)b->d_sop, (void*)b->d_sopexp, (void*)b->d_sup_rec, (void*)b->d_sup_idx})
             if (p) (void)hipFree(p);
         b->d_sop = nullptr; b->d_sopexp = nullptr; b->d_sup_rec = nullptr; b->d_sup_idx = nullptr;
         b->sgroup = group;
+        b->spt = spt;
         b->nsup_total = 0;
         if (group > 1) {
             std::vector<int> sup_rec, sup_idx;
             for (int i = 0; i < b->n_rec; ++i) {
                 b->recs[i].sup0 = (int)sup_rec.size();
-                const int ns = (b->recs[i].ntiles + group - 1) / group;
+                const int kc = spt == 2 ? (b->recs[i].T + kTileFrames / 2 - 1) / (kTileFrames / 2) : b->recs[i].ntiles;
+                const int ns = (kc + group - 1) / group;
                 for (int s = 0; s < ns; ++s) {
                     sup_rec.push_back(i);
                     sup_idx.push_back(s);
@@ -602,6 +616,13 @@ int vbx_batch_set_option(vbx_batch* b, int option, int64_t value) {
             if (value < 0 || value > 2) FAIL(b->ctx, VBX_ERR_INVALID, "fuse must be 0, 1 or 2");
             b->fuse = (int)value;
             b->mpart_valid = false;
+            return VBX_OK;
+        case VBX_OPT_HALF_CHUNKS:
+            b->half_chunks = value ? 1 : 0;
+            return VBX_OK;
+        case VBX_OPT_TWO_LEVEL_FROM:
+            if (value < 2) FAIL(b->ctx, VBX_ERR_INVALID, "two-level threshold must be >= 2 chunks");
+            b->two_level_from = (int)value;
             return VBX_OK;
         case VBX_OPT_SCAN_GROUP:
             if (value < 0 || value > 4096) FAIL(b->ctx, VBX_ERR_INVALID, "scan group must be in [0, 4096]");
@@ -856,6 +877,7 @@ int fb_step_impl(vbx_batch* b, int64_t T, int32_t S, const double* lls, double* 
         if (rc2 == VBX_OK) rc2 = dmalloc_bytes(ctx, &b->d_bw_scale, (size_t)T * sizeof(R));
         if (rc2 != VBX_OK) return rc2;
     }
+    b->fuse = 0;                                  // stand-alone scan kernels: one operator per tile
     int rc = choose_fb_algo(b, want_logs);
     if (rc != VBX_OK) return rc;
     rc = upload_recs(b);

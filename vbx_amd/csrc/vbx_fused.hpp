@@ -32,8 +32,8 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 3 : 1)) void chu
     __shared__ __attribute__((aligned(16))) R bf[LAT];
     __shared__ R sfl[kTileFrames];                     // sig_t = sum(a_t) of the row stored in af
     __shared__ R qfl[kTileFrames];                     // q_t: every element of the row stored in bf is >= q_t > 0
-    __shared__ R tl_sig[2];
-    __shared__ int tl_expo;
+    __shared__ R tl_sig[2][2];                         // per forward task: scale at its end / on entry
+    __shared__ int tl_expo[2];
     __shared__ __attribute__((aligned(16))) R c_l[SP];
     __shared__ __attribute__((aligned(16))) R aprev0[SP];
     __shared__ double ent_w[4][SP];
@@ -70,9 +70,8 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 3 : 1)) void chu
     __syncthreads();
     VBX_STAMP();
 
-    // rho fragments of d-slab `wave` (B operand of the accumulation at the end).  Waves 2-3 issue the
-    // loads now and wait for the re-run; waves 0-1 issue theirs after it, so that the 2*KS registers are
-    // not live across their loops.
+    // rho fragments of d-slab `wave` (B operand of the accumulation at the end), requested after the wave's
+    // re-run task so that the 2*KS registers are not live across its loop.
     R2 bv[KS];
     auto load_slab = [&](int slab) {
         // rows past the end of the recording are clamped, not predicated: their gamma is zero, so the value
@@ -84,10 +83,13 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 3 : 1)) void chu
         }
     };
 
-    // ---- re-run of the chunk from its boundary vectors (VBx.py:167-171 in the linear domain):
-    // wave 0 walks forward, wave 1 backward.  A lone wavefront on a dependent instruction stream pays
-    // ~8-10 cycles per instruction (measured: 16 issue slots per frame = 160 cycles), so the loops are written
-    // for instruction count.  They carry UNNORMALISED vectors (no reciprocal on the chain),
+    // ---- re-run from the boundary vectors (VBx.py:167-171 in the linear domain) -----------------------
+    // One task = (scan chunk, direction) = one wavefront: with bt.spt == 2 the tile has two scan chunks of
+    // kScanHalf frames, so waves 0..3 = (first half, forward) (first half, backward) (second half, forward)
+    // (second half, backward); with bt.spt == 1 waves 0-1 cover the whole tile and waves 2-3 only prefetch.
+    // A lone wavefront on a dependent instruction stream pays ~8-10 cycles per instruction (measured: 16 issue
+    // slots per frame = 160 cycles), so the loops are written for instruction count.  They carry UNNORMALISED
+    // vectors (no reciprocal on the chain),
     //     forward :  a_t = b_t (lp a_{t-1} + c s_{t-1}),   s_t = sum a_t              (af, sfl)
     //     backward:  x_{t-1} = lp b_t x_t + q_t,           q_t = sum c b_t x_t        (bf, qfl)
     // rescaled by an exact power of two every four frames (worst case a frame shrinks the scale by
@@ -102,20 +104,26 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 3 : 1)) void chu
 #pragma unroll
             for (int r = 0; r < NREG; ++r) dst[k][r] = btile[(f + dir * k) * SP + i16 * NREG + r];
     };
-    if (wave == 0) {
+    const int spt = bt.spt;
+    const int half = spt == 2 ? wave >> 1 : 0;
+    const int lo = spt == 2 ? half * kScanHalf : 0, hi = spt == 2 ? min(len, lo + kScanHalf) : len;
+    const bool has_task = wave < 2 * spt && lo < hi;
+    const long long chunk = (long long)tile * spt + half;
+    if (has_task && (wave & 1) == 0) {
         R a[NREG];
-        const R* __restrict__ bnd = bt.fbound + (long long)tile * SP + i16 * NREG;
+        const R* __restrict__ bnd = bt.fbound + chunk * SP + i16 * NREG;
+        const bool first = t0 + lo == 0;                     // frame 0 of the recording: a_0 = b_0 (ip + 1e-8), VBx.py:163
 #pragma unroll
         for (int r = 0; r < NREG; ++r) {
             a[r] = bnd[r];
-            if (!chunk0) aprev0[i16 * NREG + r] = a[r];      // a[t0-1] (any scale) for the statistics of frame t0
-            if (chunk0) a[r] *= btile[i16 * NREG + r];       // frame 0: a_0 = b_0 (ip + 1e-8), VBx.py:163
+            if (lo == 0 && !first) aprev0[i16 * NREG + r] = a[r];      // a[t0-1] (any scale) for the statistics of frame t0
+            if (first) a[r] *= btile[i16 * NREG + r];
         }
         R sig = a[0];
 #pragma unroll
         for (int r = 1; r < NREG; ++r) sig += a[r];
         sig = allreduce_sum<16>(sig);
-        if (chunk0) {
+        if (first) {
 #pragma unroll
             for (int r = 0; r < NREG; ++r) af[i16 * NREG + r] = a[r];
             sfl[0] = sig;
@@ -140,11 +148,11 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 3 : 1)) void chu
             for (int r = 0; r < NREG; ++r) af[f * SP + i16 * NREG + r] = a[r];
             sfl[f] = sig;
         };
-        int f = r0;
+        int f = first ? lo + 1 : lo;
         R cur[4][NREG], nxt[4][NREG];
-        if (f + 4 <= len) load_rows(cur, f, 1);
-        for (; f + 4 <= len; f += 4) {
-            if (f + 8 <= len) load_rows(nxt, f + 4, 1);
+        if (f + 4 <= hi) load_rows(cur, f, 1);
+        for (; f + 4 <= hi; f += 4) {
+            if (f + 8 <= hi) load_rows(nxt, f + 4, 1);
             renorm();
 #pragma unroll
             for (int k = 0; k < 4; ++k) step(cur[k], f + k);
@@ -154,21 +162,20 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 3 : 1)) void chu
                 for (int r = 0; r < NREG; ++r) cur[k][r] = nxt[k][r];
         }
         renorm();
-        for (; f < len; ++f) {                               // up to three left-over frames
+        for (; f < hi; ++f) {                                // up to three left-over frames
             R b[NREG];
 #pragma unroll
             for (int r = 0; r < NREG; ++r) b[r] = btile[f * SP + i16 * NREG + r];
             step(b, f);
         }
-        if (lane == 0) {                                     // log of the product of the chunk's forward scales
-            tl_sig[0] = sig;
-            tl_sig[1] = chunk0 ? (R)1 : sig_in;
-            tl_expo = expo;
+        if (lane == 0) {                                     // log of the product of this scan chunk's forward scales
+            tl_sig[half][0] = sig;
+            tl_sig[half][1] = first ? (R)1 : sig_in;
+            tl_expo[half] = expo;
         }
-        load_slab(0);
-    } else if (wave == 1) {
+    } else if (has_task) {
         R x[NREG];
-        const R* __restrict__ bnd = bt.gbound + (long long)tile * SP + i16 * NREG;
+        const R* __restrict__ bnd = bt.gbound + chunk * SP + i16 * NREG;     // backward vector at frame hi-1
         R part = 0;
 #pragma unroll
         for (int r = 0; r < NREG; ++r) {
@@ -181,9 +188,9 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 3 : 1)) void chu
 #pragma unroll
             for (int r = 0; r < NREG; ++r) {
                 x[r] = scale2(x[r], -e);
-                bf[(len - 1) * SP + i16 * NREG + r] = x[r];
+                bf[(hi - 1) * SP + i16 * NREG + r] = x[r];
             }
-            qfl[len - 1] = scale2(part, -e) * (R)(1.0 / SP);  // a positive scale of the row, like q below
+            qfl[hi - 1] = scale2(part, -e) * (R)(1.0 / SP);  // a positive scale of the row, like q below
         }
         R q = 1;
         auto step = [&](const R (&b)[NREG], int f) {         // consumes row f, produces x_{f-1}
@@ -201,11 +208,11 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 3 : 1)) void chu
             }
             qfl[f - 1] = q;
         };
-        int f = len - 1;
+        int f = hi - 1;
         R cur[4][NREG], nxt[4][NREG];
-        if (f - 4 >= 0) load_rows(cur, f, -1);
-        for (; f - 4 >= 0; f -= 4) {
-            if (f - 8 >= 0) load_rows(nxt, f - 4, -1);
+        if (f - 4 >= lo) load_rows(cur, f, -1);
+        for (; f - 4 >= lo; f -= 4) {                        // consumes rows f .. f-3 (all > lo)
+            if (f - 8 >= lo) load_rows(nxt, f - 4, -1);
 #pragma unroll
             for (int k = 0; k < 4; ++k) step(cur[k], f - k);
             const int e = rescale_exponent(q);               // (rows already stored keep their own scale)
@@ -216,16 +223,14 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 3 : 1)) void chu
 #pragma unroll
                 for (int r = 0; r < NREG; ++r) cur[k][r] = nxt[k][r];
         }
-        for (; f >= 1; --f) {                                // up to three left-over frames
+        for (; f >= lo + 1; --f) {                           // up to three left-over frames
             R b[NREG];
 #pragma unroll
             for (int r = 0; r < NREG; ++r) b[r] = btile[f * SP + i16 * NREG + r];
             step(b, f);
         }
-        load_slab(1);
-    } else {
-        load_slab(wave);
     }
+    load_slab(wave);
     VBX_STAMP();
     __syncthreads();
     VBX_STAMP();
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 3 : 1)) void chu
             const bool ok = f < len;
             const int fr = ok ? f : 0;
             const R isig = fast_rcp(sfl[fr]), iq = fast_rcp(qfl[fr]);   // (applied one after the other: their product may overflow)
-            const R sp = fr > 0 ? sfl[fr - 1] : tl_sig[1];
+            const R sp = fr > 0 ? sfl[fr - 1] : tl_sig[0][1];
             R a[NREG], x[NREG], ap[NREG], g[NREG];
             load_pack<NREG>(a, af + fr * SP + i16 * NREG);
             load_pack<NREG>(x, bf + fr * SP + i16 * NREG);
@@ -278,8 +283,10 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 3 : 1)) void chu
         // scales = log(s_end 2^expo / s_in), plus the row maxima taken out of the likelihoods
         double mpartial = 0.0;
         if (tid < len) mpartial = (double)bt.mrow[rd.row0 + t0 + tid];
-        if (tid == 128)
-            mpartial += log((double)tl_sig[0]) - log((double)tl_sig[1]) + (double)tl_expo * 0.69314718055994530942;
+        if (tid >= 128 && tid < 130 && (tid == 128 || (spt == 2 && len > kScanHalf))) {
+            const int h = tid - 128;                         // one term per forward task
+            mpartial += log((double)tl_sig[h][0]) - log((double)tl_sig[h][1]) + (double)tl_expo[h] * 0.69314718055994530942;
+        }
         mpartial = block_sum(mpartial, red);               // (contains the barrier ent_w needs)
         if (tid < SP) {
             const double e = (ent_w[0][tid] + ent_w[1][tid]) + (ent_w[2][tid] + ent_w[3][tid]);
@@ -495,66 +502,79 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)si
     __syncthreads();
     VBX_STAMP();
 
-    // ---- phase 2: transfer operator of the chunk ---------------------------------------------------
-    if (tid < SP * PH) {
-        const int col = tid / PH, part = tid % PH, j0 = part * NR;
-        R x[NR], c[NR];
+    // ---- phase 2: transfer operators -----------------------------------------------------------------
+    // bt.spt == 2: one operator per half tile (frames [0, 64) and [64, len)), built side by side by two
+    // groups of NOPT threads when the workgroup is wide enough, else one after the other.
+    {
+        constexpr int NOPT = SP * PH;                      // threads that build one operator
+        constexpr int PAR = 256 / NOPT >= 2 ? 2 : 1;       // operators built side by side
+        const int nhalf = bt.spt == 2 ? (len > kScanHalf ? 2 : 1) : 1;
+        const int grp = tid / NOPT, lt = tid % NOPT;
+        for (int h0 = 0; h0 < nhalf; h0 += PAR) {
+            const int half = h0 + grp;
+            if (grp < PAR && half < nhalf) {
+                const int lo = bt.spt == 2 ? half * kScanHalf : 0;
+                const int hi = bt.spt == 2 ? min(len, lo + kScanHalf) : len;
+                const int col = lt / PH, part = lt % PH, j0 = part * NR;
+                R x[NR], c[NR];
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            x[r] = (j0 + r == col) ? (R)1 : (R)0;
-            c[r] = (j0 + r < rd.S) ? (R)((1.0 - rd.lp) * bt.pi[(long long)rec * SP + j0 + r] + 1e-8) : (R)0;
+                for (int r = 0; r < NR; ++r) {
+                    x[r] = (j0 + r == col) ? (R)1 : (R)0;
+                    c[r] = (j0 + r < rd.S) ? (R)((1.0 - rd.lp) * bt.pi[(long long)rec * SP + j0 + r] + 1e-8) : (R)0;
+                }
+                int expo = 0, step = lo;
+                if (t0 + lo == 0) {          // frame 0 of the recording: x <- b_0 * x (VBx.py:163, no transition)
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) x[r] *= btile[j0 + r];
+                    step = 1;
+                }
+                auto colsum = [&]() {
+                    R sm = x[0];
+#pragma unroll
+                    for (int r = 1; r < NR; ++r) sm += x[r];
+                    return column_sum<PH>(sm);
+                };
+                auto frame = [&](int f, R sig) {
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) x[r] = btile[f * SP + j0 + r] * (lp * x[r] + c[r] * sig);
+                };
+                for (; step + 4 <= hi; step += 4) {
+                    R sig = colsum();
+                    const int e = rescale_exponent(sig);
+                    expo += e;
+                    sig = scale2(sig, -e);
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) x[r] = scale2(x[r], -e);
+                    frame(step, sig);
+#pragma unroll
+                    for (int k = 1; k < 4; ++k) frame(step + k, colsum());
+                }
+                for (; step < hi; ++step) {
+                    R sig = colsum();
+                    const int e = rescale_exponent(sig);
+                    expo += e;
+                    sig = scale2(sig, -e);
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) x[r] = scale2(x[r], -e);
+                    frame(step, sig);
+                }
+                {   // final power-of-two normalisation: column sums end in [0.5, 1)
+                    const R sig = colsum();
+                    const int e = rescale_exponent(sig);
+                    expo += e;
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) x[r] = scale2(x[r], -e);
+                    // an all-zero column (b = 0 for its state at frame 0, or a padded state) must never win the
+                    // exponent maximum in scan2
+                    if (!(sig > (R)0)) expo = -(1 << 24);
+                }
+                const long long chunk = (long long)tile * bt.spt + half;
+                R* __restrict__ dst = bt.op + (chunk * SP + col) * SP + j0;
+#pragma unroll
+                for (int r = 0; r < NR; ++r) dst[r] = x[r];
+                if (part == 0) bt.opexp[chunk * SP + col] = expo;
+            }
         }
-        int expo = 0, first = 0;
-        if (t0 == 0) {                       // frame 0 of the recording: x <- b_0 * x (VBx.py:163, no transition)
-#pragma unroll
-            for (int r = 0; r < NR; ++r) x[r] *= btile[j0 + r];
-            first = 1;
-        }
-        auto colsum = [&]() {
-            R sm = x[0];
-#pragma unroll
-            for (int r = 1; r < NR; ++r) sm += x[r];
-            return column_sum<PH>(sm);
-        };
-        auto frame = [&](int step, R sig) {
-#pragma unroll
-            for (int r = 0; r < NR; ++r) x[r] = btile[step * SP + j0 + r] * (lp * x[r] + c[r] * sig);
-        };
-        int step = first;
-        for (; step + 4 <= len; step += 4) {
-            R sig = colsum();
-            const int e = rescale_exponent(sig);
-            expo += e;
-            sig = scale2(sig, -e);
-#pragma unroll
-            for (int r = 0; r < NR; ++r) x[r] = scale2(x[r], -e);
-            frame(step, sig);
-#pragma unroll
-            for (int k = 1; k < 4; ++k) frame(step + k, colsum());
-        }
-        for (; step < len; ++step) {
-            R sig = colsum();
-            const int e = rescale_exponent(sig);
-            expo += e;
-            sig = scale2(sig, -e);
-#pragma unroll
-            for (int r = 0; r < NR; ++r) x[r] = scale2(x[r], -e);
-            frame(step, sig);
-        }
-        {   // final power-of-two normalisation: column sums end in [0.5, 1)
-            const R sig = colsum();
-            const int e = rescale_exponent(sig);
-            expo += e;
-#pragma unroll
-            for (int r = 0; r < NR; ++r) x[r] = scale2(x[r], -e);
-            // an all-zero column (b = 0 for its state at frame 0, or a padded state) must never win the
-            // exponent maximum in scan2
-            if (!(sig > (R)0)) expo = -(1 << 24);
-        }
-        R* __restrict__ dst = bt.op + ((long long)tile * SP + col) * SP + j0;
-#pragma unroll
-        for (int r = 0; r < NR; ++r) dst[r] = x[r];
-        if (part == 0) bt.opexp[(long long)tile * SP + col] = expo;
     }
     VBX_STAMP();
 #ifdef VBX_PHASE_CLOCKS

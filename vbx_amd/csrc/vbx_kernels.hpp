@@ -78,7 +78,17 @@ template <typename R> struct BatchView {
     const int* sup_rec;    // [nsup_total] recording of a group
     const int* sup_idx;    // [nsup_total] index of the group within its recording
     int sgroup, nsup_total;
+    // scan chunks per tile: 1 = one transfer operator / boundary pair per tile of kTileFrames frames;
+    // 2 = per half tile (kScanHalf frames), chunk index 2*tile + half -- the fused kernels use it to re-run the
+    // two halves of a tile on separate waves (half the dependent chain).  op / opexp / fbound / gbound always
+    // have room for two chunks per tile.
+    int spt;
 };
+
+constexpr int kScanHalf = kTileFrames / 2;
+__device__ __forceinline__ int chunk_count(const RecDesc& rd, int spt) {
+    return spt == 2 ? (rd.T + kScanHalf - 1) / kScanHalf : rd.ntiles;
+}
 
 // =======================================================================================
 // prep: rho = X * sqrt(Phi), G_t = -0.5 (|x_t|^2 + D log 2pi)              VBx.py:87-89

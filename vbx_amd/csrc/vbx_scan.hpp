@@ -142,13 +142,14 @@ __device__ __forceinline__ void scan2_body(const BatchView<R>& bt, int level, R*
     const int rec = level == 3 ? bt.sup_rec[blockIdx.x] : blockIdx.x;
     if (bt.state[rec].done) return;
     const RecDesc rd = bt.recs[rec];
-    const int K = rd.ntiles, G = bt.sgroup;
+    const int K = chunk_count(rd, bt.spt), G = bt.sgroup;      // chunks of this recording, first one cb0
+    const long long cb0 = (long long)rd.tile0 * bt.spt;
     // chain step n uses operator op0 + n*os and writes the boundary b0 + (n+1)*bs; the chain starts from
     // bound[binit] (level 3) or from the initial vector, which it also stores at bound[binit]
     const R* __restrict__ ops = bt.op;
     const int* __restrict__ oexp = bt.opexp;
     int nops = K - 1, os = dir == 0 ? 1 : -1, bs = os;
-    long long op0 = dir == 0 ? rd.tile0 : rd.tile0 + K - 1, b0 = op0, binit = op0;
+    long long op0 = dir == 0 ? cb0 : cb0 + K - 1, b0 = op0, binit = op0;
     if (level == 2) {
         const int ns = (K + G - 1) / G;
         ops = bt.sop;
@@ -156,10 +157,10 @@ __device__ __forceinline__ void scan2_body(const BatchView<R>& bt, int level, R*
         nops = ns - 1;
         op0 = dir == 0 ? rd.sup0 : rd.sup0 + ns - 1;
         bs = dir == 0 ? G : -G;
-        b0 = dir == 0 ? rd.tile0 : rd.tile0 + (long long)ns * G - 1;
+        b0 = dir == 0 ? cb0 : cb0 + (long long)ns * G - 1;
     } else if (level == 3) {
-        const int a = rd.tile0 + bt.sup_idx[blockIdx.x] * G, b = min(a + G, rd.tile0 + K);
-        nops = b - 1 - a;
+        const long long a = cb0 + (long long)bt.sup_idx[blockIdx.x] * G, b = min(a + G, cb0 + K);
+        nops = (int)(b - 1 - a);
         op0 = b0 = binit = dir == 0 ? a : b - 1;
         if (nops <= 0) return;
     }
@@ -314,7 +315,8 @@ __global__ __launch_bounds__(256) void scan_compose_kernel(BatchView<R> bt) {
     if (bt.state[rec].done) return;
     const RecDesc rd = bt.recs[rec];
     const int G = bt.sgroup;
-    const int a = rd.tile0 + bt.sup_idx[sup] * G, b = min(a + G, rd.tile0 + rd.ntiles);
+    const long long cb0 = (long long)rd.tile0 * bt.spt;
+    const long long a = cb0 + (long long)bt.sup_idx[sup] * G, b = min(a + G, cb0 + chunk_count(rd, bt.spt));
     const int tid = threadIdx.x, i = tid / RG, rg = tid % RG, r0 = rg * RPT;
     R pv[RPT];
     int eP = bt.opexp[(long long)a * SP + i];
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(256) void scan_compose_kernel(BatchView<R> bt) {
     for (int rr = 0; rr < RPT; ++rr) pv[rr] = bt.op[((long long)a * SP + i) * SP + r0 + rr];
     R4 fr[VPT];
     int efr = 0;
-    auto fetch = [&](int k) {                              // chunk operator k: global -> registers
+    auto fetch = [&](long long k) {                        // chunk operator k: global -> registers
         const R4* __restrict__ src = reinterpret_cast<const R4*>(bt.op + (long long)k * SP * SP);
 #pragma unroll
         for (int u = 0; u < VPT; ++u)
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(256) void scan_compose_kernel(BatchView<R> bt) {
         if (tid < SP) efr = bt.opexp[(long long)k * SP + tid];
     };
     if (a + 1 < b) fetch(a + 1);
-    for (int k = a + 1; k < b; ++k) {
+    for (long long k = a + 1; k < b; ++k) {
 #pragma unroll
         for (int u = 0; u < VPT; ++u)
             if (u * 256 + tid < SP * SP / 4) reinterpret_cast<R4*>(Fl)[u * 256 + tid] = fr[u];
