@@ -8,6 +8,16 @@
 #pragma once
 #include "vbx_scan.hpp"
 
+// Build with -DVBX_PHASE_CLOCKS to make one workgroup in a thousand print the shader-clock cycles it spent
+// in every phase of the two kernels below (the numbers quoted in DESIGN.md section 10 come from this).
+#ifdef VBX_PHASE_CLOCKS
+#define VBX_CLOCKS_DECL() long long clk[8]; int nclk = 0
+#define VBX_STAMP() clk[nclk++] = clock64()
+#else
+#define VBX_CLOCKS_DECL()
+#define VBX_STAMP()
+#endif
+
 namespace vbx {
 
 // Does the chunk_post kernel's LDS footprint fit the CU?  (3 lattices of kTileFrames x SP)
@@ -51,13 +61,7 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 3 : 1)) void chu
     const R lp = (R)rd.lp;
     const R* __restrict__ rho = bt.rho + rd.row0 * Dp;
 
-#ifdef VBX_PHASE_CLOCKS
-    long long clk[8];
-    int nclk = 0;
-#define VBX_STAMP() clk[nclk++] = clock64()
-#else
-#define VBX_STAMP()
-#endif
+    VBX_CLOCKS_DECL();
     VBX_STAMP();
     // ---- phase 0: the chunk's shifted likelihoods go to LDS --------------------------------------
     stage_to_lds<(kTileFrames * SP / 4 + 255) / 256>(reinterpret_cast<R4*>(btile),
@@ -379,10 +383,8 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)si
     // chunk-frame for PH = 8 / 4 / 2 at SP = 32, but also fewer wavefronts to hide each other's latency.
     // Measured on 64 recordings of T = 10 000: 171 / 163 / 176 us per launch, so PH = 4 (two wavefronts build
     // the operator, the other two retire after phase 1).
-#ifndef VBX_OP_LANES
-#define VBX_OP_LANES 4
-#endif
-    constexpr int PH = (SP * VBX_OP_LANES <= 256) ? VBX_OP_LANES : 256 / SP, NR = SP / PH;
+    constexpr int kOperatorLanes = 4;
+    constexpr int PH = (SP * kOperatorLanes <= 256) ? kOperatorLanes : 256 / SP, NR = SP / PH;
     constexpr int AST = kAlphaSlice + 4;               // padded row of the alpha slice: conflict-free fragment reads
     // one LDS region, two lives: the alpha slice during the MFMA pass, then b of the chunk
     constexpr int kLds = kTileFrames * SP > SP * AST ? kTileFrames * SP : SP * AST;
@@ -399,10 +401,7 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)si
     const int len = min(kTileFrames, rd.T - t0);
     const R lp = (R)rd.lp;
 
-#ifdef VBX_PHASE_CLOCKS
-    long long clk[8];
-    int nclk = 0;
-#endif
+    VBX_CLOCKS_DECL();
     VBX_STAMP();
     // ---- phase 1: wave w owns frames [32w, 32w+32) of the chunk = 2 M-tiles ----------------------
     {
