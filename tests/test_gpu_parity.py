@@ -553,3 +553,29 @@ def test_half_tile_scan_chunks_equal_whole_tile_chunks(ctx, precision, tol):
             a, b = out[key][j], out[0, 1][j]
             assert np.abs(a['gamma'] - b['gamma']).max() <= tol, (key, Ts[j], np.abs(a['gamma'] - b['gamma']).max())
             assert np.abs(a['pi'] - b['pi']).max() <= tol and rel_err(a['Li'], b['Li']) <= tol, (key, Ts[j])
+
+
+def test_python_batch_api_equals_one_call_per_recording(synth_cases):
+    """vbx_amd.batch.VBx_batch([...]) == [VBx(...) for ...]: mixed T, S and feature dims in one call, per-recording
+    hyper-parameters, the global-RNG gamma initialisation drawn in list order, return_model."""
+    import vbx_amd
+    from vbx_amd.batch import VBx_batch
+    from vbx_amd.synth import make_recording
+    recs = []
+    for k, (T, S, D) in enumerate([(500, 6, 128), (900, 20, 128), (300, 4, 64), (1300, 40, 128)]):
+        X, Phi, _ = make_recording(T, S, D=D, seed=70 + k, kappa=0.05)
+        recs.append(dict(X=X, Phi=Phi, pi=S, loopProb=0.9 - 0.1 * (k % 2), Fa=0.3 + 0.1 * k))
+    np.random.seed(11)
+    together = VBx_batch(recs, maxIters=6, epsilon=1e-4, precision='fp64', return_model=True, Fb=17.0)
+    np.random.seed(11)
+    for rec, got in zip(recs, together):
+        kw = {k: v for k, v in rec.items() if k not in ('X', 'Phi')}
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            one = vbx_amd.VBx(rec['X'], rec['Phi'], maxIters=6, epsilon=1e-4, precision='fp64', return_model=True,
+                              Fb=17.0, **kw)
+        assert len(got) == 5 and len(got[2]) == len(one[2])
+        np.testing.assert_allclose(got[0], one[0], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(got[1], one[1], rtol=0, atol=1e-10)
+        np.testing.assert_allclose([r[0] for r in got[2]], [r[0] for r in one[2]], rtol=1e-12)
+        np.testing.assert_allclose(got[3], one[3], rtol=0, atol=1e-9)
