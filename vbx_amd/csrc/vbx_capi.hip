@@ -348,6 +348,14 @@ int choose_fb_algo(vbx_batch* b, bool step_api_logs) {
     const bool fused2 = b->precision == VBX_PREC_FP64 ? (fused_available<double>(b) && fused_loglik_available<double>(b))
                                                        : (fused_available<float>(b) && fused_loglik_available<float>(b));
     const int spt = (chunked && fused2 && b->half_chunks) ? 2 : 1;
+    // the forward / backward lattices live in HBM only on the paths that do not keep them in LDS
+    const bool fused1 = b->precision == VBX_PREC_FP64 ? fused_available<double>(b) : fused_available<float>(b);
+    if (!fused1 && !b->d_ahat) {
+        const size_t cells = (size_t)b->sum_T * b->Sp;
+        int rc = dmalloc_bytes(b->ctx, &b->d_ahat, cells * b->rsize);
+        if (rc == VBX_OK) rc = dmalloc_bytes(b->ctx, &b->d_bhat, cells * b->rsize);
+        if (rc != VBX_OK) return rc;
+    }
     int maxchunks = maxtiles;
     if (spt == 2) {
         maxchunks = 0;
@@ -565,8 +573,6 @@ int vbx_batch_create(vbx_ctx* ctx, int n_rec, const int64_t* T, const int32_t* S
     ALLOC(dmalloc_bytes(ctx, &b->d_gamma, cells * rs));
     ALLOC(dmalloc_bytes(ctx, &b->d_bmat, cells * rs));
     ALLOC(dmalloc_bytes(ctx, &b->d_mrow, (size_t)b->sum_T * rs));
-    ALLOC(dmalloc_bytes(ctx, &b->d_ahat, cells * rs));
-    ALLOC(dmalloc_bytes(ctx, &b->d_bhat, cells * rs));
     ALLOC(dmalloc_bytes(ctx, &b->d_alpha, (size_t)n_rec * b->Sp * b->Dp * rs));
     ALLOC(dmalloc_bytes(ctx, &b->d_invL, (size_t)n_rec * b->Sp * b->Dp * rs));
     ALLOC(dmalloc_bytes(ctx, &b->d_bias, (size_t)n_rec * b->Sp * rs));
