@@ -579,3 +579,42 @@ def test_python_batch_api_equals_one_call_per_recording(synth_cases):
         np.testing.assert_allclose(got[1], one[1], rtol=0, atol=1e-10)
         np.testing.assert_allclose([r[0] for r in got[2]], [r[0] for r in one[2]], rtol=1e-12)
         np.testing.assert_allclose(got[3], one[3], rtol=0, atol=1e-9)
+
+
+def test_randomised_differential_against_the_oracle():
+    """Forty random problems (lengths around the 128-frame chunk edges, every padded speaker width, odd feature
+    dims, loopProb in {0, 1, ...}, priors with zeros, 1-4 iterations) on the f64 device path vs the oracle."""
+    import vbx_amd
+    rng = np.random.default_rng(2024)
+    lengths = [1, 2, 3, 63, 64, 65, 127, 128, 129, 130, 255, 256, 257, 300, 511, 640, 700]
+    for case in range(40):
+        T = int(rng.choice(lengths))
+        S = int(rng.choice([1, 2, 3, 7, 15, 16, 17, 31, 32, 33, 50, 64, 65, 70]))
+        D = int(rng.choice([8, 31, 32, 33, 64, 100, 128, 129, 200]))
+        lp = float(rng.choice([0.0, 0.3, 0.9, 0.99, 1.0]))
+        Fa, Fb = float(rng.uniform(0.1, 1.0)), float(rng.uniform(1.0, 64.0))
+        X = rng.standard_normal((T, D)) + rng.standard_normal((1, D)) * (rng.random() < 0.5)
+        Phi = np.sort(rng.uniform(0.3, 6.0, D))[::-1].copy()
+        g0 = rng.gamma(1.0, size=(T, S))
+        g0 /= g0.sum(1, keepdims=True)
+        pi0 = rng.random(S) + 0.01
+        if S > 2 and rng.random() < 0.4:
+            pi0[rng.integers(0, S, max(1, S // 3))] = 0.0
+        pi0 /= pi0.sum()
+        iters = int(rng.integers(1, 5))
+        kw = dict(loopProb=lp, Fa=Fa, Fb=Fb, pi=pi0, gamma=g0, maxIters=iters, epsilon=-1e300, return_model=True)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            gr, pr, Lr, ar, ir = _orc().VBx(X, Phi, **kw)
+            g, p, L, a, il = vbx_amd.VBx(X, Phi, precision='fp64', **kw)
+        tag = (case, T, S, D, lp, iters)
+        assert np.all(np.isfinite(g)), tag
+        assert np.abs(g - gr).max() <= 1e-8, (tag, np.abs(g - gr).max())
+        assert np.abs(p - pr).max() <= 1e-9, tag
+        assert rel_err([r[0] for r in L], [r[0] for r in Lr]) <= 1e-9, tag
+        assert np.abs(a - ar).max() <= 1e-8 * max(1.0, np.abs(ar).max()) and np.abs(il - ir).max() <= 1e-9, tag
+        with contextlib.redirect_stdout(buf):
+            g32, p32, L32 = vbx_amd.VBx(X, Phi, precision='fp32', **{**kw, 'return_model': False})
+        assert np.all(np.isfinite(g32)), tag
+        assert np.abs(g32 - gr).max() <= FP32_TOL, (tag, np.abs(g32 - gr).max())
+        assert np.abs(p32 - pr).max() <= FP32_TOL and rel_err([r[0] for r in L32], [r[0] for r in Lr]) <= FP32_TOL, tag
