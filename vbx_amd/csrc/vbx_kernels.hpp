@@ -236,12 +236,13 @@ __global__ __launch_bounds__(256) void mstep_fin_kernel(BatchView<R> bt) {
             const R* __restrict__ mp = bt.mpart + ((long long)rd.tile0 * Sp + s) * Dp + (dok ? d : 0);
             const long long stride = (long long)Sp * Dp;
             const int lo = half == 0 ? 0 : (nt + 1) / 2, hi = half == 0 ? (nt + 1) / 2 : nt;
-            for (int tl = lo; tl < hi; tl += 16) {
-                R v[16];
+            constexpr int LB = sizeof(R) == 8 ? 20 : 40;       // loads in flight per thread: T = 10 000 in one round trip
+            for (int tl = lo; tl < hi; tl += LB) {
+                R v[LB];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = mp[(long long)min(tl + u, last) * stride];
+                for (int u = 0; u < LB; ++u) v[u] = mp[(long long)min(tl + u, last) * stride];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) C += (tl + u < hi) ? (double)v[u] : 0.0;
+                for (int u = 0; u < LB; ++u) C += (tl + u < hi) ? (double)v[u] : 0.0;
             }
         }
         csum[threadIdx.x] = C;
