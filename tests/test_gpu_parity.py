@@ -555,6 +555,37 @@ def test_half_tile_scan_chunks_equal_whole_tile_chunks(ctx, precision, tol):
             assert np.abs(a['pi'] - b['pi']).max() <= tol and rel_err(a['Li'], b['Li']) <= tol, (key, Ts[j])
 
 
+@pytest.mark.parametrize('precision,tol', [('fp64', 1e-11), ('fp32', 2e-5)])
+def test_meet_in_the_middle_posteriors_equal_full_lattice_kernel(ctx, precision, tol):
+    """VBX_OPT_POST_MID: the posterior kernel that keeps half a forward and half a backward lattice (the two
+    recursions meet at the middle of the tile) against the one that keeps both whole lattices; the oracle is the
+    judge of both in the other tests.  Lengths: full tiles, a tail shorter than half a tile, a tail longer than
+    half, one frame, exactly half; S on both sides of the 16-state padding."""
+    from vbx_amd import _capi
+    from vbx_amd.synth import make_recording
+    for S in (7, 16, 30):
+        Ts = [1024, 1000, 1100, 1, 64, 129, 2]
+        recs = []
+        for k, T in enumerate(Ts):
+            X, Phi, _ = make_recording(T, S, seed=150 + k, kappa=0.05)
+            g0 = np.random.default_rng(160 + k).gamma(1.0, size=(T, S))
+            recs.append((X, Phi, g0 / g0.sum(1, keepdims=True)))
+        out = {}
+        for mid in (0, 1):
+            batch = _capi.Batch(ctx, Ts, [S] * len(Ts), 128, precision=precision, max_iters=4)
+            batch.set_option(_capi.OPT_POST_MID, mid)
+            for j, (X, Phi, g0) in enumerate(recs):
+                batch.set_recording(j, X, Phi, np.ones(S) / S, g0, 0.95, 0.3, 17.0)
+            batch.run(4, -np.inf)
+            out[mid] = [batch.result(j, want_model=True) for j in range(len(Ts))]
+            batch.close()
+        for j in range(len(Ts)):
+            a, b = out[1][j], out[0][j]
+            assert np.abs(a['gamma'] - b['gamma']).max() <= tol, (S, Ts[j], np.abs(a['gamma'] - b['gamma']).max())
+            assert np.abs(a['pi'] - b['pi']).max() <= tol and rel_err(a['Li'], b['Li']) <= tol, (S, Ts[j])
+            assert np.abs(a['alpha'] - b['alpha']).max() <= tol * max(1.0, np.abs(b['alpha']).max()), (S, Ts[j])
+
+
 def test_python_batch_api_equals_one_call_per_recording(synth_cases):
     """vbx_amd.batch.VBx_batch([...]) == [VBx(...) for ...]: mixed T, S and feature dims in one call, per-recording
     hyper-parameters, the global-RNG gamma initialisation drawn in list order, return_model."""

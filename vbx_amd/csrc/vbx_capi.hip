@@ -8,6 +8,7 @@
 #include "vbx_kernels.hpp"
 #include "vbx_scan.hpp"
 #include "vbx_fused.hpp"
+#include "vbx_fused_mid.hpp"
 #include "vbx_ahc.hpp"
 
 #include <algorithm>
@@ -92,7 +93,8 @@ struct vbx_batch {
     bool use_chunked = false;
     // two-level boundary walk
     int scan_group = 0;                           // option: 0 auto, 1 flat, >= 2 chunks per group
-    int half_chunks = 0, two_level_from = 160;    // options: half-tile scan chunks in the fused path; auto two-level threshold
+    int half_chunks = 0, two_level_from = 160;
+    int post_mid = 1;                             // option: meet-in-the-middle lattice layout of chunk_post    // options: half-tile scan chunks in the fused path; auto two-level threshold
     int sgroup = 1, nsup_total = 0;               // in effect
     int spt = 1;                                  // scan chunks per tile in effect (2: fused kernels, half-tile operators)
     void* d_sop = nullptr;
@@ -214,7 +216,10 @@ template <typename R, int SP> void launch_scan(vbx_batch* b, const BatchView<R>&
     if constexpr (ChunkPostCfg<R, SP>::kFits) {
         if (fused_post) {
             LaunchScope ls(b, VBX_K_CHUNK_POST);
-            hipLaunchKernelGGL((chunk_post_kernel<R, SP>), dim3(b->ntiles_total), dim3(256), 0, st, v);
+            if (b->post_mid && v.spt == 1)
+                hipLaunchKernelGGL((chunk_post_mid_kernel<R, SP>), dim3(b->ntiles_total), dim3(256), 0, st, v);
+            else
+                hipLaunchKernelGGL((chunk_post_kernel<R, SP>), dim3(b->ntiles_total), dim3(256), 0, st, v);
             return;
         }
     }
@@ -569,7 +574,8 @@ int vbx_batch_create(vbx_ctx* ctx, int n_rec, const int64_t* T, const int32_t* S
     ALLOC(dmalloc(ctx, &b->d_phi, (size_t)n_rec * b->Dp));
     ALLOC(dmalloc(ctx, &b->d_sqrt_phi, b->Dp));
     ALLOC(dmalloc(ctx, &b->d_gtile, b->ntiles_total));
-    ALLOC(dmalloc_bytes(ctx, &b->d_rho, (size_t)b->sum_T * b->Dp * rs));
+    // (one tile of zero rows after the last recording: kernels may read whole tiles past its end)
+    ALLOC(dmalloc_bytes(ctx, &b->d_rho, ((size_t)b->sum_T + kTileFrames) * b->Dp * rs));
     ALLOC(dmalloc_bytes(ctx, &b->d_gamma, cells * rs));
     ALLOC(dmalloc_bytes(ctx, &b->d_bmat, cells * rs));
     ALLOC(dmalloc_bytes(ctx, &b->d_mrow, (size_t)b->sum_T * rs));
@@ -594,6 +600,7 @@ int vbx_batch_create(vbx_ctx* ctx, int n_rec, const int64_t* T, const int32_t* S
         (e = hipMemcpy(b->d_tile_t0, tile_t0.data(), sizeof(int) * tile_t0.size(), hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMemset(b->d_state, 0, sizeof(RecState) * n_rec)) != hipSuccess ||
         (e = hipMemset(b->d_gamma, 0, cells * rs)) != hipSuccess ||
+        (e = hipMemset((char*)b->d_rho + (size_t)b->sum_T * b->Dp * rs, 0, (size_t)kTileFrames * b->Dp * rs)) != hipSuccess ||
         (e = hipDeviceSynchronize()) != hipSuccess ||      // null-stream memsets vs. our non-blocking stream
         (e = hipEventCreate(&b->ev_start)) != hipSuccess || (e = hipEventCreate(&b->ev_stop)) != hipSuccess) {
         ctx->err = std::string("batch initialisation failed: ") + hipGetErrorString(e);
@@ -622,6 +629,9 @@ int vbx_batch_set_option(vbx_batch* b, int option, int64_t value) {
             if (value < 0 || value > 2) FAIL(b->ctx, VBX_ERR_INVALID, "fuse must be 0, 1 or 2");
             b->fuse = (int)value;
             b->mpart_valid = false;
+            return VBX_OK;
+        case VBX_OPT_POST_MID:
+            b->post_mid = value ? 1 : 0;
             return VBX_OK;
         case VBX_OPT_HALF_CHUNKS:
             b->half_chunks = value ? 1 : 0;
@@ -1188,3 +1198,10 @@ int vbx_scores_two_gmm_calib(vbx_scores* sc, int32_t niters, double* threshold, 
 
 }  // extern "C"
 
+
+#ifdef VBX_PHASE_CLOCKS
+// instrumentation builds only: the per-tile phase stamps of chunk_post_mid_kernel (tile, {wave 0, wave 2}, 8)
+extern "C" int vbx_debug_clocks(long long* out, int n_words) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(vbx::g_phase_clocks), (size_t)n_words * sizeof(long long));
+}
+#endif

@@ -78,12 +78,13 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 3 : 1)) void chu
     // re-run task so that the 2*KS registers are not live across its loop.
     R2 bv[KS];
     auto load_slab = [&](int slab) {
-        // rows past the end of the recording are clamped, not predicated: their gamma is zero, so the value
-        // does not matter, and unconditional loads all stay in flight together
-        const R* __restrict__ src = rho + (long long)t0 * Dp + 32 * slab + 2 * i16;
+        // rows past the end of the recording are read as they lie (the next recording, or the zero rows behind
+        // the last one): their gamma is zero, so the value does not matter, unconditional loads all stay in
+        // flight together, and every address is one uniform base + a per-lane offset
+        const R* __restrict__ src = rho + (long long)t0 * Dp + 32 * slab;
         if (slab * 32 < Dp) {
 #pragma unroll
-            for (int u = 0; u < KS; ++u) bv[u] = *reinterpret_cast<const R2*>(src + min(4 * u + g4, len - 1) * Dp);
+            for (int u = 0; u < KS; ++u) bv[u] = *reinterpret_cast<const R2*>(src + 4 * u * Dp + g4 * Dp + 2 * i16);
         }
     };
 
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 3 : 1)) void chu
         for (int u = 0; u < KS; ++u) {
             const int f = 4 * u + g4;
             R2 b2 = bv[u];
-            if (!first) b2 = *reinterpret_cast<const R2*>(rho + (long long)(t0 + min(f, len - 1)) * Dp + 32 * slab + 2 * i16);
+            if (!first) b2 = *reinterpret_cast<const R2*>(rho + (long long)t0 * Dp + 32 * slab + 4 * u * Dp + g4 * Dp + 2 * i16);
             R av[NT];
 #pragma unroll
             for (int mu = 0; mu < NT; ++mu) av[mu] = bf[f * SP + NT * i16 + mu];
