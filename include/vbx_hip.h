@@ -62,7 +62,9 @@ extern "C" {
 #define VBX_OPT_CHUNK_FRAMES 4  /* frames per scan chunk for VBX_FB_CHUNKED (0 = auto)         */
 #define VBX_OPT_SCAN_GROUP 6    /* chunks per group of the two-level boundary walk: 0 auto (sqrt of the chunk count
                                    once a recording has >= 160 chunks), 1 flat chain, >= 2 explicit              */
-#define VBX_OPT_POST_MID 9      /* 1 (default): chunk_post keeps half lattices in LDS (meet in the middle); 0: full */
+#define VBX_OPT_POST_KERNEL 9   /* chunk_post variant: 1 (default) half lattices in LDS (meet in the middle, four workgroups
+                                   per CU); 0 full lattices; 2 four tiles per workgroup, one per 16-lane row of the
+                                   re-run waves, gamma^T rho fed from registers (f32, <= 32 states, D <= 128; else 1) */
 #define VBX_OPT_HALF_CHUNKS 7   /* 1: the fused kernels use one transfer operator / boundary pair per HALF tile (64
                                    frames) and re-run the halves on separate waves; 0 (default): per tile.  Halves
                                    the chunk kernels' dependent chains, doubles the boundary walk: a wash overall */

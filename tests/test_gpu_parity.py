@@ -556,34 +556,72 @@ def test_half_tile_scan_chunks_equal_whole_tile_chunks(ctx, precision, tol):
 
 
 @pytest.mark.parametrize('precision,tol', [('fp64', 1e-11), ('fp32', 2e-5)])
-def test_meet_in_the_middle_posteriors_equal_full_lattice_kernel(ctx, precision, tol):
-    """VBX_OPT_POST_MID: the posterior kernel that keeps half a forward and half a backward lattice (the two
-    recursions meet at the middle of the tile) against the one that keeps both whole lattices; the oracle is the
-    judge of both in the other tests.  Lengths: full tiles, a tail shorter than half a tile, a tail longer than
-    half, one frame, exactly half; S on both sides of the 16-state padding."""
+def test_chunk_post_variants_agree(ctx, precision, tol):
+    """VBX_OPT_POST_KERNEL: 0 = both whole lattices in LDS, 1 = half a forward and half a backward lattice (the two
+    recursions meet at the middle of the tile), 2 = four tiles per workgroup, one per 16-lane row of the re-run
+    waves (f32 and <= 32 states; otherwise the library falls back to 1).  The oracle is the judge of the default (1) in
+    the other tests; here the three must agree.  Lengths: full tiles, tails shorter and longer than half a tile,
+    1, 2, 3, 63, 64, 65 and 127 frames (where the backward recursion of a short tile starts), tile counts that are
+    not multiples of four; S on both sides of the 16-state padding."""
     from vbx_amd import _capi
     from vbx_amd.synth import make_recording
     for S in (7, 16, 30):
-        Ts = [1024, 1000, 1100, 1, 64, 129, 2]
+        Ts = [1024, 1000, 1100, 1, 64, 129, 2, 3, 63, 65, 127, 128, 191, 300]
         recs = []
         for k, T in enumerate(Ts):
             X, Phi, _ = make_recording(T, S, seed=150 + k, kappa=0.05)
             g0 = np.random.default_rng(160 + k).gamma(1.0, size=(T, S))
             recs.append((X, Phi, g0 / g0.sum(1, keepdims=True)))
         out = {}
-        for mid in (0, 1):
+        for variant in (0, 1, 2):
             batch = _capi.Batch(ctx, Ts, [S] * len(Ts), 128, precision=precision, max_iters=4)
-            batch.set_option(_capi.OPT_POST_MID, mid)
+            batch.set_option(_capi.OPT_POST_KERNEL, variant)
             for j, (X, Phi, g0) in enumerate(recs):
                 batch.set_recording(j, X, Phi, np.ones(S) / S, g0, 0.95, 0.3, 17.0)
             batch.run(4, -np.inf)
-            out[mid] = [batch.result(j, want_model=True) for j in range(len(Ts))]
+            out[variant] = [batch.result(j, want_model=True) for j in range(len(Ts))]
             batch.close()
-        for j in range(len(Ts)):
-            a, b = out[1][j], out[0][j]
-            assert np.abs(a['gamma'] - b['gamma']).max() <= tol, (S, Ts[j], np.abs(a['gamma'] - b['gamma']).max())
-            assert np.abs(a['pi'] - b['pi']).max() <= tol and rel_err(a['Li'], b['Li']) <= tol, (S, Ts[j])
-            assert np.abs(a['alpha'] - b['alpha']).max() <= tol * max(1.0, np.abs(b['alpha']).max()), (S, Ts[j])
+        for variant in (1, 2):
+            for j in range(len(Ts)):
+                a, b = out[variant][j], out[0][j]
+                key = (variant, S, Ts[j])
+                assert np.abs(a['gamma'] - b['gamma']).max() <= tol, (key, np.abs(a['gamma'] - b['gamma']).max())
+                assert np.abs(a['pi'] - b['pi']).max() <= tol and rel_err(a['Li'], b['Li']) <= tol, key
+                assert np.abs(a['alpha'] - b['alpha']).max() <= tol * max(1.0, np.abs(b['alpha']).max()), key
+
+
+def test_converged_recordings_are_skipped_by_every_chunk_post_variant(ctx):
+    """Device-side convergence: a recording that has converged keeps its results while the others of the batch go
+    on (the four-tile kernel sees it through tile_done).  Each recording of a mixed batch must equal its own
+    single-recording run with the same epsilon."""
+    from vbx_amd import _capi
+    from vbx_amd.synth import make_recording
+    Ts, S = [700, 260, 1500, 130, 900], 9
+    recs = []
+    for k, T in enumerate(Ts):
+        X, Phi, _ = make_recording(T, S, seed=250 + k, kappa=0.03 + 0.02 * k)
+        g0 = np.random.default_rng(260 + k).gamma(1.0, size=(T, S))
+        recs.append((X, Phi, g0 / g0.sum(1, keepdims=True)))
+    for variant in (0, 1, 2):
+        batch = _capi.Batch(ctx, Ts, [S] * len(Ts), 128, precision='fp32', max_iters=30)
+        batch.set_option(_capi.OPT_POST_KERNEL, variant)
+        batch.set_option(_capi.OPT_CHECK_EVERY, 1000)
+        for j, (X, Phi, g0) in enumerate(recs):
+            batch.set_recording(j, X, Phi, np.ones(S) / S, g0, 0.9, 0.3, 17.0)
+        batch.run(30, 1e-3)
+        together = [batch.result(j, want_model=False) for j in range(len(Ts))]
+        batch.close()
+        iters = [len(r['Li']) for r in together]
+        assert len(set(iters)) > 1, iters                    # the batch really is mixed
+        for j, (X, Phi, g0) in enumerate(recs):
+            one = _capi.Batch(ctx, [Ts[j]], [S], 128, precision='fp32', max_iters=30)
+            one.set_option(_capi.OPT_POST_KERNEL, variant)
+            one.set_recording(0, X, Phi, np.ones(S) / S, g0, 0.9, 0.3, 17.0)
+            one.run(30, 1e-3)
+            alone = one.result(0, want_model=False)
+            one.close()
+            assert len(alone['Li']) == iters[j], (variant, j, len(alone['Li']), iters[j])
+            assert np.abs(alone['gamma'] - together[j]['gamma']).max() <= 2e-5, (variant, j)
 
 
 def test_python_batch_api_equals_one_call_per_recording(synth_cases):

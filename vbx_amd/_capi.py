@@ -13,7 +13,7 @@ VBX_F32, VBX_F64 = 0, 1
 PREC_FP32, PREC_FP64 = 0, 1
 FB_AUTO, FB_SEQUENTIAL, FB_CHUNKED = 0, 1, 2
 OPT_FB_ALGO, OPT_CHECK_EVERY, OPT_PROFILE, OPT_CHUNK_FRAMES, OPT_FUSE, OPT_SCAN_GROUP = 1, 2, 3, 4, 5, 6
-OPT_HALF_CHUNKS, OPT_TWO_LEVEL_FROM, OPT_POST_MID = 7, 8, 9
+OPT_HALF_CHUNKS, OPT_TWO_LEVEL_FROM, OPT_POST_KERNEL = 7, 8, 9
 K_NAMES = ['prep', 'mstep_acc', 'mstep_fin', 'loglik', 'fb', 'fb_aux', 'post', 'iter_fin', 'chunk_loglik',
            'chunk_post']
 MAX_SPEAKERS = 256
@@ -250,7 +250,7 @@ class Batch:
             self.set_option(OPT_FB_ALGO, {'auto': FB_AUTO, 'sequential': FB_SEQUENTIAL,
                                           'chunked': FB_CHUNKED}[algo])
         for env, opt in (('VBX_AMD_HALF_CHUNKS', OPT_HALF_CHUNKS), ('VBX_AMD_TWO_LEVEL_FROM', OPT_TWO_LEVEL_FROM),
-                         ('VBX_AMD_POST_MID', OPT_POST_MID)):
+                         ('VBX_AMD_POST_KERNEL', OPT_POST_KERNEL)):
             if os.environ.get(env) is not None:
                 self.set_option(opt, int(os.environ[env]))
         group = os.environ.get('VBX_AMD_SCAN_GROUP')      # chunks per group of the two-level boundary walk

@@ -9,6 +9,7 @@
 #include "vbx_scan.hpp"
 #include "vbx_fused.hpp"
 #include "vbx_fused_mid.hpp"
+#include "vbx_fused_quad.hpp"
 #include "vbx_ahc.hpp"
 
 #include <algorithm>
@@ -76,7 +77,8 @@ struct vbx_batch {
     // device memory
     RecDesc* d_recs = nullptr;
     RecState* d_state = nullptr;
-    int *d_tile_rec = nullptr, *d_tile_t0 = nullptr;
+    int *d_tile_rec = nullptr, *d_tile_t0 = nullptr, *d_tile_done = nullptr;
+    int4* d_tile_desc = nullptr;
     double *d_phi = nullptr, *d_sqrt_phi = nullptr, *d_gtile = nullptr;
     void *d_rho = nullptr, *d_gamma = nullptr, *d_bmat = nullptr, *d_mrow = nullptr, *d_ahat = nullptr,
          *d_bhat = nullptr, *d_alpha = nullptr, *d_invL = nullptr, *d_bias = nullptr, *d_mpart = nullptr,
@@ -94,7 +96,8 @@ struct vbx_batch {
     // two-level boundary walk
     int scan_group = 0;                           // option: 0 auto, 1 flat, >= 2 chunks per group
     int half_chunks = 0, two_level_from = 160;
-    int post_mid = 1;                             // option: meet-in-the-middle lattice layout of chunk_post    // options: half-tile scan chunks in the fused path; auto two-level threshold
+    int post_kernel = 1;                          // option: chunk_post variant (0 full lattices, 1 meet in the middle, 2 four tiles per workgroup)
+    // options: half-tile scan chunks in the fused path; auto two-level threshold
     int sgroup = 1, nsup_total = 0;               // in effect
     int spt = 1;                                  // scan chunks per tile in effect (2: fused kernels, half-tile operators)
     void* d_sop = nullptr;
@@ -114,7 +117,7 @@ struct vbx_batch {
         BatchView<R> v;
         v.n_rec = n_rec; v.Sp = Sp; v.Dp = Dp; v.D = D; v.max_iters = max_iters;
         v.ntiles_total = ntiles_total;
-        v.recs = d_recs; v.state = d_state; v.tile_rec = d_tile_rec; v.tile_t0 = d_tile_t0;
+        v.recs = d_recs; v.state = d_state; v.tile_rec = d_tile_rec; v.tile_t0 = d_tile_t0; v.tile_desc = d_tile_desc; v.tile_done = d_tile_done;
         v.phi = d_phi;
         v.rho = (R*)d_rho; v.gamma = (R*)d_gamma; v.bmat = (R*)d_bmat; v.mrow = (R*)d_mrow;
         v.ahat = (R*)d_ahat; v.bhat = (R*)d_bhat; v.alpha = (R*)d_alpha; v.invL = (R*)d_invL;
@@ -216,7 +219,13 @@ template <typename R, int SP> void launch_scan(vbx_batch* b, const BatchView<R>&
     if constexpr (ChunkPostCfg<R, SP>::kFits) {
         if (fused_post) {
             LaunchScope ls(b, VBX_K_CHUNK_POST);
-            if (b->post_mid && v.spt == 1)
+            bool quad = false;
+            if constexpr (ChunkPostQuadCfg<R, SP>::kFits) quad = b->post_kernel == 2 && v.spt == 1 && b->Dp <= ChunkPostQuadCfg<R, SP>::kMaxDp;
+            if (quad) {
+                if constexpr (ChunkPostQuadCfg<R, SP>::kFits)
+                    hipLaunchKernelGGL((chunk_post_quad_kernel<R, SP>), dim3((b->ntiles_total + kQuadTiles - 1) / kQuadTiles),
+                                       dim3(512), 0, st, v);
+            } else if (b->post_kernel && v.spt == 1)
                 hipLaunchKernelGGL((chunk_post_mid_kernel<R, SP>), dim3(b->ntiles_total), dim3(256), 0, st, v);
             else
                 hipLaunchKernelGGL((chunk_post_kernel<R, SP>), dim3(b->ntiles_total), dim3(256), 0, st, v);
@@ -497,7 +506,7 @@ int vbx_device_info(vbx_ctx* ctx, char* name, int cap, int* compute_units, int64
 int vbx_batch_destroy(vbx_batch* b) {
     if (!b) return VBX_OK;
     (void)hipSetDevice(b->ctx->device);
-    void* ptrs[] = {b->d_recs, b->d_state, b->d_tile_rec, b->d_tile_t0, b->d_phi, b->d_sqrt_phi, b->d_gtile,
+    void* ptrs[] = {b->d_recs, b->d_state, b->d_tile_rec, b->d_tile_t0, b->d_tile_desc, b->d_tile_done, b->d_phi, b->d_sqrt_phi, b->d_gtile,
                     b->d_rho, b->d_gamma, b->d_bmat, b->d_mrow, b->d_ahat, b->d_bhat, b->d_alpha, b->d_invL,
                     b->d_bias, b->d_mpart, b->d_npart, b->d_lraw, b->d_emodel, b->d_pi, b->d_epart, b->d_Li,
                     b->d_xstage, b->d_ip, b->d_fw_scale, b->d_bw_scale, b->d_op, b->d_fbound, b->d_gbound,
@@ -563,6 +572,12 @@ int vbx_batch_create(vbx_ctx* ctx, int n_rec, const int64_t* T, const int32_t* S
     }
     b->sum_T = row;
     b->ntiles_total = (int)tile_rec.size();
+    std::vector<int4> tile_desc;
+    for (int t = 0; t < b->ntiles_total; ++t) {
+        const RecDesc& rd = b->recs[tile_rec[t]];
+        tile_desc.push_back(make_int4(tile_rec[t], tile_t0[t], std::min(kTileFrames, rd.T - tile_t0[t]), (int)(rd.row0 + tile_t0[t])));
+    }
+    while (tile_desc.size() % kQuadTiles) tile_desc.push_back(make_int4(0, 0, 0, (int)row));
     const size_t rs = b->rsize;
     const size_t cells = (size_t)b->sum_T * b->Sp;
     int rc = VBX_OK;
@@ -571,13 +586,16 @@ int vbx_batch_create(vbx_ctx* ctx, int n_rec, const int64_t* T, const int32_t* S
     ALLOC(dmalloc(ctx, &b->d_state, n_rec));
     ALLOC(dmalloc(ctx, &b->d_tile_rec, b->ntiles_total));
     ALLOC(dmalloc(ctx, &b->d_tile_t0, b->ntiles_total));
+    const int ntiles_pad = (b->ntiles_total + kQuadTiles - 1) / kQuadTiles * kQuadTiles;
+    ALLOC(dmalloc(ctx, &b->d_tile_desc, ntiles_pad));
+    ALLOC(dmalloc(ctx, &b->d_tile_done, ntiles_pad));
     ALLOC(dmalloc(ctx, &b->d_phi, (size_t)n_rec * b->Dp));
     ALLOC(dmalloc(ctx, &b->d_sqrt_phi, b->Dp));
     ALLOC(dmalloc(ctx, &b->d_gtile, b->ntiles_total));
     // (one tile of zero rows after the last recording: kernels may read whole tiles past its end)
     ALLOC(dmalloc_bytes(ctx, &b->d_rho, ((size_t)b->sum_T + kTileFrames) * b->Dp * rs));
     ALLOC(dmalloc_bytes(ctx, &b->d_gamma, cells * rs));
-    ALLOC(dmalloc_bytes(ctx, &b->d_bmat, cells * rs));
+    ALLOC(dmalloc_bytes(ctx, &b->d_bmat, (cells + (size_t)kTileFrames * b->Sp) * rs));     // (+ one tile, like rho)
     ALLOC(dmalloc_bytes(ctx, &b->d_mrow, (size_t)b->sum_T * rs));
     ALLOC(dmalloc_bytes(ctx, &b->d_alpha, (size_t)n_rec * b->Sp * b->Dp * rs));
     ALLOC(dmalloc_bytes(ctx, &b->d_invL, (size_t)n_rec * b->Sp * b->Dp * rs));
@@ -598,6 +616,9 @@ int vbx_batch_create(vbx_ctx* ctx, int n_rec, const int64_t* T, const int32_t* S
     hipError_t e;
     if ((e = hipMemcpy(b->d_tile_rec, tile_rec.data(), sizeof(int) * tile_rec.size(), hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMemcpy(b->d_tile_t0, tile_t0.data(), sizeof(int) * tile_t0.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(b->d_tile_desc, tile_desc.data(), sizeof(int4) * tile_desc.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemset(b->d_tile_done, 0, sizeof(int) * ntiles_pad)) != hipSuccess ||
+        (e = hipMemset((char*)b->d_bmat + cells * rs, 0, (size_t)kTileFrames * b->Sp * rs)) != hipSuccess ||
         (e = hipMemset(b->d_state, 0, sizeof(RecState) * n_rec)) != hipSuccess ||
         (e = hipMemset(b->d_gamma, 0, cells * rs)) != hipSuccess ||
         (e = hipMemset((char*)b->d_rho + (size_t)b->sum_T * b->Dp * rs, 0, (size_t)kTileFrames * b->Dp * rs)) != hipSuccess ||
@@ -630,8 +651,9 @@ int vbx_batch_set_option(vbx_batch* b, int option, int64_t value) {
             b->fuse = (int)value;
             b->mpart_valid = false;
             return VBX_OK;
-        case VBX_OPT_POST_MID:
-            b->post_mid = value ? 1 : 0;
+        case VBX_OPT_POST_KERNEL:
+            if (value < 0 || value > 2) FAIL(b->ctx, VBX_ERR_INVALID, "VBX_OPT_POST_KERNEL takes 0, 1 or 2");
+            b->post_kernel = (int)value;
             return VBX_OK;
         case VBX_OPT_HALF_CHUNKS:
             b->half_chunks = value ? 1 : 0;
@@ -701,6 +723,7 @@ int set_recording_impl(vbx_batch* b, int rec, const void* X, int x_dtype, const 
     RecState st;
     std::memset(&st, 0, sizeof st);
     HIPCHK(ctx, hipMemcpyAsync(b->d_state + rec, &st, sizeof st, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(b->d_tile_done + rd.tile0, 0, sizeof(int) * rd.ntiles, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // host vectors go out of scope below
     double gsum = 0.0;
     for (double g : gt) gsum += g;

@@ -55,26 +55,28 @@ __global__ __launch_bounds__(256, (ChunkPostMidCfg<R, SP>::kPerCU)) void chunk_p
     __shared__ double red[16];
 
     const int tile = blockIdx.x;
-    const int rec = bt.tile_rec[tile];
-    if (bt.state[rec].done) return;
+    // one scalar load gives every address of the first round of vector loads (tile table of vbx_capi.hip)
+    const int4 td = bt.tile_desc[tile];
+    if (bt.tile_done[tile]) return;
     VBX_CLOCKS_DECL();
     VBX_STAMP();
-    const RecDesc rd = bt.recs[rec];
+    const int rec = td.x, t0 = td.y, len = td.z;
+    const long long trow = td.w;                       // first frame row of the tile
     const int Dp = bt.Dp;
-    const int t0 = bt.tile_t0[tile];
-    const int len = min(kTileFrames, rd.T - t0);
     const int mid = len / 2;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int i16 = lane & 15, g4 = lane >> 4;
     const int so = i16 * NREG;                         // first state of this lane
-    const R lp = (R)rd.lp;
-    const R* __restrict__ rho = bt.rho + rd.row0 * Dp;
+    const double lp_d = bt.recs[rec].lp;               // (scalar loads: in flight next to the b tile)
+    const int n_spk = bt.recs[rec].S;
+    const R lp = (R)lp_d;
+    const R* __restrict__ rho = bt.rho + (trow - t0) * Dp;
 
     stage_to_lds<(kTileFrames * SP / 4 + 255) / 256>(reinterpret_cast<R4*>(bl),
-                                                     reinterpret_cast<const R4*>(bt.bmat + (rd.row0 + t0) * SP),
+                                                     reinterpret_cast<const R4*>(bt.bmat + trow * SP),
                                                      len * SP / 4, tid, 256);
     if (tid < SP)
-        c_l[tid] = (tid < rd.S) ? (R)((1.0 - rd.lp) * bt.pi[(long long)rec * SP + tid] + 1e-8) : (R)0;
+        c_l[tid] = (tid < n_spk) ? (R)((1.0 - lp_d) * bt.pi[(long long)rec * SP + tid] + 1e-8) : (R)0;
     const bool chunk0 = (t0 == 0);
     __syncthreads();
     VBX_STAMP();
@@ -146,6 +148,7 @@ __global__ __launch_bounds__(256, (ChunkPostMidCfg<R, SP>::kPerCU)) void chunk_p
     };
     auto b_renorm = [&]() {
         const int e = rescale_exponent(q);
+        q = scale2(q, -e);                                   // (x_{mid-1} and its q wait in registers for the barrier)
 #pragma unroll
         for (int r = 0; r < NREG; ++r) x[r] = scale2(x[r], -e);
     };
@@ -167,7 +170,9 @@ __global__ __launch_bounds__(256, (ChunkPostMidCfg<R, SP>::kPerCU)) void chunk_p
             f_store(0);                                      // (row 0 of bl if len == 1: b_0 is not needed again)
             ff = 1;
         }
+#ifndef VBX_EXPERIMENT_SKIP_RERUN
         f_run(max(mid, ff));                                 // rows < mid -> afh
+#endif
     } else if (wave == 1) {
         const R* __restrict__ bnd = bt.gbound + (long long)tile * SP + so;
         R part = 0;
@@ -188,6 +193,9 @@ __global__ __launch_bounds__(256, (ChunkPostMidCfg<R, SP>::kPerCU)) void chunk_p
         const int stop = max(mid, 1);
         R cur[4][NREG], nxt[4][NREG];
         if (fb - 3 >= stop) load_rows(cur, fb, -1);
+#ifdef VBX_EXPERIMENT_SKIP_RERUN
+        fb = 0;
+#endif
         while (fb - 3 >= stop) {                             // a block of four rows fb .. fb-3, all >= stop
             const bool last_block = fb - 4 < stop;           // its last output is x_{stop-1}
             if (fb - 7 >= stop) load_rows(nxt, fb - 4, -1);
@@ -209,7 +217,9 @@ __global__ __launch_bounds__(256, (ChunkPostMidCfg<R, SP>::kPerCU)) void chunk_p
     __syncthreads();                                         // midpoint: rows >= mid of b are consumed by the backward
                                                              // wave, rows < mid by the forward wave
     if (wave == 0) {
+#ifndef VBX_EXPERIMENT_SKIP_RERUN
         f_run(len);                                          // rows >= mid -> bl (over b_f, after reading it)
+#endif
         if (lane == 0) {
             tl_sig[0] = sig;
             tl_sig[1] = chunk0 ? (R)1 : sig_in;
@@ -262,7 +272,7 @@ __global__ __launch_bounds__(256, (ChunkPostMidCfg<R, SP>::kPerCU)) void chunk_p
     // hold the a or x another frame's pass 1 still needs.
     {
         constexpr int NIT = kTileFrames / 16;
-        R* __restrict__ G = bt.gamma + (rd.row0 + t0) * SP;
+        R* __restrict__ G = bt.gamma + trow * SP;
         R gam[NIT][NREG], ent[NREG];
 #pragma unroll
         for (int r = 0; r < NREG; ++r) ent[r] = 0;
@@ -300,13 +310,13 @@ __global__ __launch_bounds__(256, (ChunkPostMidCfg<R, SP>::kPerCU)) void chunk_p
             if (g4 == 0) ent_w[wave][so + r] = e;
         }
         double mpartial = 0.0;                             // this chunk's share of the total log-likelihood (VBx.py:173)
-        if (tid < len) mpartial = (double)bt.mrow[rd.row0 + t0 + tid];
+        if (tid < len) mpartial = (double)bt.mrow[trow + tid];
         if (tid == 128)
             mpartial += log((double)tl_sig[0]) - log((double)tl_sig[1]) + (double)tl_expo * 0.69314718055994530942;
         mpartial = block_sum(mpartial, red);               // (its barriers also end pass 1)
         if (tid < SP) {
             const double e = (ent_w[0][tid] + ent_w[1][tid]) + (ent_w[2][tid] + ent_w[3][tid]);
-            bt.epart[(long long)tile * SP + tid] = tid < rd.S ? e : 0.0;
+            bt.epart[(long long)tile * SP + tid] = tid < n_spk ? e : 0.0;
         }
         if (tid == 0) bt.tllpart[tile] = mpartial;
 #pragma unroll

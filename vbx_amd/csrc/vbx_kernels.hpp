@@ -44,6 +44,8 @@ template <typename R> struct BatchView {
     RecState* state;
     const int* tile_rec;   // [ntiles_total]
     const int* tile_t0;    // [ntiles_total]
+    const int4* tile_desc; // [ntiles_total rounded up to 4] {recording, t0, frames, first row}; frames = 0 behind the last tile
+    int* tile_done;        // [same] 1 once the tile's recording has converged (written by iter_fin)
     const double* phi;     // [n_rec][Dp]
     R* rho;
     R* gamma;
@@ -604,6 +606,7 @@ template <typename R>
 __global__ __launch_bounds__(256) void iter_fin_kernel(BatchView<R> bt) {
     __shared__ double lds[16];
     __shared__ double ent_sh[256];
+    __shared__ int done_sh;
     const int rec = blockIdx.x;
     RecState st = bt.state[rec];
     if (st.done) return;
@@ -650,7 +653,11 @@ __global__ __launch_bounds__(256) void iter_fin_kernel(BatchView<R> bt) {
         st.elbo_prev = elbo;
         st.n_iters = it + 1;
         bt.state[rec] = st;
+        done_sh = st.done;
     }
+    __syncthreads();
+    if (done_sh)
+        for (int tl = threadIdx.x; tl < rd.ntiles; tl += 256) bt.tile_done[rd.tile0 + tl] = 1;
 }
 
 }  // namespace vbx
