@@ -6,6 +6,7 @@
 //     (VBx.py:96) -- the forward / backward vectors never leave the CU.
 //
 #pragma once
+#include <type_traits>
 #include "vbx_scan.hpp"
 
 // Build with -DVBX_PHASE_CLOCKS to make one workgroup in a thousand print the shader-clock cycles it spent
@@ -516,11 +517,17 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)si
                 const int lo = bt.spt == 2 ? half * kScanHalf : 0;
                 const int hi = bt.spt == 2 ? min(len, lo + kScanHalf) : len;
                 const int col = lt / PH, part = lt % PH, j0 = part * NR;
+                // With lp > 0 the recursion runs on z_f = x_f / lp^(transitions so far):
+                //     x <- b (lp x + c sum(x))     becomes     z <- b (z + (c / lp) sum(z)),
+                // one FMA and one product per state instead of three operations; lp^(transitions) goes into the
+                // column's mantissa and exponent at the end.  lp == 0 (or subnormally small) keeps the plain form.
+                const bool scaled = rd.lp >= 0x1p-20;
                 R x[NR], c[NR];
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
                     x[r] = (j0 + r == col) ? (R)1 : (R)0;
-                    c[r] = (j0 + r < rd.S) ? (R)((1.0 - rd.lp) * bt.pi[(long long)rec * SP + j0 + r] + 1e-8) : (R)0;
+                    const double cj = (1.0 - rd.lp) * bt.pi[(long long)rec * SP + j0 + r] + 1e-8;
+                    c[r] = (j0 + r < rd.S) ? (R)(scaled ? cj / rd.lp : cj) : (R)0;
                 }
                 int expo = 0, step = lo;
                 if (t0 + lo == 0) {          // frame 0 of the recording: x <- b_0 * x (VBx.py:163, no transition)
@@ -528,35 +535,86 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)si
                     for (int r = 0; r < NR; ++r) x[r] *= btile[j0 + r];
                     step = 1;
                 }
-                auto colsum = [&]() {
-                    R sm = x[0];
+                const int transitions = hi - step;
+                auto colsum = [&]() {        // pairwise: packed adds
+                    R v[NR];
 #pragma unroll
-                    for (int r = 1; r < NR; ++r) sm += x[r];
-                    return column_sum<PH>(sm);
+                    for (int r = 0; r < NR; ++r) v[r] = x[r];
+#pragma unroll
+                    for (int w = NR / 2; w >= 1; w >>= 1)
+#pragma unroll
+                        for (int r = 0; r < w; ++r) v[r] += v[r + w];
+                    return column_sum<PH>(v[0]);
                 };
-                auto frame = [&](int f, R sig) {
+                auto recursion = [&](auto scaled_tag) {
+                    // written on pairs of states: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 do two per issue slot
+                    using R2 = typename Vec<R>::v2;
+                    constexpr int NP = NR / 2;
+                    static_assert(NR % 4 == 0, "operator lanes hold a multiple of four states");
+                    R2 x2[NP], c2[NP];
 #pragma unroll
-                    for (int r = 0; r < NR; ++r) x[r] = btile[f * SP + j0 + r] * (lp * x[r] + c[r] * sig);
+                    for (int p = 0; p < NP; ++p) {
+                        x2[p] = R2{x[2 * p], x[2 * p + 1]};
+                        c2[p] = R2{c[2 * p], c[2 * p + 1]};
+                    }
+                    const R2 lp2 = R2{lp, lp};
+                    auto colsum2 = [&]() {
+                        R2 v[NP];
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) v[p] = x2[p];
+#pragma unroll
+                        for (int w = NP / 2; w >= 1; w >>= 1)
+#pragma unroll
+                            for (int p = 0; p < w; ++p) v[p] += v[p + w];
+                        return column_sum<PH>(v[0].x + v[0].y);
+                    };
+                    auto frame = [&](int f, R sig) {
+                        const R2 sig2 = R2{sig, sig};
+                        const R* row = btile + f * SP + j0;
+#pragma unroll
+                        for (int q = 0; q < NR / 4; ++q) {
+                            const R4 b4 = *reinterpret_cast<const R4*>(row + 4 * q);
+                            const R2 b0 = R2{b4.x, b4.y}, b1 = R2{b4.z, b4.w};
+                            if (decltype(scaled_tag)::value) {
+                                x2[2 * q] = b0 * (c2[2 * q] * sig2 + x2[2 * q]);
+                                x2[2 * q + 1] = b1 * (c2[2 * q + 1] * sig2 + x2[2 * q + 1]);
+                            } else {
+                                x2[2 * q] = b0 * (lp2 * x2[2 * q] + c2[2 * q] * sig2);
+                                x2[2 * q + 1] = b1 * (lp2 * x2[2 * q + 1] + c2[2 * q + 1] * sig2);
+                            }
+                        }
+                    };
+                    auto renorm = [&]() {            // column sum back to [0.5, 1): one exact product per pair
+                        R sig = colsum2();
+                        const int e = rescale_exponent(sig);
+                        expo += e;
+                        const R sc = scale2((R)1, -e);
+                        const R2 sc2 = R2{sc, sc};
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) x2[p] *= sc2;
+                        return sig * sc;
+                    };
+                    for (; step + 4 <= hi; step += 4) {
+                        frame(step, renorm());
+#pragma unroll
+                        for (int k = 1; k < 4; ++k) frame(step + k, colsum2());
+                    }
+                    for (; step < hi; ++step) frame(step, renorm());
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        x[2 * p] = x2[p].x;
+                        x[2 * p + 1] = x2[p].y;
+                    }
                 };
-                for (; step + 4 <= hi; step += 4) {
-                    R sig = colsum();
-                    const int e = rescale_exponent(sig);
-                    expo += e;
-                    sig = scale2(sig, -e);
+                if (scaled) {
+                    recursion(std::true_type{});
+                    const double l2 = (double)transitions * log2(rd.lp), fl = floor(l2);
+                    const R mant = (R)exp2(l2 - fl);             // lp^transitions = mant * 2^fl, mant in [1, 2)
+                    expo += (int)fl;
 #pragma unroll
-                    for (int r = 0; r < NR; ++r) x[r] = scale2(x[r], -e);
-                    frame(step, sig);
-#pragma unroll
-                    for (int k = 1; k < 4; ++k) frame(step + k, colsum());
-                }
-                for (; step < hi; ++step) {
-                    R sig = colsum();
-                    const int e = rescale_exponent(sig);
-                    expo += e;
-                    sig = scale2(sig, -e);
-#pragma unroll
-                    for (int r = 0; r < NR; ++r) x[r] = scale2(x[r], -e);
-                    frame(step, sig);
+                    for (int r = 0; r < NR; ++r) x[r] *= mant;
+                } else {
+                    recursion(std::false_type{});
                 }
                 {   // final power-of-two normalisation: column sums end in [0.5, 1)
                     const R sig = colsum();
