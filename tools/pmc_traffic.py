@@ -17,7 +17,9 @@ import sys
 
 def short(name):
     m = re.search(r'vbx::(\w+?)(?:_kernel)?<', name)
-    return m.group(1) if m else name[:60]
+    n = m.group(1) if m else name
+    # the variants of one kernel class share its name (include/vbx_hip.h: VBX_K_CHUNK_POST)
+    return re.sub(r'^chunk_post_(mid|quad)$', 'chunk_post', n)
 
 
 def per_kernel(path, counter):

@@ -384,9 +384,11 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)si
     // slots per frame (the column sum needs log2(PH) DPP stages with their wait states): 72 / 46 / 39 slots per
     // chunk-frame for PH = 8 / 4 / 2 at SP = 32, but also fewer wavefronts to hide each other's latency.
     // Measured on 64 recordings of T = 10 000: 171 / 163 / 176 us per launch, so PH = 4 (two wavefronts build
-    // the operator, the other two retire after phase 1).
+    // the operator, the other two retire after phase 1).  With the packed two-operation frame of phase 2,
+    // PH = 8 and PH = 4 measure the same (346 vs 344-349 us per iteration).
     constexpr int kOperatorLanes = 4;
-    constexpr int PH = (SP * kOperatorLanes <= 256) ? kOperatorLanes : 256 / SP, NR = SP / PH;
+    constexpr int kLanesWanted = SP / 4 < kOperatorLanes ? SP / 4 : kOperatorLanes;     // a lane keeps >= 4 states
+    constexpr int PH = (SP * kLanesWanted <= 256) ? kLanesWanted : 256 / SP, NR = SP / PH;
     constexpr int AST = kAlphaSlice + 4;               // padded row of the alpha slice: conflict-free fragment reads
     // one LDS region, two lives: the alpha slice during the MFMA pass, then b of the chunk
     constexpr int kLds = kTileFrames * SP > SP * AST ? kTileFrames * SP : SP * AST;
