@@ -202,6 +202,26 @@ int vbx_scores_upload(vbx_ctx* ctx, int64_t n, const double* s, vbx_scores** out
 int64_t vbx_scores_count(const vbx_scores* sc);
 /* Copy count scores starting at offset to the host (out [count]). */
 int vbx_scores_get(vbx_scores* sc, int64_t offset, int64_t count, double* out);
+/* The strict upper triangle of scale * S, row by row -- the vector form scipy.spatial.distance.squareform(m,
+ * checks=False) gives -- of a T x T score matrix: vbhmm.py:139 `scr_mx = squareform(-scr_mx, checks=False)` is
+ * scale = -1.  out: [T (T - 1) / 2]. */
+int vbx_scores_get_condensed(vbx_scores* sc, int64_t T, double scale, double* out);
+
+/* Average-linkage clustering of n observations from their condensed distance vector [n (n - 1) / 2] (host code;
+ * nearest-neighbour chain, see vbx_linkage.hpp for why it is not a kernel): vbhmm.py:140-141
+ * `fastcluster.linkage(scr_mx, method='average')`.  Z: [n - 1][4] = (cluster a, cluster b, distance, members), the
+ * linkage matrix of scipy.cluster.hierarchy / fastcluster, bit for bit SciPy's.  Pure function, safe to call from
+ * several threads at once (one recording per thread); needs no vbx_ctx. */
+int vbx_linkage_average(int64_t n, const double* condensed, double* Z);
+/* Flat clusters of the linkage matrix Z cut at cophenetic distance t: vbhmm.py:145-146 `fcluster(lin_mat, t,
+ * criterion='distance')`.  labels: [n], numbered from 1 in SciPy's order (depth-first from the root). */
+int vbx_fcluster_distance(int64_t n, const double* Z, double t, int32_t* labels);
+
+/* Index of a binary Kaldi vector archive held in memory (vbhmm.py:117 `kaldi_io.read_vec_flt_ark`): offsets and
+ * lengths of the key and of the data of every entry ('FV ' float32 / 'DV ' float64 vectors).  Returns the number
+ * of entries; -1: not a well-formed binary vector archive; -2: more than `cap` entries. */
+int64_t vbx_ark_index(const void* buf, int64_t len, int64_t cap, int64_t* key_off, int32_t* key_len, int64_t* data_off,
+                      int32_t* dim, int32_t* elem_size);
 /* Two-Gaussian shared-variance EM over all the scores: threshold, and (llr != NULL) the linearly calibrated
  * log-odds of every score, [vbx_scores_count]. */
 int vbx_scores_two_gmm_calib(vbx_scores* sc, int32_t niters, double* threshold, double* llr);

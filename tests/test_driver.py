@@ -1,0 +1,357 @@
+"""The batched diarization driver ``vbx_amd.vbhmm`` and the on-disk formats either
+side of the path (``vbx_amd.kaldi_formats``, ``vbx_amd.h5_minimal``).
+
+Golden: tests/golden/driver_split3.npz -- RTTM files written by the UNCHANGED reference driver (its own VBx.py) for
+a three-recording archive cut from the reference's example x-vectors (tests/golden/make_golden_driver.py).  The
+tests rewrite the archive, the segments file and the model files with this repository's writers, run the driver and
+compare the RTTM files byte for byte:
+
+  * ``-m "not gpu"``: score stage and VB-HMM replaced by the CPU oracles (injected; the product has no fallback)
+    -- formats, grouping, projections, AHC, batching, label post-processing, RTTM text; also on two ``gloo`` ranks;
+  * ``-m gpu``: the product path end to end through ``vbx_amd.vbhmm.main``.
+"""
+import io
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(REPO, 'tests', 'golden', 'driver_split3.npz')
+REF = os.environ.get('VBX_REFERENCE', '/root/reference')
+RECS = ('recA', 'recB', 'recC')
+
+
+def _write_inputs(tmp):
+    """The golden archive as files: Kaldi ark + segments + Kaldi PLDA + transform (npz: no HDF5 writer here)."""
+    from vbx_amd import kaldi_formats as kf
+    g = np.load(GOLD)
+    tmp = str(tmp)
+    paths = dict(ark=os.path.join(tmp, 'split3.ark'), seg=os.path.join(tmp, 'split3.seg'),
+                 plda=os.path.join(tmp, 'plda'), transform=os.path.join(tmp, 'transform.npz'),
+                 out=os.path.join(tmp, 'rttm'))
+    kf.write_vec_flt_ark(paths['ark'], zip(g['keys'].tolist(), g['xvecs']))
+    kf.write_segments(paths['seg'], [(k, r, s, e) for k, r, (s, e) in zip(g['keys'].tolist(), g['recs'].tolist(), g['segments'])])
+    kf.write_plda(paths['plda'], g['plda_mean'], g['plda_trans'], g['plda_psi'])
+    np.savez(paths['transform'], mean1=g['mean1'], mean2=g['mean2'], lda=g['lda'])
+    return paths
+
+
+def _argv(paths, extra=()):
+    return ['--init', 'AHC+VB', '--out-rttm-dir', paths['out'], '--xvec-ark-file', paths['ark'],
+            '--segments-file', paths['seg'], '--xvec-transform', paths['transform'], '--plda-file', paths['plda'],
+            '--threshold', '-0.015', '--lda-dim', '128', '--Fa', '0.3', '--Fb', '17', '--loopP', '0.99',
+            '--output-2nd', 'True'] + list(extra)
+
+
+def _check_rttm(paths, recs=RECS):
+    g = np.load(GOLD)
+    for rec in recs:
+        assert open(os.path.join(paths['out'], rec + '.rttm'), 'rb').read() == g['rttm_' + rec].tobytes(), rec
+        assert open(os.path.join(paths['out'] + '2nd', rec + '.rttm'), 'rb').read() == g['rttm2_' + rec].tobytes(), rec
+
+
+def _oracle_batch(items, maxIters, epsilon, **hyper):
+    from oracle import vbx_oracle                               # checker standing in for the GPU
+    return [vbx_oracle.VBx(it['X'], it['Phi'], pi=it['pi'], gamma=it['gamma'], maxIters=maxIters, epsilon=epsilon,
+                           **hyper) for it in items]
+
+
+def _oracle_scores(x):
+    from oracle import ahc_oracle
+    m = ahc_oracle.cos_similarity(x)
+    thr, _ = ahc_oracle.twoGMMcalib_lin(m.ravel())
+    from scipy.spatial.distance import squareform
+    return squareform(-m, checks=False), float(thr)
+
+
+# ---- formats ----------------------------------------------------------------------------------------------------
+def test_vector_archive_round_trip_binary_and_text(tmp_path):
+    from vbx_amd import kaldi_formats as kf
+    rng = np.random.default_rng(0)
+    items = [(f'rec{k // 3}_{k:04d}-a', rng.standard_normal(7 + k).astype(np.float32)) for k in range(6)]
+    for dtype in (np.float32, np.float64):
+        p = str(tmp_path / f'v_{np.dtype(dtype).name}.ark')
+        kf.write_vec_flt_ark(p, items, dtype=dtype)
+        back = list(kf.read_vec_flt_ark(p))
+        assert [k for k, _ in back] == [k for k, _ in items]
+        for (_, a), (_, b) in zip(items, back):
+            assert b.dtype == np.dtype(dtype) and np.array_equal(a.astype(dtype), b)
+    # Kaldi text archive: 'key  [ v v v ]\n'
+    p = str(tmp_path / 't.ark')
+    with open(p, 'w') as fd:
+        fd.write('utt_1  [ 1.5 -2 3e-1 ]\nutt_2  [ ]\nutt_3  [ 7 ]\n')
+    back = list(kf.read_vec_flt_ark(p))
+    assert [k for k, _ in back] == ['utt_1', 'utt_2', 'utt_3']
+    assert np.allclose(back[0][1], [1.5, -2, 0.3]) and back[1][1].size == 0 and np.allclose(back[2][1], [7])
+    with open(p, 'wb') as fd:
+        fd.write(b'utt_1 \x00BXV \x04\x01\x00\x00\x00')
+    with pytest.raises(ValueError):
+        list(kf.read_vec_flt_ark(p))
+
+
+def test_plda_round_trip_and_text_form(tmp_path):
+    from vbx_amd import kaldi_formats as kf
+    rng = np.random.default_rng(1)
+    mean, trans, psi = rng.standard_normal(5), rng.standard_normal((5, 5)), rng.uniform(0.5, 6, 5)
+    for dtype in (np.float32, np.float64):
+        p = str(tmp_path / f'plda_{np.dtype(dtype).name}')
+        kf.write_plda(p, mean, trans, psi, dtype=dtype)
+        m, t, s = kf.read_plda(p)
+        assert t.shape == (5, 5) and m.dtype == np.dtype(dtype)
+        assert np.array_equal(m, mean.astype(dtype)) and np.array_equal(t, trans.astype(dtype)) and np.array_equal(s, psi.astype(dtype))
+    p = str(tmp_path / 'plda_text')
+    with open(p, 'w') as fd:          # what `ivector-copy-plda --binary=false` prints
+        fd.write('<Plda>  [ 1 2 ]\n [\n  1 0.5 \n  0 2 ]\n [ 3 4 ]\n</Plda> ')
+    m, t, s = kf.read_plda(p)
+    assert np.array_equal(m, [1, 2]) and np.array_equal(t, [[1, 0.5], [0, 2]]) and np.array_equal(s, [3, 4])
+    with open(p, 'wb') as fd:
+        fd.write(b'\x00B<Nnet> ')
+    with pytest.raises(ValueError):
+        kf.read_plda(p)
+
+
+def test_segments_rttm_and_label_merging(tmp_path):
+    from vbx_amd import kaldi_formats as kf
+    from vbx_amd.vbhmm import merge_adjacent_labels
+    p = str(tmp_path / 'seg')
+    kf.write_segments(p, [('a_0', 'a', 0.0, 1.44), ('a_1', 'a', 0.24, 1.68), ('b_0', 'b', 0.0, 1.0)])
+    d = kf.read_xvector_timing_dict(p)
+    assert list(d) == ['a', 'b'] and d['a'][0].tolist() == ['a_0', 'a_1'] and np.array_equal(d['a'][1], [[0, 1.44], [0.24, 1.68]])
+    # same label: overlapping and touching segments merge; different labels: the overlap is split in the middle
+    starts, ends, labels = merge_adjacent_labels(np.array([0.0, 0.24, 0.48, 2.0, 2.5]), np.array([1.44, 1.68, 1.92, 2.5, 3.0]),
+                                                 np.array([3, 3, 1, 1, 1]))
+    assert labels.tolist() == [3, 1, 1] and np.allclose(starts, [0.0, 1.08, 2.0]) and np.allclose(ends, [1.08, 1.92, 3.0])
+    buf = io.StringIO()
+    kf.write_rttm(buf, 'rec', labels, starts, ends)
+    assert buf.getvalue().splitlines()[0] == 'SPEAKER rec 1 0.000000 1.080000 <NA> <NA> 4 <NA> <NA>'
+    q = str(tmp_path / 'r.rttm')
+    open(q, 'w').write(buf.getvalue())
+    assert kf.read_rttm(q)[1] == ('rec', 1.08, 0.84, '2')
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, 'VBx', 'models')), reason='reference checkout not present')
+def test_readers_on_the_reference_files():
+    """The reference's own model files and example archive (authoring container): the HDF5 subset reader against
+    the known layout of transform.h5 (three contiguous float64 datasets), the PLDA and archive readers against the
+    values SURVEY.md App. B quotes."""
+    from vbx_amd import kaldi_formats as kf
+    from vbx_amd.h5_minimal import read_datasets
+    path = f'{REF}/VBx/models/ResNet101_16kHz/transform.h5'
+    d = read_datasets(path)
+    raw = open(path, 'rb').read()
+    for name, (off, shape) in {'mean1': (2048, (256,)), 'mean2': (4096, (128,)), 'lda': (5120, (256, 128))}.items():
+        assert np.array_equal(d[name], np.frombuffer(raw, '<f8', int(np.prod(shape)), off).reshape(shape))
+    with pytest.raises(KeyError):
+        read_datasets(path, ('nope',))
+    mean, trans, psi = kf.read_plda(f'{REF}/VBx/models/ResNet101_16kHz/plda')
+    assert mean.shape == (128,) and trans.shape == (128, 128) and psi.shape == (128,)
+    items = list(kf.read_vec_flt_ark(f'{REF}/exp/ES2005a.ark'))
+    assert len(items) == 1025 and items[0][0] == 'ES2005a_0000-00000000-00000144' and items[0][1].shape == (256,)
+    g = np.load(GOLD)
+    assert np.array_equal(g['xvecs'], np.array([v for _, v in items])) and np.array_equal(g['plda_psi'], psi)
+
+
+def test_h5_reader_rejects_what_it_does_not_handle(tmp_path):
+    from vbx_amd.h5_minimal import read_datasets
+    p = str(tmp_path / 'x.h5')
+    open(p, 'wb').write(b'not hdf5 at all')
+    with pytest.raises(ValueError):
+        read_datasets(p)
+    open(p, 'wb').write(b'\x89HDF\r\n\x1a\n' + bytes([2]) + bytes(64))      # superblock version 2
+    with pytest.raises(ValueError, match='superblock version 2'):
+        read_datasets(p)
+
+
+# ---- the driver ---------------------------------------------------------------------------------------------------
+def test_driver_reproduces_the_reference_rttm_with_oracle_stages(tmp_path, capsys):
+    from vbx_amd import vbhmm
+    paths = _write_inputs(tmp_path)
+    args = vbhmm.build_parser().parse_args(_argv(paths))
+    state, timing = vbhmm.diarize(args, run_batch=_oracle_batch, score_stage=_oracle_scores)
+    assert capsys.readouterr().out.split() == list(RECS)                 # vbhmm.py:121 prints each recording
+    assert list(state) == list(RECS) and timing['recordings'] == 3 and timing['xvectors'] == 1025
+    assert all(st['n_iters'] >= 2 for st in state.values())
+    _check_rttm(paths)
+
+
+def test_driver_ahc_only_and_argument_checks(tmp_path):
+    from vbx_amd import vbhmm
+    paths = _write_inputs(tmp_path)
+    argv = _argv(paths)
+    argv[1] = 'AHC'
+    args = vbhmm.build_parser().parse_args(argv)
+    called = []
+    state, _ = vbhmm.diarize(args, run_batch=lambda *a, **k: called.append(1), score_stage=_oracle_scores, log=lambda *_: None)
+    assert not called and all(st['n_iters'] == 0 and st['labels2nd'] is None for st in state.values())
+    assert sorted(os.listdir(paths['out'])) == [r + '.rttm' for r in RECS] and not os.path.exists(paths['out'] + '2nd')
+    args.loopP = 1.5
+    with pytest.raises(AssertionError):                                    # vbhmm.py:103
+        vbhmm.diarize(args, run_batch=_oracle_batch, score_stage=_oracle_scores, log=lambda *_: None)
+    with pytest.raises(SystemExit):
+        vbhmm.build_parser().parse_args(['--init', 'VB'])
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import torch.distributed as dist
+    from vbx_amd import vbhmm
+    import test_driver as td
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+    try:
+        paths = {k: os.path.join(tmp, v) for k, v in dict(ark='split3.ark', seg='split3.seg', plda='plda',
+                                                          transform='transform.npz', out='rttm').items()}
+        args = vbhmm.build_parser().parse_args(td._argv(paths))
+        state, timing = vbhmm.diarize(args, run_batch=td._oracle_batch, score_stage=td._oracle_scores, log=lambda *_: None)
+        assert (timing['rank'], timing['world']) == (rank, world)
+        with open(os.path.join(tmp, f'rank{rank}.txt'), 'w') as fd:
+            fd.write(' '.join(state))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_driver_on_two_gloo_ranks_writes_every_recording_once(tmp_path):
+    """One process per GPU under torchrun: recordings are dealt to the ranks (longest first, by T^2), each rank
+    writes the RTTM files of its own recordings, nothing is exchanged."""
+    import torch.multiprocessing as mp
+    paths = _write_inputs(tmp_path)
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    owned = [open(tmp_path / f'rank{r}.txt').read().split() for r in range(world)]
+    assert sorted(owned[0] + owned[1]) == list(RECS) and owned[0] and owned[1]
+    assert owned[0] == ['recA']                       # 400^2 > 325^2 + 300^2 is false: LPT gives rank 0 recA, rank 1 recC + recB
+    _check_rttm(paths)
+
+
+@pytest.mark.gpu
+def test_driver_reproduces_the_reference_rttm_on_the_gpu(tmp_path, capsys):
+    """Product path: GPU score stage + one fp64 ``vbx_batch`` for the three recordings, through the command line."""
+    from vbx_amd import vbhmm
+    paths = _write_inputs(tmp_path)
+    assert vbhmm.main(_argv(paths, ['--timing'])) == 0
+    out = capsys.readouterr().out.split('\n')
+    assert out[:3] == list(RECS)
+    _check_rttm(paths)
+    # fp32 kernels: same segments and speakers on this example (labels are arg-max decisions)
+    paths32 = dict(paths, out=os.path.join(str(tmp_path), 'rttm32'))
+    assert vbhmm.main(_argv(paths32, ['--precision', 'fp32'])) == 0
+    _check_rttm(paths32)
+
+
+# ---- native average linkage (host code of the library: no GPU needed) -------------------------------------------
+@pytest.mark.parametrize('case', ['cosine', 'ties', 'negative_ties', 'zeros', 'es2005a'])
+def test_native_average_linkage_is_scipy_linkage_bit_for_bit(case):
+    """vbx_linkage_average == scipy.cluster.hierarchy.linkage(y, 'average') (the stand-in for fastcluster.linkage of
+    vbhmm.py:140-141; SciPy 1.15 `nn_chain` + `label`): same merges, same cluster numbering, same distances to the
+    last bit, sign of zero included -- also with massive ties, where the chain's tie rules decide the tree."""
+    from scipy.cluster.hierarchy import linkage
+    from vbx_amd import _capi
+    rng = np.random.default_rng(5)
+    ys = []
+    if case == 'cosine':
+        for n in (2, 3, 4, 9, 64, 257, 700):
+            x = rng.standard_normal((n, 12))
+            x /= np.linalg.norm(x, axis=1, keepdims=True)
+            ys.append(np.ascontiguousarray(-(x @ x.T)[np.triu_indices(n, 1)]))
+    elif case == 'ties':
+        ys = [rng.integers(0, 4, size=n * (n - 1) // 2).astype(float) for n in (5, 6, 33, 150, 301)]
+    elif case == 'negative_ties':
+        ys = [-rng.integers(0, 3, size=n * (n - 1) // 2).astype(float) for n in (5, 40, 300)]       # has -0.0
+    elif case == 'zeros':
+        ys = [np.zeros(n * (n - 1) // 2) for n in (2, 10, 65)]
+    else:
+        g = np.load(GOLD)                                     # the example recording's first 400 x-vectors, raw
+        x = g['xvecs'][:400].astype(np.float64)
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+        ys = [np.ascontiguousarray(-(x @ x.T)[np.triu_indices(400, 1)])]
+    for y in ys:
+        want = linkage(y, method='average')
+        got = _capi.linkage_average(y)
+        assert got.shape == want.shape and np.array_equal(got, want), (case, len(want) + 1)
+        assert np.array_equal(np.signbit(got), np.signbit(want))
+    with pytest.raises(ValueError):
+        _capi.linkage_average(np.zeros(4))                    # 4 is not n (n - 1) / 2
+    with pytest.raises(ValueError):
+        _capi.linkage_average(np.zeros((3, 3)))
+
+
+def test_native_linkage_runs_concurrently_from_threads():
+    """The entry point keeps no global state and ctypes drops the interpreter lock around it: four recordings
+    clustered on four threads give the results of four calls in a row."""
+    from concurrent.futures import ThreadPoolExecutor
+    from vbx_amd import _capi
+    rng = np.random.default_rng(6)
+    ys = []
+    for n in (300, 301, 450, 200):
+        x = rng.standard_normal((n, 8))
+        ys.append(np.ascontiguousarray(-(x @ x.T)[np.triu_indices(n, 1)]))
+    serial = [_capi.linkage_average(y) for y in ys]
+    with ThreadPoolExecutor(4) as pool:
+        threaded = list(pool.map(_capi.linkage_average, ys * 3))
+    for k, z in enumerate(threaded):
+        assert np.array_equal(z, serial[k % 4])
+
+
+def test_native_distance_cut_is_scipy_fcluster():
+    """vbx_fcluster_distance == scipy.cluster.hierarchy.fcluster(Z, t, criterion='distance') (vbhmm.py:145-146): same
+    members, same numbering, for cuts below the first merge, above the last, at exact merge distances and with ties."""
+    from scipy.cluster.hierarchy import fcluster, linkage
+    from vbx_amd import _capi
+    rng = np.random.default_rng(8)
+    for n in (2, 3, 5, 17, 100, 401):
+        x = rng.standard_normal((n, 8))
+        Z = _capi.linkage_average(np.ascontiguousarray(-(x @ x.T)[np.triu_indices(n, 1)]))
+        Z[:, 2] += abs(Z[:, 2].min())                           # vbhmm.py:143-144
+        for t in list(np.quantile(Z[:, 2], [0, 0.1, 0.5, 0.9, 1.0])) + [-1.0, 1e9] + list(Z[::7, 2]):
+            got = _capi.fcluster_distance(Z, t)
+            assert got.dtype == np.int32 and np.array_equal(got, fcluster(Z, t, criterion='distance')), (n, t)
+    Z = linkage(rng.integers(0, 3, size=60 * 59 // 2).astype(float), 'average')
+    for t in (0, 0.5, 1, 1.5, 2, 3):
+        assert np.array_equal(_capi.fcluster_distance(Z, t), fcluster(Z, t, criterion='distance')), t
+    with pytest.raises(_capi.VbxError):                          # child id out of range
+        _capi.fcluster_distance(np.array([[0.0, 5.0, 1.0, 2.0], [1.0, 2.0, 2.0, 3.0]]), 1.0)
+    with pytest.raises(ValueError):
+        _capi.fcluster_distance(np.zeros((3, 3)), 1.0)
+
+
+def test_grouped_archive_reader_equals_the_entry_by_entry_reader(tmp_path):
+    """read_vec_flt_ark_grouped (native index + one gather per recording) == itertools.groupby over read_vec_flt_ark
+    (vbhmm.py:117-123), for float32 and float64 archives, keys of different lengths, a one-vector recording; a text
+    archive takes the fallback; a truncated archive is refused."""
+    import itertools
+    from vbx_amd import kaldi_formats as kf
+    rng = np.random.default_rng(9)
+    items = []
+    for rec, n in (('meeting-A', 5), ('b', 1), ('rec_with_under_scores', 7), ('NA', 2)):
+        items += [(f'{rec}_{k:03d}-x', rng.standard_normal(16).astype(np.float32)) for k in range(n)]
+    for dtype in (np.float32, np.float64):
+        p = str(tmp_path / f'g_{np.dtype(dtype).name}.ark')
+        kf.write_vec_flt_ark(p, items, dtype=dtype)
+        got = kf.read_vec_flt_ark_grouped(p)
+        want = [(name, list(g)) for name, g in itertools.groupby(kf.read_vec_flt_ark(p), lambda e: e[0].rsplit('_', 1)[0])]
+        assert [g[0] for g in got] == [w[0] for w in want] == ['meeting-A', 'b', 'rec_with_under_scores', 'NA']
+        for (name, keys, mat), (_, entries) in zip(got, want):
+            assert keys.tolist() == [k for k, _ in entries] and mat.dtype == np.dtype(dtype)
+            assert np.array_equal(mat, np.array([v for _, v in entries]))
+    raw = open(p, 'rb').read()
+    open(p, 'wb').write(raw[:-5])                                # last vector cut short
+    with pytest.raises(ValueError):
+        kf.read_vec_flt_ark_grouped(p)
+    t = str(tmp_path / 't.ark')
+    open(t, 'w').write('r_1  [ 1 2 ]\nr_2  [ 3 4 ]\ns_1  [ 5 6 ]\n')
+    got = kf.read_vec_flt_ark_grouped(t)
+    assert [g[0] for g in got] == ['r', 's'] and np.array_equal(got[0][2], [[1, 2], [3, 4]])
+    seg = str(tmp_path / 'seg')
+    kf.write_segments(seg, [('NA_000-x', 'NA', 0.0, 1.0), ('nan_1', 'nan', 1.0, 2.5)])      # names a CSV parser may eat
+    d = kf.read_xvector_timing_dict(seg)
+    assert list(d) == ['NA', 'nan'] and d['NA'][0].tolist() == ['NA_000-x'] and np.array_equal(d['nan'][1], [[1.0, 2.5]])

@@ -90,3 +90,27 @@ def test_headline_size_score_stage_properties():
     thr40, _ = twoGMMcalib_lin(scr.ravel(), niters=40)
     thr41, _ = twoGMMcalib_lin(scr.ravel(), niters=41)
     assert abs(thr40 - thr41) < 1e-6 and -1 < thr40 < 1
+
+
+@pytest.mark.parametrize('T', [1, 2, 3, 64, 65, 257, 1025])
+def test_condensed_negated_matrix_is_squareform_of_the_device_matrix(T):
+    """vbx_scores_get_condensed(scale = -1) == scipy.spatial.distance.squareform(-scr_mx, checks=False) of the very
+    matrix the device holds (vbhmm.py:139): bit for bit, sign of zero included; a vector that is not T x T is refused."""
+    from scipy.spatial.distance import squareform
+    from vbx_amd import _capi
+    ctx = _capi.default_context(None)
+    x = np.random.default_rng(T).standard_normal((T, 24))
+    x[0] = 0.0                                                   # a zero row: similarities exactly 0 -> -0.0 after negation
+    scores = _capi.Scores.cos_similarity(ctx, x)
+    try:
+        full = scores.get().reshape(T, T)
+        cond = scores.get_condensed(T, -1.0)
+        want = squareform(-full, checks=False) if T > 1 else np.empty(0)
+        assert cond.shape == want.shape and np.array_equal(cond, want)
+        assert np.array_equal(np.signbit(cond), np.signbit(want))
+        assert np.array_equal(scores.get_condensed(T, 1.0), -want if T > 1 else want)
+        if T > 2:
+            with pytest.raises(_capi.VbxError):
+                scores.get_condensed(T - 1, -1.0)
+    finally:
+        scores.close()

@@ -23,7 +23,9 @@ ABI_SYMBOLS = [
     'vbx_batch_create', 'vbx_batch_destroy', 'vbx_batch_set_option', 'vbx_batch_set_recording',
     'vbx_batch_run', 'vbx_batch_get_result', 'vbx_batch_last_run_ms', 'vbx_batch_kernel_times',
     'vbx_run', 'vbx_forward_backward', 'vbx_mstep', 'vbx_loglik',
-    'vbx_cos_similarity', 'vbx_scores_upload', 'vbx_scores_count', 'vbx_scores_get', 'vbx_scores_two_gmm_calib',
+    'vbx_cos_similarity', 'vbx_scores_upload', 'vbx_scores_count', 'vbx_scores_get', 'vbx_scores_get_condensed',
+    'vbx_linkage_average', 'vbx_fcluster_distance', 'vbx_ark_index',
+    'vbx_scores_two_gmm_calib',
     'vbx_scores_destroy',
 ]
 
@@ -78,11 +80,16 @@ def load():
     lib.vbx_scores_upload.argtypes = [vp, i64, vp, C.POINTER(vp)]
     lib.vbx_scores_count.argtypes = [vp]
     lib.vbx_scores_get.argtypes = [vp, i64, i64, vp]
+    lib.vbx_scores_get_condensed.argtypes = [vp, i64, dbl, vp]
+    lib.vbx_linkage_average.argtypes = [i64, vp, vp]
+    lib.vbx_fcluster_distance.argtypes = [i64, vp, dbl, vp]
+    lib.vbx_ark_index.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp]
+    lib.vbx_ark_index.restype = i64
     lib.vbx_scores_two_gmm_calib.argtypes = [vp, i32, C.POINTER(dbl), vp]
     lib.vbx_scores_destroy.argtypes = [vp]
     for name in ABI_SYMBOLS:
         fn = getattr(lib, name)          # AttributeError here = the .so does not export the ABI
-        if name == 'vbx_scores_count':
+        if name in ('vbx_scores_count', 'vbx_ark_index'):
             fn.restype = C.c_int64
         elif name not in ('vbx_last_error', 'vbx_abi_version'):
             fn.restype = C.c_int
@@ -208,6 +215,14 @@ class Scores:
         self.ctx.check(self._lib.vbx_scores_get(self._h, int(offset), int(count), _ptr(out)), 'vbx_scores_get')
         return out
 
+    def get_condensed(self, T, scale=1.0):
+        """Strict upper triangle of ``scale * S`` (S = these scores as a T x T matrix), row by row: the vector form
+        of ``scipy.spatial.distance.squareform``."""
+        out = np.empty(int(T) * (int(T) - 1) // 2)
+        self.ctx.check(self._lib.vbx_scores_get_condensed(self._h, int(T), float(scale), _ptr(out)),
+                       'vbx_scores_get_condensed')
+        return out
+
     def two_gmm_calib(self, niters=20, want_llr=True):
         thr = C.c_double()
         llr = np.empty(len(self)) if want_llr else None
@@ -330,6 +345,52 @@ class Batch:
 
 
 _default_ctx = {}
+
+
+def linkage_average(condensed):
+    """``scipy.cluster.hierarchy.linkage(condensed, method='average')`` (= ``fastcluster.linkage``) as native host
+    code: the (n - 1) x 4 linkage matrix, bit for bit SciPy's.  The call releases the GIL: one recording per thread."""
+    y = np.ascontiguousarray(condensed, dtype=np.float64)
+    if y.ndim != 1:
+        raise ValueError('linkage_average expects a condensed distance vector')
+    n = int(round((1.0 + np.sqrt(1.0 + 8.0 * y.size)) / 2.0))
+    if n * (n - 1) // 2 != y.size or n < 2:
+        raise ValueError(f'{y.size} is not the length n (n - 1) / 2 of a condensed distance vector')
+    Z = np.empty((n - 1, 4))
+    rc = load().vbx_linkage_average(n, _ptr(y), _ptr(Z))
+    if rc != 0:
+        raise VbxError(f'vbx_linkage_average failed ({rc})')
+    return Z
+
+
+def ark_index(buf):
+    """Entries of a binary Kaldi vector archive held in ``buf`` (bytes-like): arrays (key offset, key length, data
+    offset, dimension, element size), or ``None`` when the archive is not of that form (text archives)."""
+    raw = np.frombuffer(buf, dtype=np.uint8)
+    cap = max(16, raw.size // 64)
+    while True:
+        ko, kl = np.empty(cap, np.int64), np.empty(cap, np.int32)
+        do, dm, es = np.empty(cap, np.int64), np.empty(cap, np.int32), np.empty(cap, np.int32)
+        n = load().vbx_ark_index(_ptr(raw), raw.size, cap, _ptr(ko), _ptr(kl), _ptr(do), _ptr(dm), _ptr(es))
+        if n == -2:
+            cap *= 4
+            continue
+        if n < 0:
+            return None
+        return ko[:n], kl[:n], do[:n], dm[:n], es[:n]
+
+
+def fcluster_distance(Z, t):
+    """``scipy.cluster.hierarchy.fcluster(Z, t, criterion='distance')`` as native host code (labels from 1, int32)."""
+    Z = np.ascontiguousarray(Z, dtype=np.float64)
+    if Z.ndim != 2 or Z.shape[1] != 4:
+        raise ValueError('fcluster_distance expects an (n - 1) x 4 linkage matrix')
+    n = Z.shape[0] + 1
+    labels = np.empty(n, dtype=np.int32)
+    rc = load().vbx_fcluster_distance(n, _ptr(Z), float(t), _ptr(labels))
+    if rc != 0:
+        raise VbxError(f'vbx_fcluster_distance failed ({rc}): not a linkage matrix')
+    return labels
 
 
 def default_context(device: int | None = None) -> Context:

@@ -73,6 +73,16 @@ __global__ __launch_bounds__(256) void cos_gemm_kernel(const double* __restrict_
             }
 }
 
+// condensed (upper triangle, row by row: scipy.spatial.distance.squareform's vector form) copy of scale * S: what the
+// clustering that follows the calibration consumes (vbhmm.py:139 squareform(-scr_mx)).  grid = T - 1 rows.
+__global__ __launch_bounds__(256) void condense_kernel(const double* __restrict__ s, double* __restrict__ out, long long T,
+                                                        double scale) {
+    const long long i = blockIdx.x;
+    const double* __restrict__ row = s + i * T;
+    double* __restrict__ dst = out + i * (2 * T - i - 1) / 2 - (i + 1);      // dst[j] = element (i, j), j > i
+    for (long long j = i + 1 + threadIdx.x; j < T; j += 256) dst[j] = scale * row[j];
+}
+
 // ---- two-Gaussian calibration ---------------------------------------------------------------------
 // parameter block on the device: [0,1] weights  [2,3] means  [4] var  [5..9] the same before the last update
 constexpr int kGmmPartials = 2048;         // workgroups of a streaming pass (fixed: deterministic summation order)

@@ -10,6 +10,7 @@
 #include "vbx_fused.hpp"
 #include "vbx_fused_mid.hpp"
 #include "vbx_fused_quad.hpp"
+#include "vbx_linkage.hpp"
 #include "vbx_ahc.hpp"
 
 #include <algorithm>
@@ -1173,6 +1174,58 @@ int vbx_scores_get(vbx_scores* sc, int64_t offset, int64_t count, double* out) {
     if (!out || offset < 0 || count < 0 || offset + count > sc->n) FAIL(sc->ctx, VBX_ERR_INVALID, "vbx_scores_get: bad range");
     HIPCHK(sc->ctx, hipSetDevice(sc->ctx->device));
     if (count) HIPCHK(sc->ctx, hipMemcpy(out, sc->d_s + offset, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost));
+    return VBX_OK;
+}
+
+int vbx_linkage_average(int64_t n, const double* condensed, double* Z) {
+    if (n < 1 || (n > 1 && (!condensed || !Z))) return VBX_ERR_INVALID;
+    if (n > 65536) return VBX_ERR_UNSUPPORTED;               // n^2 doubles of working storage
+    try {
+        vbx::average_linkage(n, condensed, Z);
+    } catch (const std::bad_alloc&) {
+        return VBX_ERR_HIP - 100;                            // host allocation failure (no ctx to carry a message)
+    }
+    return VBX_OK;
+}
+
+int64_t vbx_ark_index(const void* buf, int64_t len, int64_t cap, int64_t* key_off, int32_t* key_len, int64_t* data_off,
+                      int32_t* dim, int32_t* elem_size) {
+    if (!buf || len < 0 || cap < 0 || (cap > 0 && (!key_off || !key_len || !data_off || !dim || !elem_size))) return -1;
+    return vbx::ark_index(static_cast<const unsigned char*>(buf), len, cap, key_off, key_len, data_off, dim, elem_size);
+}
+
+int vbx_fcluster_distance(int64_t n, const double* Z, double t, int32_t* labels) {
+    if (n < 1 || !labels || (n > 1 && !Z)) return VBX_ERR_INVALID;
+    for (int64_t k = 0; k < n - 1; ++k) {                      // children exist before their parent, ids in range
+        const double a = Z[4 * k], b = Z[4 * k + 1];
+        if (!(a >= 0 && b >= 0 && a < (double)(n + k) && b < (double)(n + k))) return VBX_ERR_INVALID;
+    }
+    try {
+        vbx::fcluster_distance(n, Z, t, labels);
+    } catch (const std::bad_alloc&) {
+        return VBX_ERR_HIP - 100;
+    }
+    return VBX_OK;
+}
+
+int vbx_scores_get_condensed(vbx_scores* sc, int64_t T, double scale, double* out) {
+    if (!sc) return VBX_ERR_INVALID;
+    vbx_ctx* ctx = sc->ctx;
+    if (!out || T < 1 || (long long)T * T != sc->n) FAIL(ctx, VBX_ERR_INVALID, "vbx_scores_get_condensed: the scores are not a %lld x %lld matrix", (long long)T, (long long)T);
+    if (T == 1) return VBX_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t m = (size_t)T * (size_t)(T - 1) / 2;
+    double* d_c = nullptr;
+    int rc = dmalloc(ctx, &d_c, m);
+    if (rc != VBX_OK) return rc;
+    hipLaunchKernelGGL(vbx::condense_kernel, dim3((unsigned)(T - 1)), dim3(256), 0, ctx->stream, sc->d_s, d_c, (long long)T, scale);
+    hipError_t e = hipMemcpyAsync(out, d_c, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_c);
+    if (e != hipSuccess) {
+        ctx->err = std::string("vbx_scores_get_condensed: ") + hipGetErrorString(e);
+        return VBX_ERR_HIP;
+    }
     return VBX_OK;
 }
 

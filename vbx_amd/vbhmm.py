@@ -1,0 +1,292 @@
+#!/usr/bin/env python
+"""Diarization driver with the command line of the reference's ``VBx/vbhmm.py``, built around the batched
+MI355X path:
+
+    python -m vbx_amd.vbhmm --init AHC+VB --out-rttm-dir out --xvec-ark-file x.ark --segments-file x.seg \\
+        --xvec-transform transform.h5 --plda-file plda --threshold -0.015 --lda-dim 128 --Fa 0.3 --Fb 17 --loopP 0.99
+
+The reference walks the recordings of the archive one after another (vbhmm.py:120) and runs everything on one
+CPU thread.  Here the loop is split into three stages:
+
+  1. per recording: x-vector projection (vbhmm.py:125-129), AHC initialisation -- similarity matrix, threshold
+     calibration and the condensed negated matrix on the GPU, average-linkage clustering on the host in worker
+     threads (a chain of T dependent nearest-neighbour steps: nothing for a GPU to do) -- and the PLDA projection
+     ``fea`` (vbhmm.py:153);
+  2. ALL recordings of this rank in one ``vbx_batch``: one launch sequence per EM iteration for the whole
+     archive, convergence per recording on the device (vbhmm.py:154-158 call, batched);
+  3. per recording: labels, merging of adjacent segments and the RTTM file (vbhmm.py:160-179).
+
+Under ``torchrun`` (one process per GPU) the recordings are dealt to the ranks by cost; every rank writes the
+RTTM files of its own recordings and the ranks only meet in a barrier at the end.  Same flags, same files, same
+RTTM bytes as the reference driver.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+from .kaldi_formats import (read_plda, read_vec_flt_ark_grouped, read_xvec_transform, read_xvector_timing_dict,
+                            write_rttm)
+
+__all__ = ['main', 'diarize', 'tune_host_process', 'load_models', 'project_xvectors', 'ahc_init', 'cluster', 'device_score_stage',
+           'merge_adjacent_labels', 'l2_norm']
+
+
+def l2_norm(vec_or_matrix):
+    """Rows (or the vector) scaled to unit Euclidean length.  diarization_lib.py:169-187."""
+    a = np.asarray(vec_or_matrix)
+    if a.ndim == 1:
+        return a / np.linalg.norm(a)
+    if a.ndim == 2:
+        return a / np.linalg.norm(a, axis=1, ord=2)[:, np.newaxis]
+    raise ValueError('Wrong number of dimensions, 1 or 2 is supported, not %i.' % a.ndim)
+
+
+def merge_adjacent_labels(starts, ends, labels):
+    """Adjacent or overlapping segments with the same label become one; overlapping segments with different
+    labels meet in the middle of the overlap.  diarization_lib.py:116-137."""
+    starts, ends, labels = np.asarray(starts), np.asarray(ends), np.asarray(labels)
+    touching = np.logical_or(np.isclose(ends[:-1], starts[1:]), ends[:-1] > starts[1:])
+    cut = np.nonzero(np.logical_or(~touching, labels[1:] != labels[:-1]))[0]
+    starts = starts[np.r_[0, cut + 1]]
+    ends = ends[np.r_[cut, -1]]
+    labels = labels[np.r_[0, cut + 1]]
+    over = np.nonzero(starts[1:] < ends[:-1])[0]
+    ends[over] = starts[over + 1] = (ends[over] + starts[over + 1]) / 2.0
+    return starts, ends, labels
+
+
+def load_models(xvec_transform, plda_file):
+    """x-vector transform and the PLDA model in the simultaneously diagonalised form of vbhmm.py:107-113."""
+    from scipy.linalg import eigh
+    mean1, mean2, lda = read_xvec_transform(xvec_transform)
+    plda_mu, plda_tr, plda_psi = read_plda(plda_file)
+    W = np.linalg.inv(plda_tr.T.dot(plda_tr))
+    B = np.linalg.inv((plda_tr.T / plda_psi).dot(plda_tr))
+    acvar, wccn = eigh(B, W)
+    return dict(mean1=mean1, mean2=mean2, lda=lda, plda_mu=plda_mu, plda_psi=acvar[::-1], plda_tr=wccn.T[::-1])
+
+
+def project_xvectors(x, models):
+    """vbhmm.py:129: centre, length-normalise, LDA, centre, length-normalise."""
+    return l2_norm(models['lda'].T.dot(l2_norm(x - models['mean1']).transpose()).transpose() - models['mean2'])
+
+
+def device_score_stage(x):
+    """Score stage of the AHC initialisation on the GPU (vbhmm.py:135-139): the cosine-similarity matrix of the rows
+    of ``x``, the threshold of its two-Gaussian calibration, and the negated matrix in the condensed form the
+    clustering consumes (``squareform(-scr_mx, checks=False)``).  The T x T matrix never leaves the device: only
+    the threshold and the T (T - 1) / 2 upper-triangle entries come back.  No host fallback: without the HIP
+    library this raises."""
+    from . import _capi
+    xx = np.ascontiguousarray(x, dtype=np.float64)
+    scores = _capi.Scores.cos_similarity(_capi.default_context(None), xx)
+    try:
+        thr, _ = scores.two_gmm_calib(20, want_llr=False)
+        cond = scores.get_condensed(xx.shape[0], -1.0)
+    finally:
+        scores.close()
+    return cond, float(thr)
+
+
+def cluster(cond, thr, threshold):
+    """Average-linkage clustering of the condensed negated similarities, cut at the calibrated threshold
+    (vbhmm.py:140-146) -> integer cluster label per x-vector.  The linkage is the library's native host routine
+    (``vbx_linkage_average``: nearest-neighbour chain, the linkage matrix of SciPy / fastcluster bit for bit; the cut
+    is ``vbx_fcluster_distance``): a chain
+    of T dependent steps over cache-resident rows, nothing for a GPU to do -- but it holds no interpreter lock, so the
+    driver clusters several recordings at a time next to the GPU score stage of the following ones."""
+    from . import _capi
+    lin_mat = _capi.linkage_average(cond)
+    adjust = abs(lin_mat[:, 2].min())
+    lin_mat[:, 2] += adjust
+    return _capi.fcluster_distance(lin_mat, -(thr + threshold) + adjust).astype(np.int64) - 1
+
+
+def ahc_init(x, threshold, score_stage=device_score_stage):
+    """Kaldi-like AHC of the projected x-vectors (vbhmm.py:135-146) -> (labels, calibrated threshold)."""
+    cond, thr = score_stage(x)
+    return cluster(cond, thr, threshold), thr
+
+
+def tune_host_process():
+    """Process-wide settings for a run that mixes worker threads with many multi-megabyte NumPy temporaries (measured
+    on a 256-core host: without them the per-recording host work of stage 1 runs 5-10x slower than alone):
+
+      * glibc serves every array above 128 KB with its own mmap and returns it with munmap; each munmap interrupts
+        every core the process has threads on (BLAS pool, HIP runtime, clustering workers).  Raising the mmap and
+        trim thresholds keeps those arrays in the heap, where they are recycled without system calls;
+      * the matrix products of one recording are tiny (1000 x 256 x 128): a 64-thread BLAS pool costs more to wake
+        than it saves.
+
+    Returns a context manager that limits the BLAS pools (a no-op without ``threadpoolctl``)."""
+    import contextlib
+    import ctypes
+    try:
+        libc = ctypes.CDLL(None)
+        libc.mallopt(ctypes.c_int(-3), ctypes.c_int(1 << 30))     # M_MMAP_THRESHOLD (glibc clamps it to 32 MB)
+        libc.mallopt(ctypes.c_int(-1), ctypes.c_int((1 << 31) - 1))   # M_TRIM_THRESHOLD
+    except (OSError, AttributeError):
+        pass
+    try:
+        from threadpoolctl import threadpool_limits
+        return threadpool_limits(limits=4, user_api='blas')
+    except ImportError:
+        return contextlib.nullcontext()
+
+
+def _read_recordings(ark_path):
+    """[(recording, names, x[T, D])] in archive order; x-vectors of a recording are consecutive (vbhmm.py:119)."""
+    return read_vec_flt_ark_grouped(ark_path)
+
+
+def _rank_world():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except ImportError:
+        pass
+    return int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+
+
+def diarize(args, run_batch=None, score_stage=device_score_stage, log=print):
+    """The whole archive.  ``run_batch(items, maxIters, epsilon, **hyper)`` defaults to ``vbx_amd.batch.VBx_batch``
+    and ``score_stage`` to the GPU score stage (the CPU test-suite injects its checkers for both).  Returns ``{recording: dict(labels1st, labels2nd, n_iters, thr, seconds...)}`` for
+    the recordings of this rank."""
+    from scipy.special import softmax
+    from .batch import VBx_batch, shard_recordings
+    assert 0 <= args.loopP <= 1, f'Expecting loopP between 0 and 1, got {args.loopP} instead.'
+    t_start = time.perf_counter()
+    segs_dict = read_xvector_timing_dict(args.segments_file)
+    models = load_models(args.xvec_transform, args.plda_file)
+    recordings = _read_recordings(args.xvec_ark_file)
+    rank, world = _rank_world()
+    if world > 1:                                                 # AHC is O(T^2), the VB loop O(T S): deal by T^2
+        assignment = shard_recordings([float(len(r[1])) ** 2 for r in recordings], world)
+        recordings = [r for k, r in enumerate(recordings) if assignment[k] == rank]
+    t_read = time.perf_counter()
+
+    # ---- stage 1: projections and AHC initialisation -------------------------------------------------------------
+    # GPU score stage of one recording after the other on this thread; the host clustering of each runs in a worker
+    # thread meanwhile.
+    from concurrent.futures import ThreadPoolExecutor
+    items, state = [], {}
+    pending = []
+    with tune_host_process(), ThreadPoolExecutor(max_workers=max(1, min(8, (os.cpu_count() or 2) - 1))) as pool:
+        for file_name, seg_names, xvecs in recordings:
+            log(file_name)                                        # vbhmm.py:121
+            x = project_xvectors(xvecs, models)
+            cond, thr = score_stage(x)
+            pending.append((file_name, seg_names, x, thr, pool.submit(cluster, cond, thr, args.threshold)))
+            del cond
+        for file_name, seg_names, x, thr, fut in pending:
+            labels1st = fut.result()
+            st = dict(labels1st=labels1st, labels2nd=None, thr=thr, n_iters=0, seg_names=seg_names)
+            if args.init.endswith('VB'):
+                qinit = np.zeros((len(labels1st), np.max(labels1st) + 1))
+                qinit[range(len(labels1st)), labels1st] = 1.0
+                qinit = softmax(qinit * args.init_smoothing, axis=1)
+                fea = (x - models['plda_mu']).dot(models['plda_tr'].T)[:, :args.lda_dim]
+                st['item'] = len(items)
+                items.append(dict(X=fea, Phi=models['plda_psi'][:args.lda_dim], pi=qinit.shape[1], gamma=qinit))
+            state[file_name] = st
+    del pending
+    t_ahc = time.perf_counter()
+
+    # ---- stage 2: every recording of this rank in one batch ------------------------------------------------------
+    if items:
+        hyper = dict(loopProb=args.loopP, Fa=args.Fa, Fb=args.Fb)
+        if run_batch is None:
+            results = VBx_batch(items, maxIters=40, epsilon=1e-6, precision=getattr(args, 'precision', 'fp64'), **hyper)
+        else:
+            results = run_batch(items, 40, 1e-6, **hyper)
+        for st in state.values():
+            q, _sp, L = results[st['item']]
+            order = np.argsort(-q, axis=1)
+            st['labels1st'] = order[:, 0]
+            st['labels2nd'] = order[:, 1] if q.shape[1] > 1 else None
+            st['n_iters'] = len(L)
+    t_vb = time.perf_counter()
+
+    # ---- stage 3: RTTM --------------------------------------------------------------------------------------------
+    for file_name, st in state.items():
+        assert np.all(segs_dict[file_name][0] == st['seg_names'])                 # vbhmm.py:166
+        start, end = segs_dict[file_name][1].T
+        starts, ends, out_labels = merge_adjacent_labels(start, end, st['labels1st'])
+        os.makedirs(args.out_rttm_dir, exist_ok=True)
+        with open(os.path.join(args.out_rttm_dir, f'{file_name}.rttm'), 'w') as fp:
+            write_rttm(fp, file_name, out_labels, starts, ends)
+        if args.output_2nd and args.init.endswith('VB') and st['labels2nd'] is not None:
+            starts, ends, out_labels2 = merge_adjacent_labels(start, end, st['labels2nd'])
+            second = f'{args.out_rttm_dir}2nd'
+            os.makedirs(second, exist_ok=True)
+            with open(os.path.join(second, f'{file_name}.rttm'), 'w') as fp:
+                write_rttm(fp, file_name, out_labels2, starts, ends)
+        del st['seg_names']
+        st.pop('item', None)
+    t_end = time.perf_counter()
+    timing = dict(read=t_read - t_start, ahc=t_ahc - t_read, vb=t_vb - t_ahc, rttm=t_end - t_vb, total=t_end - t_start,
+                  recordings=len(state), xvectors=int(sum(len(st['labels1st']) for st in state.values())),
+                  rank=rank, world=world)
+    return state, timing
+
+
+def build_parser():
+    """The arguments of vbhmm.py:54-101, plus the knobs of this implementation."""
+    p = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    p.add_argument('--init', required=True, type=str, choices=['AHC', 'AHC+VB'],
+                   help='AHC for using only AHC or AHC+VB for VB-HMM after AHC initilization')
+    p.add_argument('--out-rttm-dir', required=True, type=str, help='Directory to store output rttm files')
+    p.add_argument('--xvec-ark-file', required=True, type=str,
+                   help='Kaldi ark file with x-vectors from one or more input recordings (all x-vectors of one '
+                        'recording consecutive)')
+    p.add_argument('--segments-file', required=True, type=str, help='File with x-vector timing info')
+    p.add_argument('--xvec-transform', required=True, type=str, help='x-vector transformation: h5 (or npz) file')
+    p.add_argument('--plda-file', required=True, type=str, help='PLDA model in Kaldi format')
+    p.add_argument('--threshold', required=True, type=float, help='threshold (bias) used for AHC')
+    p.add_argument('--lda-dim', required=True, type=int, help='x-vectors are reduced to this dimensionality for VB-HMM')
+    p.add_argument('--Fa', required=True, type=float, help='Parameter of VB-HMM (see VBx.VBx)')
+    p.add_argument('--Fb', required=True, type=float, help='Parameter of VB-HMM (see VBx.VBx)')
+    p.add_argument('--loopP', required=True, type=float, help='Parameter of VB-HMM (see VBx.VBx)')
+    p.add_argument('--target-energy', required=False, type=float, default=1.0,
+                   help='accepted for compatibility (only used by the PLDA-scoring AHC the driver does not call)')
+    p.add_argument('--init-smoothing', required=False, type=float, default=5.0,
+                   help='smoothing of the hard AHC labels into the initial soft assignments')
+    p.add_argument('--output-2nd', required=False, type=bool, default=False,
+                   help='Output also second most likely speaker of VB-HMM')
+    p.add_argument('--precision', default='fp64', choices=['fp64', 'fp32'],
+                   help='arithmetic of the VB-HMM kernels (fp64 = the reference\'s dtype and iteration counts)')
+    p.add_argument('--timing', action='store_true', help='print a JSON line with the stage timings of this rank')
+    return p
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    dist = None
+    if int(os.environ.get('WORLD_SIZE', 1)) > 1:                  # launched by torchrun: one process per GPU
+        import torch
+        import torch.distributed as dist
+        if torch.cuda.is_available():
+            torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
+            os.environ.setdefault('VBX_AMD_DEVICE', os.environ.get('LOCAL_RANK', '0'))
+        dist.init_process_group('nccl' if torch.cuda.is_available() else 'gloo')
+    try:
+        _state, timing = diarize(args)
+        if dist is not None:
+            dist.barrier()
+    finally:
+        if dist is not None and dist.is_initialized():
+            dist.destroy_process_group()
+    if args.timing:
+        import json
+        print(json.dumps(timing))
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())
