@@ -687,3 +687,27 @@ def test_randomised_differential_against_the_oracle():
         assert np.all(np.isfinite(g32)), tag
         assert np.abs(g32 - gr).max() <= FP32_TOL, (tag, np.abs(g32 - gr).max())
         assert np.abs(p32 - pr).max() <= FP32_TOL and rel_err([r[0] for r in L32], [r[0] for r in Lr]) <= FP32_TOL, tag
+
+
+@pytest.mark.parametrize('loopProb', [0.0, 1e-9, 2.0 ** -20, 1e-3, 0.5, 1.0])
+def test_loop_probability_extremes_against_the_oracle(loopProb):
+    """loopProb at and around the switch of the operator recursion (chunk_loglik phase 2 runs on z = x / lp^t for
+    lp >= 2^-20 and in the plain form below; lp^t over a 128-frame chunk is 2^-2560 at the switch, far outside
+    float32 -- it lives in the column exponents), plus lp = 1 (c_j = 1e-8: the chain never leaves a state except
+    through the regulariser) and lp = 0.  fp64 and fp32 kernels, single call and a recording of several chunks."""
+    import vbx_amd
+    from vbx_amd.synth import make_recording
+    T, S = 1500, 9
+    X, Phi, _ = make_recording(T, S, seed=300, kappa=0.05)
+    g0 = np.random.default_rng(301).gamma(1.0, size=(T, S))
+    g0 /= g0.sum(1, keepdims=True)
+    kw = dict(loopProb=loopProb, Fa=0.3, Fb=17.0, pi=S, gamma=g0, maxIters=3, epsilon=-1e300)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        gr, pr, Lr = _orc().VBx(X, Phi, **kw)
+    for precision, tol in (('fp64', 1e-8), ('fp32', FP32_TOL)):
+        with contextlib.redirect_stdout(buf):
+            g, p, L = vbx_amd.VBx(X, Phi, precision=precision, **kw)
+        assert np.isfinite(g).all() and np.abs(g.sum(1) - 1).max() <= 1e-5
+        assert np.abs(g - gr).max() <= tol, (precision, loopProb, np.abs(g - gr).max())
+        assert np.abs(p - pr).max() <= tol and rel_err([r[0] for r in L], [r[0] for r in Lr]) <= tol, (precision, loopProb)
