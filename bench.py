@@ -25,6 +25,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')   # before any HIP runtime starts (torch included): the library's stream
+                                                    # groups want one hardware queue per stream (vbx_capi.hip)
 import sys
 import time
 
@@ -67,10 +69,12 @@ def algo_bytes(kernel, T, R, S, esize):
     return esize * (pr * T * R + ps * T * S)
 
 
-def make_batch(ctx, n_rec, T, S, D, precision, seed0, max_iters):
+def make_batch(ctx, n_rec, T, S, D, precision, seed0, max_iters, streams=None):
     from vbx_amd import _capi
     from vbx_amd.synth import make_recording
     batch = _capi.Batch(ctx, [T] * n_rec, [S] * n_rec, D, precision=precision, max_iters=max_iters)
+    if streams is not None and batch.streams != streams:
+        batch.set_option(_capi.OPT_STREAMS, streams)
     for b in range(n_rec):
         X, Phi, _ = make_recording(T, S, D=D, seed=seed0 + b, kappa=0.05, dtype=np.float32)
         g = np.random.default_rng(10_000 + seed0 + b).gamma(1.0, size=(T, S))
@@ -106,6 +110,7 @@ def main():
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'fp64'])
     ap.add_argument('--cpu-iters', type=int, default=20, help='oracle iterations for cpu_baseline (0 = skip)')
     ap.add_argument('--no-single', action='store_true', help='skip the batch=1 latency measurement')
+    ap.add_argument('--streams', type=int, default=None, help='HIP streams per batch (default: the library\'s choice)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -129,33 +134,52 @@ def main():
     K, W = args.steps, args.warmup
 
     batch = make_batch(ctx, args.batch, args.T, args.S, args.D, args.precision, seed0=rank * args.batch,
-                       max_iters=K + W + 8)
+                       max_iters=K + W + 8, streams=args.streams)
+    streams = batch.streams                      # launches of a kernel class per step; each covers batch / streams recordings
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # untimed: which kernel dominates?  (events around every launch for a few iterations)
-    batch.profile_kernels(None)
-    batch.run(8, -np.inf)
-    survey = batch.kernel_times()
+    # Kernel-level measurements run on ONE stream: with several streams per GPU (the library's default for a batch
+    # of this size) launches of different streams share the CUs, and the duration of a launch says how it shared
+    # them, not what the kernel achieves.  Same recordings, same K steps, HIP events on the batch's own stream:
+    #   - 8 untimed iterations with events around every launch: which kernel dominates?
+    #   - W + K iterations with events around the dominant kernel's launches only -> `roofline`.
+    probe = batch if streams == 1 else make_batch(ctx, args.batch, args.T, args.S, args.D, args.precision,
+                                                  seed0=rank * args.batch, max_iters=K + W + 8, streams=1)
+    probe.profile_kernels(None)
+    probe.run(8, -np.inf)
+    survey = probe.kernel_times()
     per_kernel = {k: {'avg_us': 1e3 * ms / n, 'launches': n} for k, (ms, n) in survey.items() if n}
     dom = max((k for k in per_kernel if k in ALGO_PASSES and per_kernel[k]['launches'] >= 8),
               key=lambda k: per_kernel[k]['avg_us'])          # (the one-off first accumulation does not count)
-    # timed region: HIP events (on the batch's own stream) around the dominant kernel's launches only
+    if streams > 1:
+        probe.profile_kernels([dom])
+        probe.run(W, -np.inf)
+        probe.run(K, -np.inf)
+        kt = probe.kernel_times()
+        per_kernel[dom] = {'avg_us': 1e3 * kt[dom][0] / kt[dom][1], 'launches': kt[dom][1]}
+        probe_ms_per_step = probe.last_run_ms()[0] / K
+        probe.close()
+    # timed region: the library's default configuration, HIP events (on each stream of the batch) around the
+    # dominant kernel's launches only
     batch.profile_kernels([dom])
     batch.run(W, -np.inf)
     barrier()
     t0 = time.perf_counter()
-    batch.run(K, -np.inf)                          # returns after the stream has drained
+    batch.run(K, -np.inf)                          # returns after the streams have drained
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
     dev_ms, launched = batch.last_run_ms()
     ktimes = batch.kernel_times()
     assert launched == K and ktimes[dom][1] >= K
-    per_kernel[dom] = {'avg_us': 1e3 * ktimes[dom][0] / ktimes[dom][1], 'launches': ktimes[dom][1]}
+    timed_avg_us = 1e3 * ktimes[dom][0] / ktimes[dom][1]
+    if streams == 1:
+        per_kernel[dom] = {'avg_us': timed_avg_us, 'launches': ktimes[dom][1]}
+        probe_ms_per_step = dev_ms / K
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -164,7 +188,7 @@ def main():
     # the same K steps without per-kernel events (reported beside the contract number)
     batch.close()
     batch2 = make_batch(ctx, args.batch, args.T, args.S, args.D, args.precision, seed0=rank * args.batch,
-                        max_iters=K + W)
+                        max_iters=K + W, streams=args.streams)
     batch2.run(W, -np.inf)
     barrier()
     t0 = time.perf_counter()
@@ -189,10 +213,10 @@ def main():
 
     if rank == 0:
         total_units = world * args.batch * K
-        dom_bytes = args.batch * algo_bytes(dom, args.T, args.D, args.S, esize)
+        dom_bytes = args.batch * algo_bytes(dom, args.T, args.D, args.S, esize)      # one launch of the one-stream pass
         achieved = dom_bytes / (per_kernel[dom]['avg_us'] * 1e-6) / 1e9
         traffic = pmc_traffic(dom, {'batch': args.batch, 'T': args.T, 'S': args.S, 'D': args.D,
-                                    'precision': args.precision})
+                                    'precision': args.precision})      # (profiled with --streams 1)
         out = {
             'metric': 'VB EM iterations/sec (T=10k xvecs, R=128, S=30)',
             'value': total_units / elapsed,
@@ -209,19 +233,28 @@ def main():
             'config': {'workload': f'batch of {args.batch} recordings per GPU, each T={args.T} x-vectors, '
                                    f'R={args.D}, S={args.S} (BASELINE configs[3] batch; headline shape), '
                                    'random gamma init, Fa=0.3 Fb=17 loopProb=0.99',
-                       'recordings_per_gpu': args.batch, 'T': args.T, 'R': args.D, 'S': args.S,
+                       'recordings_per_gpu': args.batch, 'T': args.T, 'R': args.D, 'S': args.S, 'streams_per_gpu': streams,
                        'parallelism': f'recordings sharded over {world} rank(s), no data-path collective'},
             'value_without_any_kernel_events': world * args.batch * K / elapsed_plain,
             'device_ms_per_step': dev_ms / K,
             'device': info['name'],
             'kernels_avg_us': {k: round(v['avg_us'], 2) for k, v in per_kernel.items()},
-            'kernels_avg_us_note': 'dominant kernel: HIP events over the timed region; others: 8 untimed survey iterations',
+            'kernels_avg_us_note': 'one-stream pass: dominant kernel over W + K steps, others over 8 survey iterations',
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic[0] if traffic else None,
                          'traffic_source': traffic[1] if traffic else None,
                          'algorithmic_bytes_per_launch': dom_bytes,
-                         'avg_launch_us': per_kernel[dom]['avg_us']},
+                         'avg_launch_us': per_kernel[dom]['avg_us'],
+                         'measured': ('HIP events on the batch stream over the timed region' if streams == 1 else
+                                      f'HIP events over W + K steps of the same batch on ONE stream (VBX_OPT_STREAMS=1, '
+                                      f'{probe_ms_per_step:.4f} ms per step): a kernel-level figure needs the kernel alone on '
+                                      'the GPU; the timed region itself is in roofline_timed_region')},
+            'roofline_timed_region': {'streams': streams, 'kernel': dom, 'avg_launch_us': timed_avg_us,
+                                      'recordings_per_launch': args.batch / streams,
+                                      'note': 'launches of different streams overlap: per-launch durations of this '
+                                              'region are not bandwidth measurements; roofline_whole_iteration is its '
+                                              'throughput view'},
             'gamma_checks': {'row_sum_max_dev': float(np.abs(res0['gamma'].sum(1) - 1).max()),
                              'elbo_last': float(res0['Li'][-1])},
         }

@@ -65,6 +65,10 @@ extern "C" {
 #define VBX_OPT_POST_KERNEL 9   /* chunk_post variant: 1 (default) half lattices in LDS (meet in the middle, four workgroups
                                    per CU); 0 full lattices; 2 four tiles per workgroup, one per 16-lane row of the
                                    re-run waves, gamma^T rho fed from registers (f32, <= 32 states, D <= 128; else 1) */
+#define VBX_OPT_STREAMS 10      /* HIP streams of a batch: its recordings are dealt to that many sub-batches, one
+                                   iteration of each is launched stream after stream, so the latency-bound launches of
+                                   one overlap the bandwidth-bound ones of the others.  0 = auto (3 from 24 recordings,
+                                   2 from 12, else 1; env VBX_AMD_STREAMS overrides).  Before the first recording. */
 #define VBX_OPT_HALF_CHUNKS 7   /* 1: the fused kernels use one transfer operator / boundary pair per HALF tile (64
                                    frames) and re-run the halves on separate waves; 0 (default): per tile.  Halves
                                    the chunk kernels' dependent chains, doubles the boundary walk: a wash overall */
@@ -138,6 +142,8 @@ int vbx_batch_last_run_ms(vbx_batch* batch, double* total_ms, int* iters_launche
 /* With VBX_OPT_PROFILE=1: summed HIP-event time (ms) and launch count per kernel class
  * for the last run; arrays of VBX_K_COUNT entries. */
 int vbx_batch_kernel_times(vbx_batch* batch, double* ms, int64_t* launches);
+/* Number of HIP streams (sub-batches) this batch runs on: VBX_OPT_STREAMS in effect. */
+int vbx_batch_streams(const vbx_batch* b);
 
 /* ---- one-shot: a single recording, host buffers in / out (= one reference VBx call) ---- */
 typedef struct {

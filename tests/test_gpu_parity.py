@@ -711,3 +711,63 @@ def test_loop_probability_extremes_against_the_oracle(loopProb):
         assert np.isfinite(g).all() and np.abs(g.sum(1) - 1).max() <= 1e-5
         assert np.abs(g - gr).max() <= tol, (precision, loopProb, np.abs(g - gr).max())
         assert np.abs(p - pr).max() <= tol and rel_err([r[0] for r in L], [r[0] for r in Lr]) <= tol, (precision, loopProb)
+
+
+@pytest.mark.parametrize('precision,tol', [('fp64', 1e-10), ('fp32', 2e-5)])
+def test_stream_groups_give_the_results_of_a_plain_batch(ctx, precision, tol, monkeypatch):
+    """VBX_OPT_STREAMS / VBX_AMD_STREAMS: the recordings of a batch dealt to K sub-batches on K HIP streams (longest
+    first), one iteration of each launched stream after stream.  Same results per recording as one plain batch --
+    mixed lengths and speaker counts (a sub-batch may pad to a narrower state width than the whole batch), device-side
+    convergence per sub-batch, options forwarded, per-kernel timings summed over the streams."""
+    from vbx_amd import _capi
+    from vbx_amd.synth import make_recording
+    Ts = [900, 300, 1500, 130, 700, 260, 1100, 64, 513]
+    Ss = [9, 4, 20, 3, 12, 6, 30, 2, 17]
+    recs = []
+    for k, (T, S) in enumerate(zip(Ts, Ss)):
+        X, Phi, _ = make_recording(T, S, seed=400 + k, kappa=0.04)
+        g0 = np.random.default_rng(410 + k).gamma(1.0, size=(T, S))
+        recs.append((X, Phi, g0 / g0.sum(1, keepdims=True)))
+
+    def run(streams, epsilon, iters):
+        monkeypatch.setenv('VBX_AMD_STREAMS', str(streams))
+        batch = _capi.Batch(ctx, Ts, Ss, 128, precision=precision, max_iters=iters)
+        assert batch.streams == streams
+        batch.set_option(_capi.OPT_CHECK_EVERY, 3)
+        batch.profile_kernels(['chunk_post'])
+        for j, (X, Phi, g0) in enumerate(recs):
+            batch.set_recording(j, X, Phi, np.ones(Ss[j]) / Ss[j], g0, 0.9, 0.3, 17.0)
+        batch.run(iters, epsilon)
+        out = [batch.result(j) for j in range(len(Ts))]
+        launches = batch.kernel_times()['chunk_post'][1]
+        batch.close()
+        return out, launches
+
+    for epsilon, iters in ((-np.inf, 5), (1e-3, 30)):
+        plain, n1 = run(1, epsilon, iters)
+        for streams in (2, 3, 4):
+            grouped, nk = run(streams, epsilon, iters)
+            assert nk <= streams * n1 and (epsilon > -1 or nk == streams * n1)
+            for j in range(len(Ts)):
+                a, b = grouped[j], plain[j]
+                assert len(a['Li']) == len(b['Li']), (streams, j)
+                assert np.abs(a['gamma'] - b['gamma']).max() <= tol, (streams, j, np.abs(a['gamma'] - b['gamma']).max())
+                assert np.abs(a['pi'] - b['pi']).max() <= tol and rel_err(a['Li'], b['Li']) <= tol, (streams, j)
+                assert np.abs(a['alpha'] - b['alpha']).max() <= tol * max(1.0, np.abs(b['alpha']).max()), (streams, j)
+    # the option: a group can be rebuilt before the first recording is set, not after; a plain batch stays plain
+    monkeypatch.setenv('VBX_AMD_STREAMS', '2')
+    batch = _capi.Batch(ctx, Ts, Ss, 128, precision=precision, max_iters=2)
+    batch.set_option(_capi.OPT_STREAMS, 3)
+    assert batch.streams == 3
+    X, Phi, g0 = recs[0]
+    batch.set_recording(0, X, Phi, np.ones(Ss[0]) / Ss[0], g0, 0.9, 0.3, 17.0)
+    with pytest.raises(_capi.VbxError):
+        batch.set_option(_capi.OPT_STREAMS, 2)
+    with pytest.raises(_capi.VbxError):
+        batch.run(2, -np.inf)                                   # recordings 1.. are not set
+    batch.close()
+    monkeypatch.setenv('VBX_AMD_STREAMS', '1')
+    plain = _capi.Batch(ctx, Ts[:2], Ss[:2], 128, precision=precision, max_iters=2)
+    with pytest.raises(_capi.VbxError):
+        plain.set_option(_capi.OPT_STREAMS, 2)
+    plain.close()

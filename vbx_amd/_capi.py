@@ -13,7 +13,7 @@ VBX_F32, VBX_F64 = 0, 1
 PREC_FP32, PREC_FP64 = 0, 1
 FB_AUTO, FB_SEQUENTIAL, FB_CHUNKED = 0, 1, 2
 OPT_FB_ALGO, OPT_CHECK_EVERY, OPT_PROFILE, OPT_CHUNK_FRAMES, OPT_FUSE, OPT_SCAN_GROUP = 1, 2, 3, 4, 5, 6
-OPT_HALF_CHUNKS, OPT_TWO_LEVEL_FROM, OPT_POST_KERNEL = 7, 8, 9
+OPT_HALF_CHUNKS, OPT_TWO_LEVEL_FROM, OPT_POST_KERNEL, OPT_STREAMS = 7, 8, 9, 10
 K_NAMES = ['prep', 'mstep_acc', 'mstep_fin', 'loglik', 'fb', 'fb_aux', 'post', 'iter_fin', 'chunk_loglik',
            'chunk_post']
 MAX_SPEAKERS = 256
@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     'vbx_batch_run', 'vbx_batch_get_result', 'vbx_batch_last_run_ms', 'vbx_batch_kernel_times',
     'vbx_run', 'vbx_forward_backward', 'vbx_mstep', 'vbx_loglik',
     'vbx_cos_similarity', 'vbx_scores_upload', 'vbx_scores_count', 'vbx_scores_get', 'vbx_scores_get_condensed',
-    'vbx_linkage_average', 'vbx_fcluster_distance', 'vbx_ark_index',
+    'vbx_linkage_average', 'vbx_fcluster_distance', 'vbx_ark_index', 'vbx_batch_streams',
     'vbx_scores_two_gmm_calib',
     'vbx_scores_destroy',
 ]
@@ -53,6 +53,7 @@ def load():
         except Exception as exc:  # a stale-but-present library is still usable on a box without hipcc
             if not os.path.exists(path):
                 raise VbxError(f'libvbx_hip.so is not built and cannot be built here: {exc}') from exc
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')      # before the HIP runtime starts (see vbx_capi.hip)
     lib = C.CDLL(path)
     vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     lib.vbx_abi_version.restype = C.c_int
@@ -71,6 +72,7 @@ def load():
                                          C.POINTER(C.c_int), vp, vp]
     lib.vbx_batch_last_run_ms.argtypes = [vp, C.POINTER(dbl), C.POINTER(C.c_int)]
     lib.vbx_batch_kernel_times.argtypes = [vp, vp, vp]
+    lib.vbx_batch_streams.argtypes = [vp]
     lib.vbx_run.argtypes = [vp, vp, vp]
     lib.vbx_forward_backward.argtypes = [vp, i64, i32, vp, vp, vp, dbl, C.c_int, C.c_int, vp, C.POINTER(dbl),
                                          vp, vp, vp]
@@ -310,6 +312,11 @@ class Batch:
         ms, it = C.c_double(), C.c_int()
         self.ctx.check(self._lib.vbx_batch_last_run_ms(self._h, C.byref(ms), C.byref(it)), 'vbx_batch_last_run_ms')
         return ms.value, it.value
+
+    @property
+    def streams(self) -> int:
+        """HIP streams (sub-batches) this batch runs on (VBX_OPT_STREAMS in effect)."""
+        return int(self._lib.vbx_batch_streams(self._h))
 
     def kernel_times(self):
         ms = np.zeros(len(K_NAMES))
