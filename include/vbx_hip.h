@@ -67,8 +67,9 @@ extern "C" {
                                    re-run waves, gamma^T rho fed from registers (f32, <= 32 states, D <= 128; else 1) */
 #define VBX_OPT_STREAMS 10      /* HIP streams of a batch: its recordings are dealt to that many sub-batches, one
                                    iteration of each is launched stream after stream, so the latency-bound launches of
-                                   one overlap the bandwidth-bound ones of the others.  0 = auto (3 from 24 recordings,
-                                   2 from 12, else 1; env VBX_AMD_STREAMS overrides).  Before the first recording. */
+                                   one overlap the bandwidth-bound ones of the others.  0 = auto (3 from 24 recordings and
+                                   1536 chunks, 2 from 12 and 768, else 1; env VBX_AMD_STREAMS overrides).  Before the
+                                   first recording. */
 #define VBX_OPT_HALF_CHUNKS 7   /* 1: the fused kernels use one transfer operator / boundary pair per HALF tile (64
                                    frames) and re-run the halves on separate waves; 0 (default): per tile.  Halves
                                    the chunk kernels' dependent chains, doubles the boundary walk: a wash overall */

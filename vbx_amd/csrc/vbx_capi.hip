@@ -916,7 +916,7 @@ static int leaf_kernel_times(vbx_batch* b, double* ms, int64_t* launches) {
 // ---------------------------------------------------------------------------------------
 // public batch API: a plain batch (one stream) or a stream group of plain batches
 // ---------------------------------------------------------------------------------------
-static int auto_streams(int n_rec) {
+static int auto_streams(int n_rec, long long tiles) {
     const char* env = std::getenv("VBX_AMD_STREAMS");
     if (env && *env) {
         const int k = std::atoi(env);
@@ -924,7 +924,8 @@ static int auto_streams(int n_rec) {
     }
     // measured on 64 recordings of T = 10 000: 1 / 2 / 3 / 4 streams = 341 / 321 / 312 / 334 us per
     // iteration (three is the robust optimum: the fourth stream brought nothing in any queue configuration tried)
-    return n_rec >= 24 ? 3 : n_rec >= 12 ? 2 : 1;
+    // -- and only when every stream still has several rounds of workgroups per launch (a chunk = one workgroup)
+    return (n_rec >= 24 && tiles >= 1536) ? 3 : (n_rec >= 12 && tiles >= 768) ? 2 : 1;
 }
 
 static void group_clear(vbx_batch* b) {
@@ -1006,7 +1007,9 @@ int vbx_batch_create(vbx_ctx* ctx, int n_rec, const int64_t* T, const int32_t* S
                      int max_iters, vbx_batch** out) {
     if (!ctx) return VBX_ERR_INVALID;
     if (!out || !T || !S || n_rec <= 0) FAIL(ctx, VBX_ERR_INVALID, "vbx_batch_create: bad argument");
-    const int K = auto_streams(n_rec);
+    long long tiles = 0;
+    for (int i = 0; i < n_rec; ++i) tiles += T[i] > 0 ? (T[i] + kTileFrames - 1) / kTileFrames : 0;
+    const int K = auto_streams(n_rec, tiles);
     if (K <= 1) return leaf_create(ctx, n_rec, T, S, D, precision, max_iters, out);
     *out = nullptr;
     vbx_batch* b = new vbx_batch();
@@ -1040,7 +1043,9 @@ int vbx_batch_set_option(vbx_batch* b, int option, int64_t value) {
     if (option == VBX_OPT_STREAMS) {
         if (value < 0 || value > 8) FAIL(b->ctx, VBX_ERR_INVALID, "VBX_OPT_STREAMS takes 0 (auto) .. 8");
         const bool group = !b->kids.empty();
-        const int want = value == 0 ? auto_streams(b->n_rec) : (int)std::min<int64_t>(value, b->n_rec);
+        long long tiles = 0;
+        for (int64_t t : b->all_T) tiles += (t + kTileFrames - 1) / kTileFrames;
+        const int want = value == 0 ? auto_streams(b->n_rec, tiles) : (int)std::min<int64_t>(value, b->n_rec);
         const int have = group ? (int)b->kids.size() : 1;
         if (want == have) return VBX_OK;
         if (!group) FAIL(b->ctx, VBX_ERR_STATE, "VBX_OPT_STREAMS: this batch was created as a plain batch (set VBX_AMD_STREAMS "
