@@ -14,10 +14,13 @@
 #include "vbx_ahc.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <mutex>
+#include <condition_variable>
 #include <thread>
 #include <vector>
 
@@ -69,6 +72,17 @@ struct EventPair {
     hipEvent_t a, b;
 };
 
+struct GroupThreads {
+    std::mutex m;
+    std::condition_variable go, done;
+    long long generation = 0;
+    int pending = 0, max_iters = 0;
+    double epsilon = 0.0;
+    bool quit = false;
+    std::vector<int> rc;
+    std::vector<std::thread> workers;
+};
+
 struct vbx_batch {
     vbx_ctx* ctx = nullptr;
     // Stream groups (VBX_OPT_STREAMS): a batch of many recordings is a parent that owns no device memory but K
@@ -83,6 +97,7 @@ struct vbx_batch {
     std::vector<int32_t> all_S;
     std::vector<std::pair<int, int64_t>> options; // options set so far (replayed when the kids are rebuilt)
     int streams = 0;                              // option: 0 auto, >= 1 explicit
+    struct GroupThreads* threads = nullptr;       // one sleeping host thread per kid beyond the first
     bool any_set = false;
     int n_rec = 0, D = 0, Dp = 0, Sp = 0, NT = 0, precision = 0, max_iters = 0;
     size_t rsize = 4;
@@ -928,7 +943,51 @@ static int auto_streams(int n_rec, long long tiles) {
     return (n_rec >= 24 && tiles >= 1536) ? 3 : (n_rec >= 12 && tiles >= 768) ? 2 : 1;
 }
 
+static int leaf_run(vbx_batch* b, int max_iters, double epsilon);
+
+static void group_stop_threads(vbx_batch* b) {
+    if (!b->threads) return;
+    {
+        std::lock_guard<std::mutex> lock(b->threads->m);
+        b->threads->quit = true;
+    }
+    b->threads->go.notify_all();
+    for (auto& w : b->threads->workers) w.join();
+    delete b->threads;
+    b->threads = nullptr;
+}
+
+static void group_start_threads(vbx_batch* b) {
+    const int K = (int)b->kids.size();
+    GroupThreads* g = new GroupThreads();
+    g->rc.assign(K, VBX_OK);
+    b->threads = g;
+    for (int k = 1; k < K; ++k)
+        g->workers.emplace_back([b, g, k]() {
+            long long seen = 0;
+            while (true) {
+                int max_iters;
+                double epsilon;
+                {
+                    std::unique_lock<std::mutex> lock(g->m);
+                    g->go.wait(lock, [&] { return g->quit || g->generation != seen; });
+                    if (g->quit) return;
+                    seen = g->generation;
+                    max_iters = g->max_iters;
+                    epsilon = g->epsilon;
+                }
+                const int rc = leaf_run(b->kids[k], max_iters, epsilon);
+                {
+                    std::lock_guard<std::mutex> lock(g->m);
+                    g->rc[k] = rc;
+                    if (--g->pending == 0) g->done.notify_one();
+                }
+            }
+        });
+}
+
 static void group_clear(vbx_batch* b) {
+    group_stop_threads(b);
     for (vbx_batch* k : b->kids) leaf_destroy(k);
     b->kids.clear();
     for (size_t i = 0; i < b->kid_ctx.size(); ++i) {
@@ -1000,6 +1059,7 @@ static int group_build(vbx_batch* b, int K) {
                 return rc;
             }
     }
+    group_start_threads(b);
     return VBX_OK;
 }
 
@@ -1082,12 +1142,23 @@ int vbx_batch_run(vbx_batch* b, int max_iters, double epsilon) {
     // stream) are issued in parallel and the streams drift out of phase by themselves.  Fed round-robin from ONE
     // thread (also with the streams started a fraction of a period apart) the same streams gave no gain at all.
     const int K = (int)b->kids.size();
-    std::vector<int> rcs(K, VBX_OK);
-    std::vector<std::thread> workers;
-    for (int k = 1; k < K; ++k)
-        workers.emplace_back([&, k]() { rcs[k] = leaf_run(b->kids[k], max_iters, epsilon); });
-    rcs[0] = leaf_run(b->kids[0], max_iters, epsilon);
-    for (auto& w : workers) w.join();
+    // The feeding threads are created with the group and sleep between runs: a VBx() call is a few dozen
+    // iterations, and starting three threads (with their first HIP call each) cost as much as two of them.
+    GroupThreads& g = *b->threads;
+    {
+        std::lock_guard<std::mutex> lock(g.m);
+        g.max_iters = max_iters;
+        g.epsilon = epsilon;
+        g.pending = K - 1;
+        ++g.generation;
+    }
+    g.go.notify_all();
+    g.rc[0] = leaf_run(b->kids[0], max_iters, epsilon);
+    {
+        std::unique_lock<std::mutex> lock(g.m);
+        g.done.wait(lock, [&] { return g.pending == 0; });
+    }
+    std::vector<int>& rcs = g.rc;
     b->last_ms = 0.0;
     b->iters_launched = 0;
     for (int k = 0; k < K; ++k) {
