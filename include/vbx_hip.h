@@ -229,6 +229,9 @@ int vbx_fcluster_distance(int64_t n, const double* Z, double t, int32_t* labels)
  * of entries; -1: not a well-formed binary vector archive; -2: more than `cap` entries. */
 int64_t vbx_ark_index(const void* buf, int64_t len, int64_t cap, int64_t* key_off, int32_t* key_len, int64_t* data_off,
                       int32_t* dim, int32_t* elem_size);
+/* n rows of row_bytes bytes each, row i starting at buf + offsets[i], packed into out (the vectors of one recording
+ * out of an indexed archive: `np.array(xvecs)` of vbhmm.py:123). */
+int vbx_gather_rows(const void* buf, int64_t len, const int64_t* offsets, int64_t n, int64_t row_bytes, void* out);
 /* Two-Gaussian shared-variance EM over all the scores: threshold, and (llr != NULL) the linearly calibrated
  * log-odds of every score, [vbx_scores_count]. */
 int vbx_scores_two_gmm_calib(vbx_scores* sc, int32_t niters, double* threshold, double* llr);

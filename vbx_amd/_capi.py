@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     'vbx_batch_run', 'vbx_batch_get_result', 'vbx_batch_last_run_ms', 'vbx_batch_kernel_times',
     'vbx_run', 'vbx_forward_backward', 'vbx_mstep', 'vbx_loglik',
     'vbx_cos_similarity', 'vbx_scores_upload', 'vbx_scores_count', 'vbx_scores_get', 'vbx_scores_get_condensed',
-    'vbx_linkage_average', 'vbx_fcluster_distance', 'vbx_ark_index', 'vbx_batch_streams',
+    'vbx_linkage_average', 'vbx_fcluster_distance', 'vbx_ark_index', 'vbx_gather_rows', 'vbx_batch_streams',
     'vbx_scores_two_gmm_calib',
     'vbx_scores_destroy',
 ]
@@ -87,6 +87,7 @@ def load():
     lib.vbx_fcluster_distance.argtypes = [i64, vp, dbl, vp]
     lib.vbx_ark_index.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp]
     lib.vbx_ark_index.restype = i64
+    lib.vbx_gather_rows.argtypes = [vp, i64, vp, i64, i64, vp]
     lib.vbx_scores_two_gmm_calib.argtypes = [vp, i32, C.POINTER(dbl), vp]
     lib.vbx_scores_destroy.argtypes = [vp]
     for name in ABI_SYMBOLS:
@@ -385,6 +386,16 @@ def ark_index(buf):
         if n < 0:
             return None
         return ko[:n], kl[:n], do[:n], dm[:n], es[:n]
+
+
+def gather_rows(raw, offsets, row_bytes, dtype):
+    """``len(offsets)`` rows of ``row_bytes`` bytes of the uint8 array ``raw`` packed into a new 2-D array of ``dtype``."""
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    out = np.empty((offsets.size, row_bytes // np.dtype(dtype).itemsize), dtype=dtype)
+    rc = load().vbx_gather_rows(_ptr(raw), raw.size, _ptr(offsets), offsets.size, int(row_bytes), _ptr(out))
+    if rc != 0:
+        raise VbxError(f'vbx_gather_rows failed ({rc}): offsets outside the buffer')
+    return out
 
 
 def fcluster_distance(Z, t):

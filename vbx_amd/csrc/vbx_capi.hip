@@ -1522,6 +1522,17 @@ int64_t vbx_ark_index(const void* buf, int64_t len, int64_t cap, int64_t* key_of
     return vbx::ark_index(static_cast<const unsigned char*>(buf), len, cap, key_off, key_len, data_off, dim, elem_size);
 }
 
+int vbx_gather_rows(const void* buf, int64_t len, const int64_t* offsets, int64_t n, int64_t row_bytes, void* out) {
+    if (!buf || !out || !offsets || n < 0 || row_bytes < 0) return VBX_ERR_INVALID;
+    const unsigned char* src = static_cast<const unsigned char*>(buf);
+    unsigned char* dst = static_cast<unsigned char*>(out);
+    for (int64_t i = 0; i < n; ++i) {
+        if (offsets[i] < 0 || offsets[i] + row_bytes > len) return VBX_ERR_INVALID;
+        std::memcpy(dst + i * row_bytes, src + offsets[i], (size_t)row_bytes);
+    }
+    return VBX_OK;
+}
+
 int vbx_fcluster_distance(int64_t n, const double* Z, double t, int32_t* labels) {
     if (n < 1 || !labels || (n > 1 && !Z)) return VBX_ERR_INVALID;
     for (int64_t k = 0; k < n - 1; ++k) {                      // children exist before their parent, ids in range

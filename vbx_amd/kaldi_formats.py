@@ -106,8 +106,7 @@ def read_vec_flt_ark_grouped(path, group_key=lambda key: key.rsplit('_', 1)[0]):
             d, e = int(dim[lo]), int(esize[lo])
             if np.any(dim[lo:hi] != d) or np.any(esize[lo:hi] != e):
                 raise ValueError(f'x-vectors of {groups[lo]} differ in dimension or type')
-            gather = data_off[lo:hi, None] + np.arange(d * e, dtype=np.int64)[None, :]
-            mat = buf[gather].view('<f4' if e == 4 else '<f8')
+            mat = _capi.gather_rows(buf, data_off[lo:hi], d * e, '<f4' if e == 4 else '<f8')
             out.append((groups[lo], np.array(keys[lo:hi]), mat))
             lo = hi
     return out
