@@ -943,8 +943,6 @@ static int auto_streams(int n_rec, long long tiles) {
     return (n_rec >= 24 && tiles >= 1536) ? 3 : (n_rec >= 12 && tiles >= 768) ? 2 : 1;
 }
 
-static int leaf_run(vbx_batch* b, int max_iters, double epsilon);
-
 static void group_stop_threads(vbx_batch* b) {
     if (!b->threads) return;
     {

@@ -15,6 +15,9 @@
 //
 // 16 + 8 + 8 KB at SP = 32 -> five workgroups per CU by LDS.  The rho fragments of the accumulation are no
 // longer held in registers across the re-run (64 registers); they are fetched in quarters, one quarter ahead.
+// Instrumentation builds: -DVBX_PHASE_CLOCKS (per-workgroup phase stamps, tools/phase_timeline.py) and
+// -DVBX_EXPERIMENT_SKIP_RERUN (elimination run of DESIGN section 10: the kernel without its re-run loops; the
+// results are garbage, only the timing means something).
 #pragma once
 #include "vbx_fused.hpp"
 

@@ -167,11 +167,7 @@ __global__ __launch_bounds__(512) void chunk_post_quad_kernel(BatchView<R> bt) {
     // The two re-run waves go first, while the CU's memory queue is empty: a request issued behind the 192 of the
     // other six waves stalls the issuing wave until those have drained (measured: 13 k cycles).
     if (wave >= 2) __builtin_amdgcn_s_sleep(32);
-#ifdef VBX_EXPERIMENT_NO_OWN_LOADS
-    if (p_len > 0 && wave >= VBX_EXPERIMENT_NO_OWN_LOADS) load_rho();
-#else
     if (p_len > 0) load_rho();
-#endif
 
     // ---- re-run: wave 0 forward, wave 1 backward, lane row = tile ---------------------------------------------
     R* const bls = bl + g4 * TS + so;
