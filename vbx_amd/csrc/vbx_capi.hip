@@ -45,6 +45,10 @@ struct vbx_ctx {
     hipStream_t stream = nullptr;
     hipDeviceProp_t prop;
     std::string err;
+    // Device blocks of the score stage (vbx_cos_similarity ... vbx_scores_destroy) are recycled: a driver runs it once
+    // per recording, and eight hipMalloc / hipFree pairs (each hipFree waits for the device) cost more than its kernels.
+    std::vector<std::pair<void*, size_t>> spare;              // (block, bytes), kept until vbx_destroy
+    size_t spare_bytes = 0;
 };
 
 #define HIPCHK(ctx_, call)                                                                    \
@@ -374,6 +378,38 @@ int dmalloc_bytes(vbx_ctx* ctx, void** p, size_t bytes) {
     return VBX_OK;
 }
 
+// a block of at least `count` elements from the ctx's spare list (smallest that fits, at most 2x too large), else new
+template <typename T> int scratch_get(vbx_ctx* ctx, T** p, size_t count, size_t* got_bytes) {
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    int best = -1;
+    for (int i = 0; i < (int)ctx->spare.size(); ++i)
+        if (ctx->spare[i].second >= bytes && ctx->spare[i].second <= 2 * bytes + 4096 &&
+            (best < 0 || ctx->spare[i].second < ctx->spare[best].second))
+            best = i;
+    if (best >= 0) {
+        *p = static_cast<T*>(ctx->spare[best].first);
+        *got_bytes = ctx->spare[best].second;
+        ctx->spare_bytes -= ctx->spare[best].second;
+        ctx->spare.erase(ctx->spare.begin() + best);
+        return VBX_OK;
+    }
+    *got_bytes = bytes;
+    HIPCHK(ctx, hipMalloc((void**)p, bytes));
+    return VBX_OK;
+}
+
+// back to the spare list (work queued on the ctx stream that still uses the block stays ordered before its next
+// use: every user of the list runs on that stream); beyond 4 GB of spares the block is freed
+void scratch_put(vbx_ctx* ctx, void* p, size_t bytes) {
+    if (!p) return;
+    if (ctx->spare_bytes + bytes > ((size_t)4 << 30) || ctx->spare.size() >= 32) {
+        (void)hipFree(p);
+        return;
+    }
+    ctx->spare.emplace_back(p, bytes);
+    ctx->spare_bytes += bytes;
+}
+
 // Decide between the sequential walk and the chunked scan, allocating the scan buffers on first use.
 int choose_fb_algo(vbx_batch* b, bool step_api_logs) {
     int maxtiles = 0;
@@ -524,6 +560,7 @@ int vbx_create(vbx_ctx** out, int device) {
 int vbx_destroy(vbx_ctx* ctx) {
     if (!ctx) return VBX_OK;
     (void)hipSetDevice(ctx->device);
+    for (auto& sp : ctx->spare) (void)hipFree(sp.first);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return VBX_OK;
@@ -1417,6 +1454,7 @@ struct vbx_scores {
     vbx_ctx* ctx = nullptr;
     long long n = 0;
     double* d_s = nullptr;
+    size_t d_s_bytes = 0;
 };
 
 extern "C" {
@@ -1424,7 +1462,7 @@ extern "C" {
 int vbx_scores_destroy(vbx_scores* sc) {
     if (!sc) return VBX_OK;
     (void)hipSetDevice(sc->ctx->device);
-    if (sc->d_s) (void)hipFree(sc->d_s);
+    scratch_put(sc->ctx, sc->d_s, sc->d_s_bytes);
     delete sc;
     return VBX_OK;
 }
@@ -1442,9 +1480,10 @@ int vbx_cos_similarity(vbx_ctx* ctx, int64_t T, int32_t D, const double* x, vbx_
     vbx_scores* sc = new vbx_scores();
     sc->ctx = ctx;
     sc->n = (long long)T * T;
-    int rc = dmalloc(ctx, &d_x, (size_t)T * D);
-    if (rc == VBX_OK) rc = dmalloc(ctx, &d_xn, (size_t)T * Dp);
-    if (rc == VBX_OK) rc = dmalloc(ctx, &sc->d_s, (size_t)sc->n);
+    size_t x_bytes = 0, xn_bytes = 0;
+    int rc = scratch_get(ctx, &d_x, (size_t)T * D, &x_bytes);
+    if (rc == VBX_OK) rc = scratch_get(ctx, &d_xn, (size_t)T * Dp, &xn_bytes);
+    if (rc == VBX_OK) rc = scratch_get(ctx, &sc->d_s, (size_t)sc->n, &sc->d_s_bytes);
     hipError_t e = hipSuccess;
     if (rc == VBX_OK) {
         e = hipMemcpyAsync(d_x, x, sizeof(double) * (size_t)T * D, hipMemcpyHostToDevice, ctx->stream);
@@ -1461,8 +1500,8 @@ int vbx_cos_similarity(vbx_ctx* ctx, int64_t T, int32_t D, const double* x, vbx_
             rc = VBX_ERR_HIP;
         }
     }
-    if (d_x) (void)hipFree(d_x);
-    if (d_xn) (void)hipFree(d_xn);
+    scratch_put(ctx, d_x, x_bytes);
+    scratch_put(ctx, d_xn, xn_bytes);
     if (rc != VBX_OK) {
         vbx_scores_destroy(sc);
         return rc;
@@ -1479,7 +1518,7 @@ int vbx_scores_upload(vbx_ctx* ctx, int64_t n, const double* s, vbx_scores** out
     vbx_scores* sc = new vbx_scores();
     sc->ctx = ctx;
     sc->n = n;
-    int rc = dmalloc(ctx, &sc->d_s, (size_t)n);
+    int rc = scratch_get(ctx, &sc->d_s, (size_t)n, &sc->d_s_bytes);
     if (rc == VBX_OK) {
         hipError_t e = hipMemcpy(sc->d_s, s, sizeof(double) * (size_t)n, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
@@ -1553,12 +1592,13 @@ int vbx_scores_get_condensed(vbx_scores* sc, int64_t T, double scale, double* ou
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t m = (size_t)T * (size_t)(T - 1) / 2;
     double* d_c = nullptr;
-    int rc = dmalloc(ctx, &d_c, m);
+    size_t c_bytes = 0;
+    int rc = scratch_get(ctx, &d_c, m, &c_bytes);
     if (rc != VBX_OK) return rc;
     hipLaunchKernelGGL(vbx::condense_kernel, dim3((unsigned)(T - 1)), dim3(256), 0, ctx->stream, sc->d_s, d_c, (long long)T, scale);
     hipError_t e = hipMemcpyAsync(out, d_c, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_c);
+    scratch_put(ctx, d_c, c_bytes);
     if (e != hipSuccess) {
         ctx->err = std::string("vbx_scores_get_condensed: ") + hipGetErrorString(e);
         return VBX_ERR_HIP;
@@ -1574,9 +1614,10 @@ int vbx_scores_two_gmm_calib(vbx_scores* sc, int32_t niters, double* threshold, 
     hipStream_t st = ctx->stream;
     const int nb = (int)std::min<long long>(vbx::kGmmPartials, (sc->n + 255) / 256);
     double *d_par = nullptr, *d_part = nullptr, *d_llr = nullptr;
-    int rc = dmalloc(ctx, &d_par, 16);
-    if (rc == VBX_OK) rc = dmalloc(ctx, &d_part, (size_t)nb * 6);
-    if (rc == VBX_OK && llr) rc = dmalloc(ctx, &d_llr, (size_t)sc->n);
+    size_t par_bytes = 0, part_bytes = 0, llr_bytes = 0;
+    int rc = scratch_get(ctx, &d_par, 16, &par_bytes);
+    if (rc == VBX_OK) rc = scratch_get(ctx, &d_part, (size_t)nb * 6, &part_bytes);
+    if (rc == VBX_OK && llr) rc = scratch_get(ctx, &d_llr, (size_t)sc->n, &llr_bytes);
     double par[16];
     hipError_t e = hipSuccess;
     if (rc == VBX_OK) {
@@ -1604,8 +1645,9 @@ int vbx_scores_two_gmm_calib(vbx_scores* sc, int32_t niters, double* threshold, 
         const double t0 = std::log(w0 * w0 / var) - m0 * m0 / var, t1 = std::log(w1 * w1 / var) - m1 * m1 / var;
         *threshold = -0.5 * (t0 - t1) / (m0 / var - m1 / var);
     }
-    for (double* p : {d_par, d_part, d_llr})
-        if (p) (void)hipFree(p);
+    scratch_put(ctx, d_par, par_bytes);
+    scratch_put(ctx, d_part, part_bytes);
+    scratch_put(ctx, d_llr, llr_bytes);
     return rc;
 }
 
