@@ -22,6 +22,7 @@
 #include <mutex>
 #include <condition_variable>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 using namespace vbx;
@@ -45,10 +46,13 @@ struct vbx_ctx {
     hipStream_t stream = nullptr;
     hipDeviceProp_t prop;
     std::string err;
-    // Device blocks of the score stage (vbx_cos_similarity ... vbx_scores_destroy) are recycled: a driver runs it once
-    // per recording, and eight hipMalloc / hipFree pairs (each hipFree waits for the device) cost more than its kernels.
+    // Device blocks are recycled: the reference's usage is one VBx() call (one batch of ~35 buffers) and one score
+    // stage (8 buffers) per recording, and that many hipMalloc / hipFree pairs (each hipFree waits for the device)
+    // cost more than the kernels of a short recording.
     std::vector<std::pair<void*, size_t>> spare;              // (block, bytes), kept until vbx_destroy
     size_t spare_bytes = 0;
+    std::unordered_map<void*, size_t> live;                    // blocks handed out by ctx_alloc
+    bool recycle = true;                                       // false for the private ctx of a stream-group kid
 };
 
 #define HIPCHK(ctx_, call)                                                                    \
@@ -369,46 +373,53 @@ void launch_prep(vbx_batch* b, const RecDesc& rd) {
                        b->D, b->Dp);
 }
 
-template <typename T> int dmalloc(vbx_ctx* ctx, T** p, size_t count) {
-    HIPCHK(ctx, hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T)));
-    return VBX_OK;
-}
-int dmalloc_bytes(vbx_ctx* ctx, void** p, size_t bytes) {
-    HIPCHK(ctx, hipMalloc(p, std::max<size_t>(bytes, 16)));
-    return VBX_OK;
-}
-
-// a block of at least `count` elements from the ctx's spare list (smallest that fits, at most 2x too large), else new
-template <typename T> int scratch_get(vbx_ctx* ctx, T** p, size_t count, size_t* got_bytes) {
-    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
-    int best = -1;
-    for (int i = 0; i < (int)ctx->spare.size(); ++i)
-        if (ctx->spare[i].second >= bytes && ctx->spare[i].second <= 2 * bytes + 4096 &&
-            (best < 0 || ctx->spare[i].second < ctx->spare[best].second))
-            best = i;
-    if (best >= 0) {
-        *p = static_cast<T*>(ctx->spare[best].first);
-        *got_bytes = ctx->spare[best].second;
-        ctx->spare_bytes -= ctx->spare[best].second;
-        ctx->spare.erase(ctx->spare.begin() + best);
-        return VBX_OK;
+// A block of at least `bytes` bytes: the smallest spare one that fits (and is at most twice too large), else a new one.
+int ctx_alloc(vbx_ctx* ctx, void** p, size_t bytes) {
+    bytes = std::max<size_t>(bytes, 16);
+    if (ctx->recycle) {
+        int best = -1;
+        for (int i = 0; i < (int)ctx->spare.size(); ++i)
+            if (ctx->spare[i].second >= bytes && ctx->spare[i].second <= 2 * bytes + 4096 &&
+                (best < 0 || ctx->spare[i].second < ctx->spare[best].second))
+                best = i;
+        if (best >= 0) {
+            *p = ctx->spare[best].first;
+            ctx->live[*p] = ctx->spare[best].second;
+            ctx->spare_bytes -= ctx->spare[best].second;
+            ctx->spare.erase(ctx->spare.begin() + best);
+            return VBX_OK;
+        }
     }
-    *got_bytes = bytes;
-    HIPCHK(ctx, hipMalloc((void**)p, bytes));
+    HIPCHK(ctx, hipMalloc(p, bytes));
+    ctx->live[*p] = bytes;
     return VBX_OK;
 }
 
-// back to the spare list (work queued on the ctx stream that still uses the block stays ordered before its next
-// use: every user of the list runs on that stream); beyond 4 GB of spares the block is freed
-void scratch_put(vbx_ctx* ctx, void* p, size_t bytes) {
+// Back to the spare list.  Work queued on the ctx stream that still touches the block stays ordered before its next
+// use (every user of the list runs on that stream or has waited for it); beyond 4 GB / 256 spares the block is freed.
+void ctx_free(vbx_ctx* ctx, void* p) {
     if (!p) return;
-    if (ctx->spare_bytes + bytes > ((size_t)4 << 30) || ctx->spare.size() >= 32) {
+    auto it = ctx->live.find(p);
+    const size_t bytes = it == ctx->live.end() ? 0 : it->second;
+    if (it != ctx->live.end()) ctx->live.erase(it);
+    if (!ctx->recycle || bytes == 0 || ctx->spare_bytes + bytes > ((size_t)4 << 30) || ctx->spare.size() >= 256) {
         (void)hipFree(p);
         return;
     }
     ctx->spare.emplace_back(p, bytes);
     ctx->spare_bytes += bytes;
 }
+
+template <typename T> int dmalloc(vbx_ctx* ctx, T** p, size_t count) {
+    return ctx_alloc(ctx, (void**)p, std::max<size_t>(count, 1) * sizeof(T));
+}
+int dmalloc_bytes(vbx_ctx* ctx, void** p, size_t bytes) { return ctx_alloc(ctx, p, bytes); }
+
+template <typename T> int scratch_get(vbx_ctx* ctx, T** p, size_t count, size_t* got_bytes) {
+    *got_bytes = 0;
+    return ctx_alloc(ctx, (void**)p, std::max<size_t>(count, 1) * sizeof(T));
+}
+void scratch_put(vbx_ctx* ctx, void* p, size_t) { ctx_free(ctx, p); }
 
 // Decide between the sequential walk and the chunked scan, allocating the scan buffers on first use.
 int choose_fb_algo(vbx_batch* b, bool step_api_logs) {
@@ -455,8 +466,7 @@ int choose_fb_algo(vbx_batch* b, bool step_api_logs) {
             group = std::max(4, (int)std::lround(std::sqrt((double)maxchunks)));
     }
     if (group != b->sgroup || spt != b->spt || (group > 1 && !b->d_sop)) {
-        for (void* p : {(void*)b->d_sop, (void*)b->d_sopexp, (void*)b->d_sup_rec, (void*)b->d_sup_idx})
-            if (p) (void)hipFree(p);
+        for (void* p : {(void*)b->d_sop, (void*)b->d_sopexp, (void*)b->d_sup_rec, (void*)b->d_sup_idx}) ctx_free(b->ctx, p);
         b->d_sop = nullptr; b->d_sopexp = nullptr; b->d_sup_rec = nullptr; b->d_sup_idx = nullptr;
         b->sgroup = group;
         b->spt = spt;
@@ -584,8 +594,8 @@ static int leaf_destroy(vbx_batch* b) {
                     b->d_bias, b->d_mpart, b->d_npart, b->d_lraw, b->d_emodel, b->d_pi, b->d_epart, b->d_Li,
                     b->d_xstage, b->d_ip, b->d_fw_scale, b->d_bw_scale, b->d_op, b->d_fbound, b->d_gbound,
                     b->d_opexp, b->d_tllpart, b->d_sfw, b->d_dump, b->d_sop, b->d_sopexp, b->d_sup_rec, b->d_sup_idx};
-    for (void* p : ptrs)
-        if (p) (void)hipFree(p);
+    (void)hipStreamSynchronize(b->ctx->stream);               // nothing of this batch may still be running when its
+    for (void* p : ptrs) ctx_free(b->ctx, p);                 // blocks go back to the spare list
     if (b->ev_start) (void)hipEventDestroy(b->ev_start);
     if (b->ev_stop) (void)hipEventDestroy(b->ev_stop);
     for (auto& ep : b->ev_pool) {
@@ -1059,6 +1069,10 @@ static int group_build(vbx_batch* b, int K) {
         std::sort(members[k].begin(), members[k].end());
         vbx_ctx* kc = new vbx_ctx(*ctx);
         kc->err.clear();
+        kc->spare.clear();
+        kc->spare_bytes = 0;
+        kc->live.clear();
+        kc->recycle = false;
         if (k > 0) {
             kc->stream = nullptr;
             hipError_t e = hipStreamCreateWithFlags(&kc->stream, hipStreamNonBlocking);
