@@ -355,3 +355,31 @@ def test_grouped_archive_reader_equals_the_entry_by_entry_reader(tmp_path):
     kf.write_segments(seg, [('NA_000-x', 'NA', 0.0, 1.0), ('nan_1', 'nan', 1.0, 2.5)])      # names a CSV parser may eat
     d = kf.read_xvector_timing_dict(seg)
     assert list(d) == ['NA', 'nan'] and d['NA'][0].tolist() == ['NA_000-x'] and np.array_equal(d['nan'][1], [[1.0, 2.5]])
+
+
+def test_native_clustering_randomised_against_scipy():
+    """400 random condensed matrices (Gaussian, small-integer, one-decimal and cosine distances: from no ties to almost
+    only ties), n = 2 .. 119: linkage matrix and distance cut equal SciPy's in every case."""
+    from scipy.cluster.hierarchy import fcluster, linkage
+    from vbx_amd import _capi
+    rng = np.random.default_rng(123)
+    for trial in range(400):
+        n = int(rng.integers(2, 120))
+        m = n * (n - 1) // 2
+        kind = trial % 4
+        if kind == 0:
+            y = rng.standard_normal(m)
+        elif kind == 1:
+            y = rng.integers(0, 3, m).astype(float)
+        elif kind == 2:
+            y = np.round(rng.standard_normal(m), 1)
+        else:
+            x = rng.standard_normal((n, 3))
+            x /= np.linalg.norm(x, axis=1, keepdims=True)
+            y = np.ascontiguousarray(-(x @ x.T)[np.triu_indices(n, 1)])
+        want = linkage(y, 'average')
+        got = _capi.linkage_average(y)
+        assert np.array_equal(got, want) and np.array_equal(np.signbit(got), np.signbit(want)), (trial, n, kind)
+        want[:, 2] += abs(want[:, 2].min())
+        t = float(rng.choice(want[:, 2])) if rng.random() < 0.7 else float(abs(rng.standard_normal()))
+        assert np.array_equal(_capi.fcluster_distance(want, t), fcluster(want, t, criterion='distance')), (trial, t)
