@@ -10,15 +10,20 @@
 //     the same ~16 issue slots per frame now advance four tiles.  Wave 0 = forward, wave 1 = backward,
 //     meet-in-the-middle layout of vbx_fused_mid.hpp with the midpoint fixed at frame 64;
 //   * eight waves, one workgroup per CU, 256 registers per wave: every wave requests the rho fragments of its
-//     share of the accumulation (tile, two 32-feature slabs = 128 registers) right after the b tiles, i.e. the
-//     64 KB of rho per tile cross the memory system WHILE the re-run runs and the MFMA phase starts with its
-//     operands in registers;
+//     share of the accumulation (one tile, every second k-step, all 128 features = 128 registers) behind the b
+//     tiles, i.e. the 64 KB of rho per tile cross the memory system WHILE the re-run runs, and gamma goes from
+//     the registers it is computed in straight into the MFMA as the A operand;
 //   * the tile table tile_desc = {recording, t0, frames, first row} and the per-tile convergence flag tile_done
 //     make every address of the first round of loads depend on one scalar load only.
 //
 // Short tiles (the tail of a recording) are padded with zero rows of b: the forward rows stay zero, the backward
 // recursion of such a row is (re)started at its last frame by a rarely taken variant of the four-frame block.
-// Results are those of chunk_post_kernel (same recursions, same order of the per-tile sums over frames).
+// Results are those of chunk_post_kernel up to the order of the gamma^T rho sum over the frames of a tile (even and odd
+// k-steps are accumulated by two waves and added at the end): tests/test_gpu_parity.py::test_chunk_post_variants_agree.
+//
+// Status: correct and tested, 171-175 us per launch of 64 recordings against 162-164 us of chunk_post_mid_kernel (the
+// default), for the reasons in DESIGN.md section 10; kept behind VBX_OPT_POST_KERNEL = 2 as the base of a pipelined
+// version.
 #pragma once
 #include <type_traits>
 
