@@ -83,19 +83,34 @@ def make_batch(ctx, n_rec, T, S, D, precision, seed0, max_iters, streams=None):
     return batch
 
 
-def cpu_baseline(T, S, D, iters):
-    """oracle (kind="port"): same algorithm and third-party calls as the reference's VBx.py."""
+def cpu_baseline(T, S, D, iters, precision='fp32'):
+    """oracle (kind="port"): same algorithm and third-party calls as the reference's VBx.py.  Timed on one core; its
+    first two iterations also serve BASELINE.json's second metric: max |gamma - gamma_NumPy| of the GPU path on the
+    same recording and initialisation (two iterations: further on, fp32 and fp64 EM trajectories drift apart by
+    themselves)."""
+    import contextlib
+    import io
     from oracle import vbx_oracle
     from vbx_amd.synth import make_recording
     X, Phi, _ = make_recording(T, S, D=D, seed=0, kappa=0.05)
     g = np.random.default_rng(10_000).gamma(1.0, size=(T, S))
     g /= g.sum(1, keepdims=True)
+    kw = dict(loopProb=0.99, Fa=0.3, Fb=17.0, pi=S, gamma=g, epsilon=-1e300)
     t0 = time.perf_counter()
-    vbx_oracle.VBx(X, Phi, loopProb=0.99, Fa=0.3, Fb=17.0, pi=S, gamma=g, maxIters=iters, epsilon=-1e300)
+    vbx_oracle.VBx(X, Phi, maxIters=iters, **kw)
     dt = time.perf_counter() - t0
-    return {'value': iters / dt, 'unit': 'EM iterations/s', 'cores': 1, 'kind': 'port',
-            'sample': f'{iters} iterations of one recording T={T} S={S} R={D} (float64, NumPy+SciPy logsumexp, '
-                      f'{dt:.1f} s on {os.cpu_count()} visible cores; the path is single-threaded)'}
+    out = {'value': iters / dt, 'unit': 'EM iterations/s', 'cores': 1, 'kind': 'port',
+           'sample': f'{iters} iterations of one recording T={T} S={S} R={D} (float64, NumPy+SciPy logsumexp, '
+                     f'{dt:.1f} s on {os.cpu_count()} visible cores; the path is single-threaded)'}
+    import vbx_amd
+    with contextlib.redirect_stdout(io.StringIO()):
+        g_ref, pi_ref, L_ref = vbx_oracle.VBx(X, Phi, maxIters=2, **kw)
+        g_gpu, pi_gpu, L_gpu = vbx_amd.VBx(X, Phi, maxIters=2, precision=precision, **kw)
+    out['parity_after_2_iterations'] = {
+        'gamma_max_abs_diff': float(np.abs(g_gpu - g_ref).max()), 'pi_max_abs_diff': float(np.abs(pi_gpu - pi_ref).max()),
+        'elbo_max_rel_diff': float(max(abs(a[0] - b[0]) / abs(b[0]) for a, b in zip(L_gpu, L_ref))),
+        'precision': precision, 'target': 1e-4}
+    return out
 
 
 def main():
@@ -265,7 +280,7 @@ def main():
         if single:
             out['single_recording'] = single
         if world == 1 and args.cpu_iters > 0:
-            cb = cpu_baseline(args.T, args.S, args.D, args.cpu_iters)
+            cb = cpu_baseline(args.T, args.S, args.D, args.cpu_iters, args.precision)
             out['cpu_baseline'] = cb
             if single:
                 out['single_recording']['speedup_vs_cpu_baseline'] = single['value'] / cb['value']
