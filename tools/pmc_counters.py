@@ -1,0 +1,68 @@
+#!/usr/bin/env python
+"""Per-kernel averages of every PMC counter in a rocprofv3 rocpd database (``--pmc A B C ...`` pass).
+
+    python tools/pmc_counters.py <results.db> [out.txt]
+
+Second half of the launches of each kernel only (the first ones include first-touch effects).  Ratios between SQ
+counters of one pass (e.g. SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES) are what they are good for; MI355X_MICROARCH.md
+("rocprofv3 PMC slots") lists the units."""
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    m = re.search(r'vbx::(\w+?)(?:_kernel)?<', name)
+    return m.group(1) if m else name[:40]
+
+
+def main(path, out=None):
+    db = sqlite3.connect(path)
+    rows = db.execute('select name, counter_name, counter_value from pmc_events').fetchall()
+    agg = {}
+    for name, cname, val in rows:
+        agg.setdefault(short(name), {}).setdefault(cname, []).append(float(val))
+    counters = sorted({c for k in agg.values() for c in k})
+    lines = ['# per-launch averages (second half of the launches of each kernel) from ' + path,
+             f'{"kernel":24s} {"launches":>8s} ' + ' '.join(f'{c:>26s}' for c in counters)]
+    for k, d in sorted(agg.items()):
+        n = max(len(v) for v in d.values())
+        vals = []
+        for c in counters:
+            v = d.get(c, [])
+            v = v[len(v) // 2:]
+            vals.append(sum(v) / len(v) if v else float('nan'))
+        lines.append(f'{k:24s} {n:8d} ' + ' '.join(f'{v:26.1f}' for v in vals))
+    if 'SQ_VALU_MFMA_BUSY_CYCLES' in counters:
+        # the counter is summed over the SIMDs of the unit a row belongs to; rows per launch x value = SIMD-cycles the
+        # matrix pipes were busy; over (1024 SIMDs x launch duration x 2.4 GHz) it is the chip-wide MFMA utilisation
+        cols = [r[1] for r in db.execute('pragma table_info(kernels)')]
+        name_col = 'name' if 'name' in cols else [c for c in cols if 'name' in c][0]
+        dur = {}
+        for name, st, en in db.execute(f'select {name_col}, start, end from kernels'):
+            dur.setdefault(short(name), []).append(en - st)
+        lines.append('')
+        lines.append('# kernel: MFMA-busy SIMD-cycles per launch, launch duration (us, under the profiler), MFMA utilisation of the')
+        lines.append('# chip (busy / (1024 SIMDs x duration x 2.4 GHz)), issue activity of the resident waves (ACTIVE_INST_ANY / WAVE_CYCLES)')
+        for k, d in sorted(agg.items()):
+            v = d.get('SQ_VALU_MFMA_BUSY_CYCLES', [])
+            launches = len(dur.get(k, [])) or 1
+            rows_per_launch = len(v) / launches
+            v = v[len(v) // 2:]
+            busy = (sum(v) / len(v) if v else 0.0) * rows_per_launch
+            dd = dur.get(k, [0])
+            dd = dd[len(dd) // 2:]
+            us = sum(dd) / len(dd) / 1e3
+            w = d.get('SQ_WAVE_CYCLES', [])
+            a = d.get('SQ_ACTIVE_INST_ANY', [])
+            act = (sum(a) / max(sum(w), 1.0)) if w and a else float('nan')
+            util = busy / (1024 * us * 2400.0) if us > 0 else float('nan')
+            lines.append(f'{k:24s} mfma_busy_simd_cycles {busy:14.0f}   duration_us {us:9.2f}   mfma_util {util:7.4f}   active/wave_cycles {act:7.4f}')
+    text = '\n'.join(lines) + '\n'
+    if out:
+        open(out, 'w').write(text)
+    print(text)
+
+
+if __name__ == '__main__':
+    main(*sys.argv[1:3])
