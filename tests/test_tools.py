@@ -1,0 +1,50 @@
+"""The profile post-processing tools on a tiny synthetic rocprofv3 database (they run offline, on the files the GPU
+box sends back): kernel statistics, HBM bytes per launch with the gfx950 corrections, SQ counter summary."""
+import json
+import os
+import sqlite3
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NAME = 'void vbx::chunk_post_mid_kernel<float, 32>(vbx::BatchView<float>)'
+OTHER = 'void vbx::scan2_kernel<float, 32>(vbx::BatchView<float>, int)'
+
+
+def _db(path, counters):
+    db = sqlite3.connect(path)
+    db.execute('create table kernels (name text, start integer, end integer)')
+    db.execute('create table pmc_events (name text, counter_name text, counter_value real)')
+    for k in range(4):
+        db.execute('insert into kernels values (?, ?, ?)', (NAME, 1000 * k, 1000 * k + 200_000))
+        db.execute('insert into kernels values (?, ?, ?)', (OTHER, 1000 * k, 1000 * k + 25_000))
+        for cname, val in counters.items():
+            for inst in range(2):                                 # two counter rows per launch (two instances)
+                db.execute('insert into pmc_events values (?, ?, ?)', (NAME, cname, val))
+                db.execute('insert into pmc_events values (?, ?, ?)', (OTHER, cname, val / 10))
+    db.commit()
+    db.close()
+
+
+def test_kernel_stats_and_pmc_tools(tmp_path):
+    fetch, write, sq = (str(tmp_path / n) for n in ('fetch.db', 'write.db', 'sq.db'))
+    _db(fetch, {'FETCH_SIZE': 1000.0})
+    _db(write, {'WRITE_SIZE': 500.0})
+    _db(sq, {'SQ_VALU_MFMA_BUSY_CYCLES': 245_760.0, 'SQ_BUSY_CYCLES': 10.0, 'SQ_WAVE_CYCLES': 100.0, 'SQ_ACTIVE_INST_ANY': 25.0})
+    out = str(tmp_path / 'traffic.json')
+    subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'pmc_traffic.py'), fetch, write, out, 'batch=64', 'T=10000',
+                    'precision=fp32'], check=True, capture_output=True)
+    doc = json.load(open(out))
+    assert doc['workload'] == {'batch': 64, 'T': 10000, 'precision': 'fp32'}
+    k = doc['kernels']['chunk_post']                              # variants are filed under their kernel class
+    assert k['hbm_read_bytes'] == 2 * 1000 * 1024 and k['hbm_write_bytes'] == 500 * 1024
+    assert k['hbm_bytes_per_launch'] == 2 * 1000 * 1024 + 500 * 1024 and 'scan2' in doc['kernels']
+    stats = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'rocpd_stats.py'), fetch], check=True,
+                           capture_output=True, text=True).stdout
+    row = [line for line in stats.splitlines() if line.startswith('chunk_post_mid_kernel<float, 32>')][0].split()
+    assert row[-6:-1] == ['4', '800.0', '200.00', '200.00', '200.00']          # calls, total, avg, min, max (us)
+    txt = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'pmc_counters.py'), sq], check=True,
+                         capture_output=True, text=True).stdout
+    line = [ln for ln in txt.splitlines() if ln.startswith('chunk_post_mid') and 'mfma_util' in ln][0]
+    # 2 rows x 245 760 busy cycles = 491 520 SIMD-cycles over 1024 SIMDs x 200 us x 2400 cycles/us = 0.001
+    assert 'mfma_busy_simd_cycles         491520' in line and 'mfma_util  0.0010' in line and 'active/wave_cycles  0.2500' in line
