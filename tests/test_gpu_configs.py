@@ -1,0 +1,155 @@
+"""BASELINE.json's configs at FULL size against outputs of the reference itself (-m gpu).
+
+tests/golden/config_*.npz were written by tests/golden/make_golden_configs.py from the unmodified
+/root/reference/VBx/VBx.py::VBx (pi, ELBO history, alpha, invL in full; gamma on 2000 fixed rows + its column sums).
+Tolerances: fp64 path 5e-6 absolute on gamma (the reference's own log-domain rounding at |lfw| ~ 1e6 is the noise
+floor), fp32 path 1e-4 -- the tolerance BASELINE.json's north_star states.  Every measured
+deviation is also written to gpurun_out/config_parity.json so that the margins can be read off a run.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from golden_util import load_config, config_inputs, config_diffs
+
+pytestmark = pytest.mark.gpu
+
+TOL = {'fp64': 5e-6, 'fp32': 1e-4}
+_REPORT = {}
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from vbx_amd import _capi
+    return _capi.Context(0)
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _write_report():
+    yield
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, 'config_parity.json'), 'w') as f:
+            json.dump(_REPORT, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def check(name, precision, d, n_iters=None):
+    _REPORT[f'{name}/{precision}'] = d
+    tol = TOL[precision]
+    if n_iters is not None:
+        assert d['n_iters'][0] == n_iters, (name, precision, d)
+    assert d['n_iters'][0] == d['n_iters'][1], (name, precision, d)
+    assert d['gamma'] <= tol, (name, precision, d)
+    assert d['pi'] <= tol, (name, precision, d)
+    assert d['Li_rel'] <= (1e-9 if precision == 'fp64' else 1e-6), (name, precision, d)
+    assert d['gamma_colsum_rel'] <= tol, (name, precision, d)
+    if 'alpha' in d:
+        assert d['alpha'] <= tol and d['invL_rel'] <= tol, (name, precision, d)
+
+
+def run_one(ctx, X, Phi, g0, S, hyper, iters, precision, epsilon=-np.inf):
+    from vbx_amd import _capi
+    lp, fa, fb = (float(v) for v in hyper)
+    batch = _capi.Batch(ctx, [X.shape[0]], [S], X.shape[1], precision=precision, max_iters=iters)
+    batch.set_recording(0, X, Phi, np.ones(S) / S, g0, lp, fa, fb)
+    batch.run(iters, epsilon)
+    res = batch.result(0)
+    batch.close()
+    return res
+
+
+@pytest.mark.parametrize('precision', ['fp64', 'fp32'])
+def test_c2_ten_iterations_from_the_global_rng(precision):
+    """configs[1]: T=10 000, S=10, gamma=None (VBx.py:79-83 draws it from the global RNG), ten iterations."""
+    import vbx_amd
+    cfg = load_config('c2')
+    X, Phi, _ = config_inputs(cfg, 'c2')
+    lp, fa, fb = (float(v) for v in cfg['c2/hyper'])
+    np.random.seed(1)
+    gamma, pi, Li, alpha, invL = vbx_amd.VBx(X, Phi, loopProb=lp, Fa=fa, Fb=fb, pi=10, gamma=None, maxIters=10,
+                                             epsilon=-1e300, return_model=True, precision=precision)
+    check('c2/it10', precision, config_diffs(cfg, 'c2/it10', gamma, pi, [r[0] for r in Li], alpha, invL), 10)
+
+
+@pytest.mark.parametrize('precision', ['fp64', 'fp32'])
+def test_headline_shape_two_iterations_and_converged(ctx, precision):
+    """T=10 000, R=128, S=30 (the metric's shape): after two iterations, and the run the reference stops by itself
+    (maxIters=40, epsilon=1e-4: seven iterations).  fp64 applies the reference's own stopping rule; fp32 cannot
+    resolve 1e-4 on an ELBO of -6e5 and is compared after the same seven iterations."""
+    cfg = load_config('headline')
+    X, Phi, g0 = config_inputs(cfg, 'hl', g0_seed=1)
+    res = run_one(ctx, X, Phi, g0, 30, cfg['hl/hyper'], 2, precision)
+    check('hl/it2', precision, config_diffs(cfg, 'hl/it2', res['gamma'], res['pi'], res['Li'], res['alpha'], res['invL']), 2)
+    n_ref = len(cfg['hl/stop/Li'])
+    if precision == 'fp64':
+        res = run_one(ctx, X, Phi, g0, 30, cfg['hl/hyper'], 40, precision, epsilon=1e-4)
+    else:
+        res = run_one(ctx, X, Phi, g0, 30, cfg['hl/hyper'], n_ref, precision)
+    check('hl/stop', precision, config_diffs(cfg, 'hl/stop', res['gamma'], res['pi'], res['Li'], res['alpha'], res['invL']),
+          n_ref)
+
+
+@pytest.mark.parametrize('precision', ['fp64', 'fp32'])
+def test_c3_long_recording(precision):
+    """configs[2]: T=50 000, S=30, gamma=None, after 2, 3 and 40 iterations (391 chunks: the two-level boundary walk
+    is active)."""
+    import vbx_amd
+    cfg = load_config('c3')
+    X, Phi, _ = config_inputs(cfg, 'c3')
+    lp, fa, fb = (float(v) for v in cfg['c3/hyper'])
+    for n in (2, 3, 40):
+        np.random.seed(1)
+        gamma, pi, Li, alpha, invL = vbx_amd.VBx(X, Phi, loopProb=lp, Fa=fa, Fb=fb, pi=30, gamma=None, maxIters=n,
+                                                 epsilon=-1e300, return_model=True, precision=precision)
+        check(f'c3/it{n}', precision, config_diffs(cfg, f'c3/it{n}', gamma, pi, [r[0] for r in Li], alpha, invL), n)
+
+
+@pytest.mark.parametrize('precision', ['fp64', 'fp32'])
+def test_c4_batch_of_64_on_the_default_streams(ctx, precision):
+    """configs[3]: the 64 recordings of T=10 000, S=30 that bench.py runs, as ONE batch on the library's default
+    stream groups; recordings 0, 31 and 63 against the reference after four iterations."""
+    from vbx_amd import _capi
+    from vbx_amd.synth import make_recording
+    cfg = load_config('c4')
+    T, S, n_rec = 10000, 30, 64
+    lp, fa, fb = (float(v) for v in cfg['c4/hyper'])
+    batch = _capi.Batch(ctx, [T] * n_rec, [S] * n_rec, 128, precision=precision, max_iters=4)
+    assert batch.streams == 3
+    for k in range(n_rec):
+        if k in (0, 31, 63):
+            X, Phi, g0 = config_inputs(cfg, f'c4/rec{k}', g0_seed=10_000 + k)
+        else:
+            X, Phi, _ = make_recording(T, S, seed=k, kappa=0.05, dtype=np.float32)
+            g0 = np.random.default_rng(10_000 + k).gamma(1.0, size=(T, S)).astype(np.float32)
+            g0 /= g0.sum(1, keepdims=True)
+        batch.set_recording(k, X, Phi, np.ones(S) / S, g0, lp, fa, fb)
+    batch.run(4, -np.inf)
+    for k in (0, 31, 63):
+        res = batch.result(k)
+        check(f'c4/rec{k}/it4', precision,
+              config_diffs(cfg, f'c4/rec{k}/it4', res['gamma'], res['pi'], res['Li'], res['alpha'], res['invL']), 4)
+    batch.close()
+
+
+@pytest.mark.parametrize('precision', ['fp64', 'fp32'])
+def test_c5_very_long_recording_sweep_points(ctx, precision):
+    """configs[4]: T=200 000, S=50, loopProb 0.9, two points of the Fa/Fb sweep as one batch (1563 chunks each:
+    two-level walk with groups of 40), two iterations."""
+    from vbx_amd import _capi
+    cfg = load_config('c5')
+    X, Phi, g0 = config_inputs(cfg, 'c5', g0_seed=4)
+    points = [(0.3, 17.0), (0.2, 6.0)]
+    batch = _capi.Batch(ctx, [X.shape[0]] * 2, [50] * 2, 128, precision=precision, max_iters=2)
+    for k, (fa, fb) in enumerate(points):
+        batch.set_recording(k, X, Phi, np.ones(50) / 50, g0, 0.9, fa, fb)
+    batch.run(2, -np.inf)
+    for k, (fa, fb) in enumerate(points):
+        tag = f'c5/fa{fa}_fb{fb:g}/it2'
+        res = batch.result(k)
+        check(tag, precision, config_diffs(cfg, tag, res['gamma'], res['pi'], res['Li'], res['alpha'], res['invL']), 2)
+    batch.close()
