@@ -62,20 +62,15 @@ extern "C" {
 #define VBX_OPT_CHUNK_FRAMES 4  /* frames per scan chunk for VBX_FB_CHUNKED (0 = auto)         */
 #define VBX_OPT_SCAN_GROUP 6    /* chunks per group of the two-level boundary walk: 0 auto (sqrt of the chunk count
                                    once a recording has >= 160 chunks), 1 flat chain, >= 2 explicit              */
-#define VBX_OPT_POST_KERNEL 9   /* chunk_post variant: 1 (default) half lattices in LDS (meet in the middle, four workgroups
-                                   per CU); 0 full lattices; 2 four tiles per workgroup, one per 16-lane row of the
-                                   re-run waves, gamma^T rho fed from registers (f32, <= 32 states, D <= 128; else 1) */
 #define VBX_OPT_STREAMS 10      /* HIP streams of a batch: its recordings are dealt to that many sub-batches, one
                                    iteration of each is launched stream after stream, so the latency-bound launches of
                                    one overlap the bandwidth-bound ones of the others.  0 = auto (3 from 24 recordings and
                                    1536 chunks, 2 from 12 and 768, else 1; env VBX_AMD_STREAMS overrides).  Before the
                                    first recording. */
-#define VBX_OPT_HALF_CHUNKS 7   /* 1: the fused kernels use one transfer operator / boundary pair per HALF tile (64
-                                   frames) and re-run the halves on separate waves; 0 (default): per tile.  Halves
-                                   the chunk kernels' dependent chains, doubles the boundary walk: a wash overall */
 #define VBX_OPT_TWO_LEVEL_FROM 8 /* chunk count from which VBX_OPT_SCAN_GROUP = 0 picks the two-level walk           */
 #define VBX_OPT_FUSE 5          /* per-chunk fused kernels when the lattices fit in LDS: 0 none, 1 chunk_post,
-                                   2 (default) chunk_post + chunk_loglik                                */
+                                   2 (default) chunk_post + chunk_loglik.  On the fused path the responsibilities are
+                                   written once, when vbx_batch_run returns (they are not needed between iterations) */
 
 typedef struct vbx_ctx vbx_ctx;
 typedef struct vbx_batch vbx_batch;

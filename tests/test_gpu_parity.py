@@ -525,44 +525,11 @@ def test_vbx_shapes_sweep_against_the_oracle(S, D):
         assert np.abs(a - ar).max() <= tol * max(1.0, np.abs(ar).max()) and np.abs(il - ir).max() <= tol
 
 
-@pytest.mark.parametrize('precision,tol', [('fp64', 1e-11), ('fp32', 2e-5)])
-def test_half_tile_scan_chunks_equal_whole_tile_chunks(ctx, precision, tol):
-    """VBX_OPT_HALF_CHUNKS: the fused kernels build one operator per 64 frames and re-run a tile as four tasks
-    (two halves x two directions).  Same results as one operator per tile, for lengths that end in the first
-    half of a tile, exactly at a half, and in the second half, with and without the two-level walk."""
-    from vbx_amd import _capi
-    from vbx_amd.synth import make_recording
-    Ts, S = [1000, 1088, 1153, 64, 65, 3], 12
-    recs = []
-    for k, T in enumerate(Ts):
-        X, Phi, _ = make_recording(T, S, seed=50 + k, kappa=0.05)
-        g0 = np.random.default_rng(60 + k).gamma(1.0, size=(T, S))
-        recs.append((X, Phi, g0 / g0.sum(1, keepdims=True)))
-    out = {}
-    for half, group in ((0, 1), (1, 1), (1, 3)):
-        batch = _capi.Batch(ctx, Ts, [S] * len(Ts), 128, precision=precision, max_iters=4)
-        batch.set_option(_capi.OPT_HALF_CHUNKS, half)
-        batch.set_option(_capi.OPT_SCAN_GROUP, group)
-        for j, (X, Phi, g0) in enumerate(recs):
-            batch.set_recording(j, X, Phi, np.ones(S) / S, g0, 0.95, 0.3, 17.0)
-        batch.run(4, -np.inf)
-        out[half, group] = [batch.result(j, want_model=False) for j in range(len(Ts))]
-        batch.close()
-    for key in ((1, 1), (1, 3)):
-        for j in range(len(Ts)):
-            a, b = out[key][j], out[0, 1][j]
-            assert np.abs(a['gamma'] - b['gamma']).max() <= tol, (key, Ts[j], np.abs(a['gamma'] - b['gamma']).max())
-            assert np.abs(a['pi'] - b['pi']).max() <= tol and rel_err(a['Li'], b['Li']) <= tol, (key, Ts[j])
-
-
-@pytest.mark.parametrize('precision,tol', [('fp64', 1e-11), ('fp32', 2e-5)])
-def test_chunk_post_variants_agree(ctx, precision, tol):
-    """VBX_OPT_POST_KERNEL: 0 = both whole lattices in LDS, 1 = half a forward and half a backward lattice (the two
-    recursions meet at the middle of the tile), 2 = four tiles per workgroup, one per 16-lane row of the re-run
-    waves (f32 and <= 32 states; otherwise the library falls back to 1).  The oracle is the judge of the default (1) in
-    the other tests; here the three must agree.  Lengths: full tiles, tails shorter and longer than half a tile,
-    1, 2, 3, 63, 64, 65 and 127 frames (where the backward recursion of a short tile starts), tile counts that are
-    not multiples of four; S on both sides of the 16-state padding."""
+@pytest.mark.parametrize('precision,tol', [('fp64', 2e-8), ('fp32', 2e-5)])
+def test_chunk_post_tile_shapes_against_the_oracle(ctx, precision, tol):
+    """chunk_post (half lattices that meet in the middle of the tile, gamma written by the replay instance) against
+    the oracle, for lengths of full tiles, tails shorter and longer than half a tile, 1, 2, 3, 63, 64, 65 and 127
+    frames (where the backward recursion of a short tile starts); S on both sides of the 16-state padding."""
     from vbx_amd import _capi
     from vbx_amd.synth import make_recording
     for S in (7, 16, 30):
@@ -572,28 +539,27 @@ def test_chunk_post_variants_agree(ctx, precision, tol):
             X, Phi, _ = make_recording(T, S, seed=150 + k, kappa=0.05)
             g0 = np.random.default_rng(160 + k).gamma(1.0, size=(T, S))
             recs.append((X, Phi, g0 / g0.sum(1, keepdims=True)))
-        out = {}
-        for variant in (0, 1, 2):
-            batch = _capi.Batch(ctx, Ts, [S] * len(Ts), 128, precision=precision, max_iters=4)
-            batch.set_option(_capi.OPT_POST_KERNEL, variant)
-            for j, (X, Phi, g0) in enumerate(recs):
-                batch.set_recording(j, X, Phi, np.ones(S) / S, g0, 0.95, 0.3, 17.0)
-            batch.run(4, -np.inf)
-            out[variant] = [batch.result(j, want_model=True) for j in range(len(Ts))]
-            batch.close()
-        for variant in (1, 2):
-            for j in range(len(Ts)):
-                a, b = out[variant][j], out[0][j]
-                key = (variant, S, Ts[j])
-                assert np.abs(a['gamma'] - b['gamma']).max() <= tol, (key, np.abs(a['gamma'] - b['gamma']).max())
-                assert np.abs(a['pi'] - b['pi']).max() <= tol and rel_err(a['Li'], b['Li']) <= tol, key
-                assert np.abs(a['alpha'] - b['alpha']).max() <= tol * max(1.0, np.abs(b['alpha']).max()), key
+        batch = _capi.Batch(ctx, Ts, [S] * len(Ts), 128, precision=precision, max_iters=4)
+        batch.set_option(_capi.OPT_FB_ALGO, _capi.FB_CHUNKED)
+        for j, (X, Phi, g0) in enumerate(recs):
+            batch.set_recording(j, X, Phi, np.ones(S) / S, g0, 0.95, 0.3, 17.0)
+        batch.run(4, -np.inf)
+        for j, (X, Phi, g0) in enumerate(recs):
+            a = batch.result(j, want_model=True)
+            gr, pr, Lr, ar, ir = _orc().VBx(X, Phi, loopProb=0.95, Fa=0.3, Fb=17.0, pi=S, gamma=g0, maxIters=4,
+                                            epsilon=-1e300, return_model=True)
+            key = (S, Ts[j])
+            assert np.abs(a['gamma'] - gr).max() <= tol, (key, np.abs(a['gamma'] - gr).max())
+            assert np.abs(a['pi'] - pr).max() <= tol and rel_err(a['Li'], [r[0] for r in Lr]) <= max(tol, 1e-10), key
+            assert np.abs(a['alpha'] - ar).max() <= tol * max(1.0, np.abs(ar).max()), key
+        batch.close()
 
 
-def test_converged_recordings_are_skipped_by_every_chunk_post_variant(ctx):
+def test_converged_recordings_keep_their_results(ctx):
     """Device-side convergence: a recording that has converged keeps its results while the others of the batch go
-    on (the four-tile kernel sees it through tile_done).  Each recording of a mixed batch must equal its own
-    single-recording run with the same epsilon."""
+    on (every kernel sees it through tile_done / state.done; the replay writes its gamma from the state of its own
+    last iteration).  Each recording of a mixed batch must equal its own single-recording run with the same epsilon,
+    and the oracle after that many iterations."""
     from vbx_amd import _capi
     from vbx_amd.synth import make_recording
     Ts, S = [700, 260, 1500, 130, 900], 9
@@ -602,26 +568,25 @@ def test_converged_recordings_are_skipped_by_every_chunk_post_variant(ctx):
         X, Phi, _ = make_recording(T, S, seed=250 + k, kappa=0.03 + 0.02 * k)
         g0 = np.random.default_rng(260 + k).gamma(1.0, size=(T, S))
         recs.append((X, Phi, g0 / g0.sum(1, keepdims=True)))
-    for variant in (0, 1, 2):
-        batch = _capi.Batch(ctx, Ts, [S] * len(Ts), 128, precision='fp32', max_iters=30)
-        batch.set_option(_capi.OPT_POST_KERNEL, variant)
-        batch.set_option(_capi.OPT_CHECK_EVERY, 1000)
-        for j, (X, Phi, g0) in enumerate(recs):
-            batch.set_recording(j, X, Phi, np.ones(S) / S, g0, 0.9, 0.3, 17.0)
-        batch.run(30, 1e-3)
-        together = [batch.result(j, want_model=False) for j in range(len(Ts))]
-        batch.close()
-        iters = [len(r['Li']) for r in together]
-        assert len(set(iters)) > 1, iters                    # the batch really is mixed
-        for j, (X, Phi, g0) in enumerate(recs):
-            one = _capi.Batch(ctx, [Ts[j]], [S], 128, precision='fp32', max_iters=30)
-            one.set_option(_capi.OPT_POST_KERNEL, variant)
-            one.set_recording(0, X, Phi, np.ones(S) / S, g0, 0.9, 0.3, 17.0)
-            one.run(30, 1e-3)
-            alone = one.result(0, want_model=False)
-            one.close()
-            assert len(alone['Li']) == iters[j], (variant, j, len(alone['Li']), iters[j])
-            assert np.abs(alone['gamma'] - together[j]['gamma']).max() <= 2e-5, (variant, j)
+    batch = _capi.Batch(ctx, Ts, [S] * len(Ts), 128, precision='fp32', max_iters=30)
+    batch.set_option(_capi.OPT_CHECK_EVERY, 1000)
+    for j, (X, Phi, g0) in enumerate(recs):
+        batch.set_recording(j, X, Phi, np.ones(S) / S, g0, 0.9, 0.3, 17.0)
+    batch.run(30, 1e-3)
+    together = [batch.result(j, want_model=False) for j in range(len(Ts))]
+    batch.close()
+    iters = [len(r['Li']) for r in together]
+    assert len(set(iters)) > 1, iters                    # the batch really is mixed
+    for j, (X, Phi, g0) in enumerate(recs):
+        one = _capi.Batch(ctx, [Ts[j]], [S], 128, precision='fp32', max_iters=30)
+        one.set_recording(0, X, Phi, np.ones(S) / S, g0, 0.9, 0.3, 17.0)
+        one.run(30, 1e-3)
+        alone = one.result(0, want_model=False)
+        one.close()
+        assert len(alone['Li']) == iters[j], (j, len(alone['Li']), iters[j])
+        assert np.abs(alone['gamma'] - together[j]['gamma']).max() <= 2e-5, j
+        gr, pr, Lr = _orc().VBx(X, Phi, loopProb=0.9, Fa=0.3, Fb=17.0, pi=S, gamma=g0, maxIters=iters[j], epsilon=-1e300)
+        assert np.abs(together[j]['gamma'] - gr).max() <= 1e-4, j
 
 
 def test_python_batch_api_equals_one_call_per_recording(synth_cases):

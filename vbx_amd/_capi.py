@@ -4,6 +4,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -13,7 +14,7 @@ VBX_F32, VBX_F64 = 0, 1
 PREC_FP32, PREC_FP64 = 0, 1
 FB_AUTO, FB_SEQUENTIAL, FB_CHUNKED = 0, 1, 2
 OPT_FB_ALGO, OPT_CHECK_EVERY, OPT_PROFILE, OPT_CHUNK_FRAMES, OPT_FUSE, OPT_SCAN_GROUP = 1, 2, 3, 4, 5, 6
-OPT_HALF_CHUNKS, OPT_TWO_LEVEL_FROM, OPT_POST_KERNEL, OPT_STREAMS = 7, 8, 9, 10
+OPT_TWO_LEVEL_FROM, OPT_STREAMS = 8, 10
 K_NAMES = ['prep', 'mstep_acc', 'mstep_fin', 'loglik', 'fb', 'fb_aux', 'post', 'iter_fin', 'chunk_loglik',
            'chunk_post']
 MAX_SPEAKERS = 256
@@ -145,6 +146,8 @@ class Context:
             self._h = None
 
     def __del__(self):
+        if sys.is_finalizing():          # the HIP runtime may already be gone: leave the device memory to the process exit
+            return
         try:
             self.close()
         except Exception:
@@ -239,6 +242,8 @@ class Scores:
             self._h = None
 
     def __del__(self):
+        if sys.is_finalizing():          # the HIP runtime may already be gone: leave the device memory to the process exit
+            return
         try:
             self.close()
         except Exception:
@@ -267,10 +272,8 @@ class Batch:
         if algo:
             self.set_option(OPT_FB_ALGO, {'auto': FB_AUTO, 'sequential': FB_SEQUENTIAL,
                                           'chunked': FB_CHUNKED}[algo])
-        for env, opt in (('VBX_AMD_HALF_CHUNKS', OPT_HALF_CHUNKS), ('VBX_AMD_TWO_LEVEL_FROM', OPT_TWO_LEVEL_FROM),
-                         ('VBX_AMD_POST_KERNEL', OPT_POST_KERNEL)):
-            if os.environ.get(env) is not None:
-                self.set_option(opt, int(os.environ[env]))
+        if os.environ.get('VBX_AMD_TWO_LEVEL_FROM') is not None:
+            self.set_option(OPT_TWO_LEVEL_FROM, int(os.environ['VBX_AMD_TWO_LEVEL_FROM']))
         group = os.environ.get('VBX_AMD_SCAN_GROUP')      # chunks per group of the two-level boundary walk
         if group is not None:
             self.set_option(OPT_SCAN_GROUP, int(group))
@@ -346,6 +349,8 @@ class Batch:
             self._h = None
 
     def __del__(self):
+        if sys.is_finalizing():          # the HIP runtime may already be gone: leave the device memory to the process exit
+            return
         try:
             self.close()
         except Exception:

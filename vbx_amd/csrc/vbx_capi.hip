@@ -7,9 +7,8 @@
 #include "../../include/vbx_hip.h"
 #include "vbx_kernels.hpp"
 #include "vbx_scan.hpp"
-#include "vbx_fused.hpp"
-#include "vbx_fused_mid.hpp"
-#include "vbx_fused_quad.hpp"
+#include "vbx_chunk_loglik.hpp"
+#include "vbx_chunk_post.hpp"
 #include "vbx_linkage.hpp"
 #include "vbx_ahc.hpp"
 
@@ -123,6 +122,10 @@ struct vbx_batch {
     int fb_algo = VBX_FB_AUTO, check_every = 4, chunk_frames = 0, fuse = 2;
     int64_t profile = 0;                          // bit k: bracket launches of kernel class k with HIP events
     bool mpart_valid = false;                     // mpart/npart hold gamma^T rho of the current gamma (fused path)
+    bool gamma_stale = false;                     // fused iterations have run since gamma was last written (run_end replays)
+    bool fused_now = false;                       // in effect for the launches being issued: the fused per-chunk kernels
+    void* d_gamma0 = nullptr;
+    double* d_pi_prev = nullptr;
     // device memory
     RecDesc* d_recs = nullptr;
     RecState* d_state = nullptr;
@@ -144,9 +147,7 @@ struct vbx_batch {
     bool use_chunked = false;
     // two-level boundary walk
     int scan_group = 0;                           // option: 0 auto, 1 flat, >= 2 chunks per group
-    int half_chunks = 0, two_level_from = 160;
-    int post_kernel = 1;                          // option: chunk_post variant (0 full lattices, 1 meet in the middle, 2 four tiles per workgroup)
-    // options: half-tile scan chunks in the fused path; auto two-level threshold
+    int two_level_from = 160;
     int sgroup = 1, nsup_total = 0;               // in effect
     int spt = 1;                                  // scan chunks per tile in effect (2: fused kernels, half-tile operators)
     void* d_sop = nullptr;
@@ -177,6 +178,7 @@ struct vbx_batch {
         v.tllpart = use_chunked ? d_tllpart : nullptr; v.sfw = (R*)d_sfw; v.dump = (R*)d_dump;
         v.sop = (R*)d_sop; v.sopexp = d_sopexp; v.sup_rec = d_sup_rec; v.sup_idx = d_sup_idx;
         v.sgroup = sgroup; v.nsup_total = nsup_total; v.spt = spt;
+        v.gamma0 = fused_now ? (R*)d_gamma0 : nullptr; v.pi_prev = d_pi_prev;
         return v;
     }
 };
@@ -241,6 +243,12 @@ template <typename R> void launch_loglik(vbx_batch* b, double eps, bool raw) {
                                         b->ctx->stream, v, lraw);)
 }
 
+// chunk_post over the tiles of the batch; REPLAY: the instance that only writes the responsibilities
+template <typename R, int SP, bool REPLAY> void launch_chunk_post(vbx_batch* b, const BatchView<R>& v) {
+    if constexpr (ChunkPostCfg<R, SP>::kFits)
+        hipLaunchKernelGGL((chunk_post_kernel<R, SP, REPLAY>), dim3(b->ntiles_total), dim3(256), 0, b->ctx->stream, v);
+}
+
 template <typename R, int SP> void launch_scan(vbx_batch* b, const BatchView<R>& v, bool fused_post, bool fused_loglik) {
     hipStream_t st = b->ctx->stream;
     bool have_op = false;
@@ -268,16 +276,7 @@ template <typename R, int SP> void launch_scan(vbx_batch* b, const BatchView<R>&
     if constexpr (ChunkPostCfg<R, SP>::kFits) {
         if (fused_post) {
             LaunchScope ls(b, VBX_K_CHUNK_POST);
-            bool quad = false;
-            if constexpr (ChunkPostQuadCfg<R, SP>::kFits) quad = b->post_kernel == 2 && v.spt == 1 && b->Dp <= ChunkPostQuadCfg<R, SP>::kMaxDp;
-            if (quad) {
-                if constexpr (ChunkPostQuadCfg<R, SP>::kFits)
-                    hipLaunchKernelGGL((chunk_post_quad_kernel<R, SP>), dim3((b->ntiles_total + kQuadTiles - 1) / kQuadTiles),
-                                       dim3(512), 0, st, v);
-            } else if (b->post_kernel && v.spt == 1)
-                hipLaunchKernelGGL((chunk_post_mid_kernel<R, SP>), dim3(b->ntiles_total), dim3(256), 0, st, v);
-            else
-                hipLaunchKernelGGL((chunk_post_kernel<R, SP>), dim3(b->ntiles_total), dim3(256), 0, st, v);
+            launch_chunk_post<R, SP, false>(b, v);
             return;
         }
     }
@@ -349,7 +348,8 @@ template <typename R> void launch_iter_fin(vbx_batch* b, double eps) {
 }
 
 template <typename R> void launch_iteration(vbx_batch* b, double eps) {
-    if (fused_available<R>(b)) {
+    b->fused_now = fused_available<R>(b);
+    if (b->fused_now) {
         // chunk_post leaves gamma^T rho of the gamma it has just written in mpart/npart, so only the
         // first iteration after an upload needs the stand-alone accumulation
         if (!b->mpart_valid) launch_mstep_acc<R>(b, eps);
@@ -359,6 +359,7 @@ template <typename R> void launch_iteration(vbx_batch* b, double eps) {
         launch_fb<R>(b, eps, true, fl);
         launch_iter_fin<R>(b, eps);
         b->mpart_valid = true;
+        b->gamma_stale = true;
         return;
     }
     launch_mstep<R>(b, eps);
@@ -446,10 +447,7 @@ int choose_fb_algo(vbx_batch* b, bool step_api_logs) {
         if (rc != VBX_OK) return rc;
     }
     b->use_chunked = chunked;
-    // the fused kernels work on half-tile scan chunks (two re-run tasks per half: half the dependent chain)
-    const bool fused2 = b->precision == VBX_PREC_FP64 ? (fused_available<double>(b) && fused_loglik_available<double>(b))
-                                                       : (fused_available<float>(b) && fused_loglik_available<float>(b));
-    const int spt = (chunked && fused2 && b->half_chunks) ? 2 : 1;
+    const int spt = 1;
     // the forward / backward lattices live in HBM only on the paths that do not keep them in LDS
     const bool fused1 = b->precision == VBX_PREC_FP64 ? fused_available<double>(b) : fused_available<float>(b);
     if (!fused1 && !b->d_ahat) {
@@ -599,7 +597,8 @@ static int leaf_destroy(vbx_batch* b) {
                     b->d_rho, b->d_gamma, b->d_bmat, b->d_mrow, b->d_ahat, b->d_bhat, b->d_alpha, b->d_invL,
                     b->d_bias, b->d_mpart, b->d_npart, b->d_lraw, b->d_emodel, b->d_pi, b->d_epart, b->d_Li,
                     b->d_xstage, b->d_ip, b->d_fw_scale, b->d_bw_scale, b->d_op, b->d_fbound, b->d_gbound,
-                    b->d_opexp, b->d_tllpart, b->d_sfw, b->d_dump, b->d_sop, b->d_sopexp, b->d_sup_rec, b->d_sup_idx};
+                    b->d_opexp, b->d_tllpart, b->d_sfw, b->d_dump, b->d_sop, b->d_sopexp, b->d_sup_rec, b->d_sup_idx,
+                    b->d_gamma0, b->d_pi_prev};
     (void)hipStreamSynchronize(b->ctx->stream);               // nothing of this batch may still be running when its
     for (void* p : ptrs) ctx_free(b->ctx, p);                 // blocks go back to the spare list
     if (b->ev_start) (void)hipEventDestroy(b->ev_start);
@@ -666,7 +665,7 @@ static int leaf_create(vbx_ctx* ctx, int n_rec, const int64_t* T, const int32_t*
         const RecDesc& rd = b->recs[tile_rec[t]];
         tile_desc.push_back(make_int4(tile_rec[t], tile_t0[t], std::min(kTileFrames, rd.T - tile_t0[t]), (int)(rd.row0 + tile_t0[t])));
     }
-    while (tile_desc.size() % kQuadTiles) tile_desc.push_back(make_int4(0, 0, 0, (int)row));
+    while (tile_desc.size() % 4) tile_desc.push_back(make_int4(0, 0, 0, (int)row));
     const size_t rs = b->rsize;
     const size_t cells = (size_t)b->sum_T * b->Sp;
     int rc = VBX_OK;
@@ -675,7 +674,7 @@ static int leaf_create(vbx_ctx* ctx, int n_rec, const int64_t* T, const int32_t*
     ALLOC(dmalloc(ctx, &b->d_state, n_rec));
     ALLOC(dmalloc(ctx, &b->d_tile_rec, b->ntiles_total));
     ALLOC(dmalloc(ctx, &b->d_tile_t0, b->ntiles_total));
-    const int ntiles_pad = (b->ntiles_total + kQuadTiles - 1) / kQuadTiles * kQuadTiles;
+    const int ntiles_pad = (b->ntiles_total + 3) / 4 * 4;
     ALLOC(dmalloc(ctx, &b->d_tile_desc, ntiles_pad));
     ALLOC(dmalloc(ctx, &b->d_tile_done, ntiles_pad));
     ALLOC(dmalloc(ctx, &b->d_phi, (size_t)n_rec * b->Dp));
@@ -693,6 +692,8 @@ static int leaf_create(vbx_ctx* ctx, int n_rec, const int64_t* T, const int32_t*
     ALLOC(dmalloc_bytes(ctx, &b->d_npart, (size_t)b->ntiles_total * b->Sp * rs));
     ALLOC(dmalloc(ctx, &b->d_emodel, (size_t)n_rec * b->Sp));
     ALLOC(dmalloc(ctx, &b->d_pi, (size_t)n_rec * b->Sp));
+    ALLOC(dmalloc(ctx, &b->d_pi_prev, (size_t)n_rec * b->Sp));
+    ALLOC(dmalloc_bytes(ctx, &b->d_gamma0, (size_t)n_rec * b->Sp * rs));
     ALLOC(dmalloc(ctx, &b->d_epart, (size_t)b->ntiles_total * b->Sp));
     ALLOC(dmalloc(ctx, &b->d_Li, (size_t)n_rec * std::max(max_iters, 1)));
     b->xstage_bytes = (size_t)maxT * D * 8;
@@ -707,6 +708,7 @@ static int leaf_create(vbx_ctx* ctx, int n_rec, const int64_t* T, const int32_t*
         (e = hipMemcpy(b->d_tile_t0, tile_t0.data(), sizeof(int) * tile_t0.size(), hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMemcpy(b->d_tile_desc, tile_desc.data(), sizeof(int4) * tile_desc.size(), hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMemset(b->d_tile_done, 0, sizeof(int) * ntiles_pad)) != hipSuccess ||
+        (e = hipMemset(b->d_pi_prev, 0, sizeof(double) * (size_t)n_rec * b->Sp)) != hipSuccess ||
         (e = hipMemset((char*)b->d_bmat + cells * rs, 0, (size_t)kTileFrames * b->Sp * rs)) != hipSuccess ||
         (e = hipMemset(b->d_state, 0, sizeof(RecState) * n_rec)) != hipSuccess ||
         (e = hipMemset(b->d_gamma, 0, cells * rs)) != hipSuccess ||
@@ -739,13 +741,6 @@ static int leaf_set_option(vbx_batch* b, int option, int64_t value) {
             if (value < 0 || value > 2) FAIL(b->ctx, VBX_ERR_INVALID, "fuse must be 0, 1 or 2");
             b->fuse = (int)value;
             b->mpart_valid = false;
-            return VBX_OK;
-        case VBX_OPT_POST_KERNEL:
-            if (value < 0 || value > 2) FAIL(b->ctx, VBX_ERR_INVALID, "VBX_OPT_POST_KERNEL takes 0, 1 or 2");
-            b->post_kernel = (int)value;
-            return VBX_OK;
-        case VBX_OPT_HALF_CHUNKS:
-            b->half_chunks = value ? 1 : 0;
             return VBX_OK;
         case VBX_OPT_TWO_LEVEL_FROM:
             if (value < 2) FAIL(b->ctx, VBX_ERR_INVALID, "two-level threshold must be >= 2 chunks");
@@ -886,8 +881,31 @@ static int run_all_done(vbx_batch* b, bool* all_done) {
     return VBX_OK;
 }
 
+// The fused path keeps gamma on the chip; what a caller can ask for (VBx.py:126) is written here, once, from the b,
+// boundary vectors and priors of every recording's last iteration (vbx_chunk_post.hpp, REPLAY).
+extern "C++" {
+namespace {
+template <typename R> void launch_gamma_replay(vbx_batch* b) {
+    b->fused_now = true;
+    auto v = b->view<R>(0.0);
+    LaunchScope ls(b, VBX_K_POST);
+    switch (b->Sp) {
+        case 16: launch_chunk_post<R, 16, true>(b, v); break;
+        case 32: launch_chunk_post<R, 32, true>(b, v); break;
+        case 64: launch_chunk_post<R, 64, true>(b, v); break;
+        default: break;
+    }
+}
+}  // namespace
+}  // extern "C++"
+
 static int run_end(vbx_batch* b) {
     vbx_ctx* ctx = b->ctx;
+    if (b->gamma_stale) {
+        if (b->precision == VBX_PREC_FP64) launch_gamma_replay<double>(b);
+        else launch_gamma_replay<float>(b);
+        b->gamma_stale = false;
+    }
     HIPCHK(ctx, hipEventRecord(b->ev_stop, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipGetLastError());

@@ -1,0 +1,431 @@
+// vbx_chunk_post.hpp -- chunk_post: re-run of a chunk from its boundary vectors, posteriors, prior statistics,
+// log-likelihood share and the NEXT iteration's M-step accumulation gamma^T rho   (VBx.py:96,101-103,167-174).
+//
+// One workgroup = one chunk (tile of kTileFrames frames):
+//
+//   stage    b of the tile -> LDS region `bl`
+//   re-run   wave 0 forward, wave 1 backward over the tile, unnormalised vectors rescaled by powers of two every
+//            four frames; the two meet in the middle: each direction stores only the half of its lattice that the
+//            OTHER has not produced yet in region `hl`, and everything after the midpoint overwrites rows of b that
+//            both directions have consumed:
+//                rows [0, mid)   : a_f -> hl[f]            (forward, before the midpoint barrier)
+//                                  x_f -> bl[f]            (backward, after the barrier)
+//                rows [mid, len) : x_f -> hl[HALF + f-mid] (backward, before the barrier)
+//                                  a_f -> bl[f]            (forward, after the barrier)
+//   post     gamma ~ a x, "entered" statistic, log-likelihood share; gamma -> bl (A operand of the accumulation)
+//   MFMA     C[s][d] = sum_t gamma[t][s] rho[t][d] on v_mfma 16x16x4, rho fetched a quarter of the chunk ahead.
+//
+// What leaves the workgroup: the partial sums of the tile (gamma^T rho, sum gamma, "entered", tll share) -- and NOT
+// gamma: nothing in the iteration loop reads it (iter_fin needs row 0 only: gamma0).  The responsibilities a caller
+// asks for are written by the REPLAY instance of the same kernel after the last iteration (re-run + posteriors only,
+// from the b, boundary vectors and priors of each recording's last iteration, which stay in HBM untouched once it
+// has stopped).  Measured on 64 recordings of T = 10 000, S = 30: 174 -> 165 us per launch, 77 MB less written.
+//
+// Tried and dropped (round 2): one workgroup walking a RUN of several tiles with the accumulators kept in registers
+// across them (one partial per run instead of per tile) and b of the next tile prefetched into `hl` during the
+// accumulation.  As a loop the compiler keeps per-lane addresses of the whole body live across it (100-130 spilled
+// registers at the 128-register budget of four workgroups per CU; laundering the lane index per tile and unrolling
+// the loop completely brings that to ~25); measured 182 us (two tiles per run), 226 us (three), 277-333 us (five:
+// one balanced round of persistent workgroups also puts the phases of the whole chip in lock-step) against 165 us.
+//
+// LDS: 2 regions of kTileFrames x SP + ~3 KB: 35 KB at SP = 32 (f32) -> four workgroups per CU.
+// Instrumentation build: -DVBX_PHASE_CLOCKS (per-workgroup phase stamps, tools/phase_timeline.py).
+#pragma once
+#include "vbx_scan.hpp"
+
+namespace vbx {
+
+#ifdef VBX_PHASE_CLOCKS
+constexpr int kClockTiles = 8192;
+__device__ long long g_phase_clocks[kClockTiles * 16];
+#endif
+
+template <typename R, int SP> struct ChunkPostCfg {
+    static constexpr int kBytes = 2 * kTileFrames * SP * (int)sizeof(R) + 6144;
+    static constexpr bool kFits = kBytes <= 160 * 1024;
+    static constexpr int kPerCU = kBytes <= 32 * 1024 ? 5 : kBytes <= 40 * 1024 ? 4 : kBytes <= 53 * 1024 ? 3
+                                  : kBytes <= 80 * 1024 ? 2 : 1;
+};
+
+// REPLAY: write gamma only (see above).
+template <typename R, int SP, bool REPLAY>
+__global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post_kernel(BatchView<R> bt) {
+    using M = Mfma16<R>;
+    using acc_t = typename M::acc_t;
+    using R2 = typename Vec<R>::v2;
+    using R4 = typename Vec<R>::v4;
+    constexpr int NREG = SP / 16;                      // states per lane in the re-run
+    constexpr int NT = SP / 16;                        // M-tiles (speakers) of the accumulation
+    constexpr int HALF = kTileFrames / 2;
+    constexpr int KS = kTileFrames / 4;                // MFMA k-steps per chunk
+    constexpr int LAT = kTileFrames * SP;
+    constexpr int NST = (LAT / 4 + 255) / 256;         // 16/32-byte vectors of a b tile per thread
+    __shared__ __attribute__((aligned(16))) R region[2][LAT];
+    __shared__ R sfl[kTileFrames];                     // s_f = sum(a_f) of the stored forward row
+    __shared__ R qfl[kTileFrames];                     // q_f: every element of the stored backward row is >= q_f > 0
+    __shared__ R tl_sig[2];
+    __shared__ int tl_expo;
+    __shared__ __attribute__((aligned(16))) R c_l[SP];
+    __shared__ __attribute__((aligned(16))) R aprev0[SP];
+    __shared__ double ent_w[4][SP];
+    __shared__ double red[16];
+
+    const int tile = blockIdx.x;
+    if (!REPLAY && bt.tile_done[tile]) return;
+    VBX_CLOCKS_DECL();
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int i16 = lane & 15, g4 = lane >> 4;
+    const int so = i16 * NREG;                         // first state of this lane
+    const int Dp = bt.Dp;
+    {
+        // one scalar load gives every address of the first round of vector loads (tile table of vbx_capi.hip)
+        const int4 td = bt.tile_desc[tile];            // {recording, t0, frames, first row}
+        const int rec = td.x, t0 = td.y, len = td.z;
+        const long long trow = td.w;
+        const int mid = len / 2;
+        const double lp_d = bt.recs[rec].lp;
+        const int n_spk = bt.recs[rec].S;
+        const R lp = (R)lp_d;
+        const R* __restrict__ rho = bt.rho + (trow - t0) * Dp;
+        R* const bl = region[0];                       // b, then a (rows >= mid) / x (rows < mid), then gamma
+        R* const afh = region[1];                      // a_f,  f < mid
+        R* const bfh = region[1] + HALF * SP;          // x_f,  f >= mid  (row f - mid)
+        VBX_STAMP();
+        stage_to_lds<NST>(reinterpret_cast<R4*>(bl), reinterpret_cast<const R4*>(bt.bmat + trow * SP), len * SP / 4, tid, 256);
+        if (tid < SP) {
+            const double pj = (REPLAY ? bt.pi_prev : bt.pi)[(long long)rec * SP + tid];
+            c_l[tid] = (tid < n_spk) ? (R)((1.0 - lp_d) * pj + 1e-8) : (R)0;
+        }
+        const bool chunk0 = (t0 == 0);
+        __syncthreads();
+        VBX_STAMP();
+
+        // ---- re-run: wave 0 forward, wave 1 backward (VBx.py:167-171 in the linear domain) ----------------------
+        // A lone wavefront on a dependent instruction stream pays ~8-10 cycles per instruction, so the loops are
+        // written for instruction count.  They carry UNNORMALISED vectors (no reciprocal on the chain),
+        //     forward :  a_t = b_t (lp a_{t-1} + c s_{t-1}),   s_t = sum a_t
+        //     backward:  x_{t-1} = lp b_t x_t + q_t,           q_t = sum c b_t x_t
+        // rescaled by an exact power of two every four frames (worst case a frame shrinks the scale by min c = 1e-8).
+        // A lane holds NREG adjacent states, 16 lanes a vector; rows of b are fetched four frames ahead.
+        R c[NREG];
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) c[r] = c_l[so + r];
+        auto load_rows = [&](R (&dst)[4][NREG], int f, int dir) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) load_pack<NREG>(dst[k], bl + (f + dir * k) * SP + so);
+        };
+        // forward state
+        R a[NREG], sig = 1, sig_in = 1;
+        int expo = 0, ff = 0;
+        auto f_renorm = [&]() {
+            const int e = rescale_exponent(sig);
+            expo += e;
+            sig = scale2(sig, -e);
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) a[r] = scale2(a[r], -e);
+        };
+        auto f_store = [&](int f) { store_pack<NREG>((f < mid ? afh + f * SP : bl + f * SP) + so, a); sfl[f] = sig; };
+        auto f_step = [&](const R (&b)[NREG], int f) {
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) a[r] = b[r] * (lp * a[r] + c[r] * sig);
+            R sm = a[0];
+#pragma unroll
+            for (int r = 1; r < NREG; ++r) sm += a[r];
+            sig = allreduce_sum<16>(sm);
+            f_store(f);
+        };
+        auto f_run = [&](int end) {                              // frames ff .. end-1
+            R cu[4][NREG], nx[4][NREG];
+            if (ff + 4 <= end) load_rows(cu, ff, 1);
+            for (; ff + 4 <= end; ff += 4) {
+                if (ff + 8 <= end) load_rows(nx, ff + 4, 1);
+                f_renorm();
+#pragma unroll
+                for (int k = 0; k < 4; ++k) f_step(cu[k], ff + k);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int r = 0; r < NREG; ++r) cu[k][r] = nx[k][r];
+            }
+            f_renorm();
+            for (; ff < end; ++ff) {
+                R b[NREG];
+                load_pack<NREG>(b, bl + ff * SP + so);
+                f_step(b, ff);
+            }
+        };
+        // backward state: x = x_{fb} (unnormalised), produced by consuming rows > fb
+        R x[NREG], q = 1;
+        int fb = len - 1;
+        auto b_store = [&](int f) { store_pack<NREG>((f < mid ? bl + f * SP : bfh + (f - mid) * SP) + so, x); qfl[f] = q; };
+        auto b_step = [&](const R (&b)[NREG], bool store) {      // consumes row fb, produces x_{fb-1}
+            R u[NREG];
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) u[r] = b[r] * x[r];
+            R qs = c[0] * u[0];
+#pragma unroll
+            for (int r = 1; r < NREG; ++r) qs += c[r] * u[r];
+            q = allreduce_sum<16>(qs);
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) x[r] = lp * u[r] + q;
+            --fb;
+            if (store) b_store(fb);
+        };
+        auto b_renorm = [&]() {
+            const int e = rescale_exponent(q);
+            q = scale2(q, -e);                                   // (x_{mid-1} and its q wait in registers for the barrier)
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) x[r] = scale2(x[r], -e);
+        };
+
+        if (wave == 0) {
+            const R* __restrict__ bnd = bt.fbound + (long long)tile * SP + so;
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) {
+                a[r] = bnd[r];
+                if (!chunk0) aprev0[so + r] = a[r];              // a[t0-1] (any scale) for the statistics of frame t0
+                if (chunk0) a[r] *= bl[so + r];                  // frame 0: a_0 = b_0 (ip + 1e-8), VBx.py:163
+            }
+            sig = a[0];
+#pragma unroll
+            for (int r = 1; r < NREG; ++r) sig += a[r];
+            sig = allreduce_sum<16>(sig);
+            sig_in = sig;
+            if (chunk0) {
+                f_store(0);                                      // (row 0 of bl if len == 1: b_0 is not needed again)
+                ff = 1;
+            }
+            f_run(max(mid, ff));                                 // rows < mid -> afh
+        } else if (wave == 1) {
+            const R* __restrict__ bnd = bt.gbound + (long long)tile * SP + so;
+            R part = 0;
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) {
+                x[r] = bnd[r];
+                part += x[r];
+            }
+            part = allreduce_sum<16>(part);
+            const int e = rescale_exponent(part);
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) x[r] = scale2(x[r], -e);
+            q = scale2(part, -e) * (R)(1.0 / SP);                // a positive scale of the row, like q of the steps
+            b_store(len - 1);                                    // -> bfh (len-1 >= mid always)
+            // consume rows len-1 .. max(mid, 1); the outputs with index >= mid go to bfh, the last one (x_{mid-1})
+            // stays in registers until the barrier: its slot in bl still holds b_{mid-1}, which the forward wave
+            // may not have consumed yet
+            const int stop = max(mid, 1);
+            R cu[4][NREG], nx[4][NREG];
+            if (fb - 3 >= stop) load_rows(cu, fb, -1);
+            while (fb - 3 >= stop) {                             // a block of four rows fb .. fb-3, all >= stop
+                const bool last_block = fb - 4 < stop;           // its last output is x_{stop-1}
+                if (fb - 7 >= stop) load_rows(nx, fb - 4, -1);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) b_step(cu[k], !(last_block && k == 3) || stop - 1 >= mid);
+                b_renorm();
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int r = 0; r < NREG; ++r) cu[k][r] = nx[k][r];
+            }
+            while (fb >= stop) {
+                R b[NREG];
+                load_pack<NREG>(b, bl + fb * SP + so);
+                b_step(b, fb - 1 >= mid);
+            }
+        }
+        VBX_STAMP();
+        __syncthreads();                                         // midpoint: rows >= mid of b are consumed by the backward
+                                                                 // wave, rows < mid by the forward wave
+        if (wave == 0) {
+            f_run(len);                                          // rows >= mid -> bl (over b_f, after reading it)
+            if (lane == 0) {
+                tl_sig[0] = sig;
+                tl_sig[1] = chunk0 ? (R)1 : sig_in;
+                tl_expo = expo;
+            }
+        } else if (wave == 1 && mid >= 1) {
+            // x = x_{mid-1} is in registers, rows mid-1 .. 1 remain.  Every output x_{f-1} lands on b_{f-1}, the row
+            // the NEXT step consumes, so rows are always in registers before their slot is written: up to three
+            // leading single rows and the first block of four are fetched before the first store.
+            const int n = fb, tail = n & 3;                      // fb == mid - 1
+            R lead[3][NREG], cu[4][NREG], nx[4][NREG];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (k < tail) load_pack<NREG>(lead[k], bl + (fb - k) * SP + so);
+            if (n - tail >= 4) load_rows(cu, fb - tail, -1);
+            b_store(fb);                                         // x_{mid-1} -> bl[mid-1]
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (k < tail) b_step(lead[k], true);
+            if (tail) b_renorm();
+            while (fb >= 4) {                                    // blocks of four rows fb .. fb-3 (fb is a multiple of 4 here)
+                if (fb - 4 >= 4) load_rows(nx, fb - 4, -1);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) b_step(cu[k], true);
+                b_renorm();
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int r = 0; r < NREG; ++r) cu[k][r] = nx[k][r];
+            }
+        }
+        // rho fragments of the first quarter of the accumulation (d-slab `wave`): in flight during the posterior phase
+        constexpr int QK = KS / 4;                               // k-steps per quarter
+        R2 bq[2][QK];
+        // (rows past the end of the recording belong to the next recording or to the zero padding behind the last
+        //  one: finite values that meet gamma = 0, so the addresses need no clamp -- uniform base + per-lane offset)
+        const int lane_off = g4 * Dp + 2 * i16;
+        auto load_quarter = [&](R2 (&dst)[QK], int slab, int qi) {
+            const R* __restrict__ src = rho + (long long)t0 * Dp + 32 * slab;
+#pragma unroll
+            for (int u = 0; u < QK; ++u) dst[u] = *reinterpret_cast<const R2*>(src + 4 * (qi * QK + u) * Dp + lane_off);
+        };
+        if (!REPLAY && wave * 32 < Dp) load_quarter(bq[0], wave, 0);
+        VBX_STAMP();
+        __syncthreads();
+        VBX_STAMP();
+
+        // ---- posteriors and the "entered" statistic                               (VBx.py:101-103,174) --
+        //   gamma_t = a_t x_t / sum;   entered_j += gamma_t[j] s_{t-1} / (lp a_{t-1}[j] + c_j s_{t-1}),  t >= 1
+        // rows are brought to scale 1 first (a/s sums to 1, x/q >= 1 elementwise): no product can underflow.
+        // pass 1 reads (a, x, a of the previous frame) into registers, pass 2 writes gamma over bl: a row of bl may
+        // hold the a or x another frame's pass 1 still needs.
+        {
+            constexpr int NIT = kTileFrames / 16;
+            R gam[NIT][NREG], ent[NREG];
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) ent[r] = 0;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int f = 16 * it + 4 * wave + g4;
+                const bool ok = f < len;
+                const int fr = ok ? f : 0;
+                const R isig = fast_rcp(sfl[fr]), iq = fast_rcp(qfl[fr]);   // (applied one after the other: their product may overflow)
+                const R sp = fr > 0 ? sfl[fr - 1] : tl_sig[1];
+                R av[NREG], xv[NREG], ap[NREG];
+                load_pack<NREG>(av, (fr < mid ? afh + fr * SP : bl + fr * SP) + so);
+                load_pack<NREG>(xv, (fr < mid ? bl + fr * SP : bfh + (fr - mid) * SP) + so);
+                if (!REPLAY) load_pack<NREG>(ap, (fr == 0 ? aprev0 : fr - 1 < mid ? afh + (fr - 1) * SP : bl + (fr - 1) * SP) + so);
+#pragma unroll
+                for (int r = 0; r < NREG; ++r) gam[it][r] = (av[r] * isig) * (xv[r] * iq);
+                R sum = gam[it][0];
+#pragma unroll
+                for (int r = 1; r < NREG; ++r) sum += gam[it][r];
+                sum = allreduce_sum<16>(sum);
+                const R inv = ok ? fast_rcp(sum) : (R)0;
+                const bool stat = ok && t0 + f >= 1;               // frame 0 of the recording has no "entered" term
+#pragma unroll
+                for (int r = 0; r < NREG; ++r) {
+                    gam[it][r] *= inv;
+                    if (!REPLAY) {
+                        const R term = gam[it][r] * sp * fast_rcp(lp * ap[r] + c[r] * sp);
+                        ent[r] += stat ? term : (R)0;              // (select, not multiply: ap is undefined for frame 0)
+                    }
+                }
+            }
+            if (REPLAY) {
+                // the responsibilities themselves: [T][SP] in HBM (VBx.py:99,126)
+                R* __restrict__ G = bt.gamma + trow * SP;
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int f = 16 * it + 4 * wave + g4;
+                    if (f < len) store_pack<NREG>(G + f * SP + so, gam[it]);
+                }
+                return;
+            }
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) {
+                double e = (double)ent[r];                     // <= 8 terms per lane in working precision
+                e += __shfl_xor(e, 16, 64);
+                e += __shfl_xor(e, 32, 64);
+                if (g4 == 0) ent_w[wave][so + r] = e;
+            }
+            double mpartial = 0.0;                             // this chunk's share of the total log-likelihood (VBx.py:173)
+            if (tid < len) mpartial = (double)bt.mrow[trow + tid];
+            if (tid == 128)
+                mpartial += log((double)tl_sig[0]) - log((double)tl_sig[1]) + (double)tl_expo * 0.69314718055994530942;
+            mpartial = block_sum(mpartial, red);               // (its barriers also end pass 1)
+            if (tid < SP) {
+                const double e = (ent_w[0][tid] + ent_w[1][tid]) + (ent_w[2][tid] + ent_w[3][tid]);
+                bt.epart[(long long)tile * SP + tid] = tid < n_spk ? e : 0.0;
+            }
+            if (tid == 0) bt.tllpart[tile] = mpartial;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int f = 16 * it + 4 * wave + g4;
+                store_pack<NREG>(bl + f * SP + so, gam[it]);       // A operand of the accumulation below (0 past the end)
+            }
+            // iter_fin needs the responsibilities of frame 0 (VBx.py:102)
+            if (chunk0 && wave == 0 && g4 == 0) store_pack<NREG>(bt.gamma0 + (long long)rec * SP + so, gam[0]);
+        }
+        __syncthreads();
+        VBX_STAMP();
+
+        // ---- next M-step: C[s][d] = sum_t gamma[t][s] rho[t][d] on MFMA 16x16x4        (VBx.py:96) --
+        // M index i of tile mu <-> speaker NT*i + mu (one vector LDS read feeds every tile);
+        // N index j of half h <-> feature 32*slab + 2j + h (one 8/16-byte global load feeds both).
+        for (int slab = wave; slab * 32 < Dp; slab += 4) {
+            acc_t acc[NT][2];
+            R nsum[NT];
+#pragma unroll
+            for (int mu = 0; mu < NT; ++mu) {
+                acc[mu][0] = acc_t{0, 0, 0, 0};
+                acc[mu][1] = acc_t{0, 0, 0, 0};
+                nsum[mu] = 0;
+            }
+            if (slab != wave) load_quarter(bq[0], slab, 0);
+            auto quarter = [&](const R2 (&bfr)[QK], int qi) {
+#pragma unroll
+                for (int u = 0; u < QK; ++u) {
+                    const int f = 4 * (qi * QK + u) + g4;
+                    R av[NT];
+                    load_pack<NT>(av, bl + f * SP + NT * i16);
+#pragma unroll
+                    for (int mu = 0; mu < NT; ++mu) {
+                        nsum[mu] += av[mu];
+                        acc[mu][0] = M::mma(av[mu], bfr[u].x, acc[mu][0]);
+                        acc[mu][1] = M::mma(av[mu], bfr[u].y, acc[mu][1]);
+                    }
+                }
+            };
+#pragma unroll 1
+            for (int pair = 0; pair < 2; ++pair) {               // (not unrolled: bounds how many LDS reads are hoisted)
+                load_quarter(bq[1], slab, 2 * pair + 1);         // next quarter in flight
+                quarter(bq[0], 2 * pair);
+                if (pair == 0) load_quarter(bq[0], slab, 2);
+                quarter(bq[1], 2 * pair + 1);
+            }
+            R* __restrict__ part = bt.mpart + (long long)tile * SP * Dp;
+#pragma unroll
+            for (int mu = 0; mu < NT; ++mu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int s = NT * M::row(lane, r) + mu;
+                    *reinterpret_cast<R2*>(part + (long long)s * Dp + 32 * slab + 2 * i16) = R2{acc[mu][0][r], acc[mu][1][r]};
+                }
+            }
+            if (slab == 0) {
+#pragma unroll
+                for (int mu = 0; mu < NT; ++mu) {
+                    R v = nsum[mu];
+                    v += __shfl_xor(v, 16, 64);
+                    v += __shfl_xor(v, 32, 64);
+                    if (g4 == 0) bt.npart[(long long)tile * SP + NT * i16 + mu] = v;
+                }
+            }
+        }
+        VBX_STAMP();
+#ifdef VBX_PHASE_CLOCKS
+        // plain stores into a module-scope table (printf would fence the whole XCD): read with vbx_debug_clocks()
+        if (lane == 0 && (wave == 0 || wave == 2) && bt.state[rec].n_iters == 3 && tile < kClockTiles) {
+            unsigned hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            long long* dstc = g_phase_clocks + ((long long)tile * 2 + (wave >> 1)) * 8;
+            for (int k = 0; k < 7; ++k) dstc[k] = clk[k];
+            dstc[7] = hw;
+        }
+#endif
+    }
+}
+
+}  // namespace vbx

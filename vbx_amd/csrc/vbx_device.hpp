@@ -6,6 +6,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Build with -DVBX_PHASE_CLOCKS to make the two per-chunk kernels stamp the shader clock at every phase boundary
+// (the per-phase cycle counts quoted in DESIGN.md come from such builds; tools/phase_timeline.py).
+#ifdef VBX_PHASE_CLOCKS
+#define VBX_CLOCKS_DECL() long long clk[8]; int nclk = 0
+#define VBX_STAMP() do { if (nclk < 8) clk[nclk++] = clock64(); } while (0)
+#else
+#define VBX_CLOCKS_DECL()
+#define VBX_STAMP()
+#endif
+
 namespace vbx {
 
 constexpr int kWave = 64;

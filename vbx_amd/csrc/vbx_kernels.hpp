@@ -64,6 +64,9 @@ template <typename R> struct BatchView {
     R* mpart;              // [ntiles_total][Sp][Dp]   gamma^T rho per tile
     R* npart;              // [ntiles_total][Sp]       sum_t gamma per tile
     double* epart;         // [ntiles_total][Sp]       "entered" statistic per tile (VBx.py:101-103)
+    R* gamma0;             // [n_rec][Sp] or null: responsibilities of frame 0 (fused path: gamma itself is written once,
+                           // after the last iteration, vbx_chunk_post.hpp)
+    double* pi_prev;       // [n_rec][Sp] the priors the last forward-backward pass ran with (gamma replay)
     double* Li;            // [n_rec][max_iters]
     double epsilon;
     // chunked scan (VBX_FB_CHUNKED): one chunk = one tile of kTileFrames frames
@@ -217,11 +220,12 @@ __global__ __launch_bounds__(256) void mstep_fin_kernel(BatchView<R> bt) {
     const int Sp = bt.Sp, Dp = bt.Dp;
     const bool given = (st.n_iters == 0 && rd.has_model);
     const double fafb = rd.Fa / rd.Fb;
+    const int u0 = rd.tile0, nu = rd.ntiles;
     double N = 0.0;
     if (!given) {
         double part = 0.0;
-        for (int tl = threadIdx.x; tl < rd.ntiles; tl += blockDim.x)
-            part += (double)bt.npart[(long long)(rd.tile0 + tl) * Sp + s];
+        for (int tl = threadIdx.x; tl < nu; tl += blockDim.x)
+            part += (double)bt.npart[(long long)(u0 + tl) * Sp + s];
         N = block_sum(part, lds);
     }
     const long long sd = ((long long)rec * Sp + s) * Dp;
@@ -234,8 +238,8 @@ __global__ __launch_bounds__(256) void mstep_fin_kernel(BatchView<R> bt) {
         const bool dok = d < Dp;
         double C = 0.0;
         if (!given) {
-            const int nt = rd.ntiles, last = nt - 1;
-            const R* __restrict__ mp = bt.mpart + ((long long)rd.tile0 * Sp + s) * Dp + (dok ? d : 0);
+            const int nt = nu, last = nt - 1;
+            const R* __restrict__ mp = bt.mpart + ((long long)u0 * Sp + s) * Dp + (dok ? d : 0);
             const long long stride = (long long)Sp * Dp;
             const int lo = half == 0 ? 0 : (nt + 1) / 2, hi = half == 0 ? (nt + 1) / 2 : nt;
             constexpr int LB = sizeof(R) == 8 ? 20 : 40;       // loads in flight per thread: T = 10 000 in one round trip
@@ -613,34 +617,38 @@ __global__ __launch_bounds__(256) void iter_fin_kernel(BatchView<R> bt) {
     const RecDesc rd = bt.recs[rec];
     const int Sp = bt.Sp, j = threadIdx.x;
     // "entered" statistic: thread (slot, state) sums tiles slot, slot+nslot, ... ; Sp divides 256
+    const int u0 = rd.tile0, nu = rd.ntiles;
     const int nslot = 256 / Sp, slot = threadIdx.x / Sp, sj = threadIdx.x % Sp;
     double part = 0.0;
-    for (int tl = slot; tl < rd.ntiles; tl += 16 * nslot) {
+    for (int tl = slot; tl < nu; tl += 16 * nslot) {
         double v[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u)
-            v[u] = (tl + u * nslot < rd.ntiles) ? bt.epart[(long long)(rd.tile0 + tl + u * nslot) * Sp + sj] : 0.0;
+            v[u] = (tl + u * nslot < nu) ? bt.epart[(long long)(u0 + tl + u * nslot) * Sp + sj] : 0.0;
 #pragma unroll
         for (int u = 0; u < 16; ++u) part += v[u];
     }
     ent_sh[threadIdx.x] = part;
     double tpart = 0.0;
     if (bt.tllpart)
-        for (int tl = threadIdx.x; tl < rd.ntiles; tl += 256) tpart += bt.tllpart[rd.tile0 + tl];
+        for (int tl = threadIdx.x; tl < nu; tl += 256) tpart += bt.tllpart[u0 + tl];
     __syncthreads();
-    double pn = 0.0, em = 0.0;
+    double pn = 0.0, em = 0.0, pj = 0.0;
     if (j < rd.S) {
         double ent = 0.0;
         for (int q = 0; q < nslot; ++q) ent += ent_sh[q * Sp + j];
-        const double pj = bt.pi[(long long)rec * Sp + j];
-        const double g0 = (double)bt.gamma[rd.row0 * Sp + j];
+        pj = bt.pi[(long long)rec * Sp + j];
+        const double g0 = bt.gamma0 ? (double)bt.gamma0[(long long)rec * Sp + j] : (double)bt.gamma[rd.row0 * Sp + j];
         pn = g0 + (1.0 - rd.lp) * pj * ent;
         em = bt.emodel[(long long)rec * Sp + j];
     }
     const double tot = block_sum(pn, lds);
     const double emt = block_sum(em, lds);
     const double tll = bt.tllpart ? block_sum(tpart, lds) : st.tll;
-    if (j < Sp) bt.pi[(long long)rec * Sp + j] = pn / tot;
+    if (j < Sp) {
+        bt.pi_prev[(long long)rec * Sp + j] = pj;       // what this iteration's forward-backward pass ran with
+        bt.pi[(long long)rec * Sp + j] = pn / tot;
+    }
     if (j == 0) {
         const double elbo = tll + rd.Fa * rd.gsum + 0.5 * rd.Fb * emt;
         const int it = st.n_iters;
