@@ -106,3 +106,15 @@ def test_bench_rejects_mismatched_world_size():
     res = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '4'], env=env,
                          capture_output=True, text=True)
     assert res.returncode != 0 and 'WORLD_SIZE' in (res.stderr + res.stdout)
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus N` without a torchrun environment (how the driver calls it) becomes N ranks."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    res = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--dry-run'], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    ranks = [json.loads(line) for line in res.stdout.splitlines() if line.startswith('{')]
+    assert sorted(r['rank'] for r in ranks) == [0, 1] and all(r['world'] == 2 for r in ranks), res.stdout
