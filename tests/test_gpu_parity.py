@@ -503,10 +503,11 @@ def test_two_level_boundary_walk_equals_flat_chain(ctx, precision, tol):
             assert rel_err(a['Li'], b['Li']) <= tol, (group, i)
 
 
-@pytest.mark.parametrize('S,D', [(1, 128), (16, 40), (17, 200), (33, 128), (64, 96), (65, 128), (5, 300)])
+@pytest.mark.parametrize('S,D', [(1, 128), (16, 40), (17, 200), (33, 128), (64, 96), (65, 128), (5, 300), (128, 128),
+                                 (129, 64), (200, 128), (256, 128)])
 def test_vbx_shapes_sweep_against_the_oracle(S, D):
-    """Speaker counts across the padded widths (16 / 32 / 64 / 128: fused kernels up to 64, the sequential
-    path beyond) and feature dims that need padding or more than one alpha slice of the log-likelihood kernel."""
+    """Speaker counts across the padded widths (16 / 32 / 64: fused kernels; 128 / 256: the wide chunked scan of
+    vbx_scan_wide.hpp) and feature dims that need padding or more than one alpha slice of the log-likelihood kernel."""
     import vbx_amd
     from vbx_amd.synth import make_recording
     T = 700
@@ -523,6 +524,48 @@ def test_vbx_shapes_sweep_against_the_oracle(S, D):
         assert np.abs(g - gr).max() <= tol, (precision, np.abs(g - gr).max())
         assert np.abs(p - pr).max() <= tol and rel_err([r[0] for r in L], [r[0] for r in Lr]) <= tol
         assert np.abs(a - ar).max() <= tol * max(1.0, np.abs(ar).max()) and np.abs(il - ir).max() <= tol
+
+
+@pytest.mark.parametrize('S', [65, 128, 200])
+def test_wide_speaker_counts_at_ten_thousand_frames(ctx, S):
+    """64 < S <= 256 at T = 10 000 (AHC on a long file can hand VBx() that many clusters, vbhmm.py:150-158): the wide
+    chunked scan against the oracle after two iterations, against the sequential walk it replaces, and its time per
+    iteration next to the S = 64 case (which runs the fused kernels)."""
+    import time
+    from vbx_amd import _capi
+    from vbx_amd.synth import make_recording
+    T = 10000
+    X, Phi, _ = make_recording(T, S, seed=S, kappa=0.05)
+    g0 = np.random.default_rng(S + 1).gamma(1.0, size=(T, S))
+    g0 /= g0.sum(1, keepdims=True)
+    gr, pr, Lr = _orc().VBx(X, Phi, loopProb=0.99, Fa=0.3, Fb=17.0, pi=S, gamma=g0, maxIters=2, epsilon=-1e300)
+
+    def run(precision, algo, S_, X_, g_, iters):
+        batch = _capi.Batch(ctx, [T], [S_], 128, precision=precision, max_iters=iters + 12)
+        batch.set_option(_capi.OPT_FB_ALGO, algo)
+        batch.set_recording(0, X_, Phi, np.ones(S_) / S_, g_, 0.99, 0.3, 17.0)
+        batch.run(iters, -np.inf)
+        res = batch.result(0, want_model=False)
+        t0 = time.perf_counter()
+        batch.run(10, -np.inf)
+        res['ms_per_iteration'] = 100.0 * (time.perf_counter() - t0)
+        batch.close()
+        return res
+    timing = {}
+    for precision, tol in (('fp64', 5e-6), ('fp32', FP32_TOL)):
+        res = run(precision, _capi.FB_CHUNKED, S, X, g0, 2)
+        seq = run(precision, _capi.FB_SEQUENTIAL, S, X, g0, 2)
+        assert np.abs(res['gamma'] - gr).max() <= tol, (precision, np.abs(res['gamma'] - gr).max())
+        assert np.abs(res['pi'] - pr).max() <= tol and rel_err(res['Li'], [r[0] for r in Lr]) <= 1e-6
+        assert np.abs(res['gamma'] - seq['gamma']).max() <= tol
+        timing[precision] = (res['ms_per_iteration'], seq['ms_per_iteration'])
+    X64, _, _ = make_recording(T, 64, seed=64, kappa=0.05)
+    g64 = np.random.default_rng(65).gamma(1.0, size=(T, 64))
+    g64 /= g64.sum(1, keepdims=True)
+    ref64 = run('fp32', _capi.FB_AUTO, 64, X64, g64, 2)['ms_per_iteration']
+    print(f'S={S}: wide scan {timing["fp32"][0]:.3f} ms / iteration (sequential walk {timing["fp32"][1]:.3f}, '
+          f'S=64 fused {ref64:.3f}); fp64 {timing["fp64"][0]:.3f} ({timing["fp64"][1]:.3f})')
+    assert timing['fp32'][0] < timing['fp32'][1]            # the chunked scan beats the walk it replaces
 
 
 @pytest.mark.parametrize('precision,tol', [('fp64', 2e-8), ('fp32', 2e-5)])

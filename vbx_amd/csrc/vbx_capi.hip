@@ -7,6 +7,7 @@
 #include "../../include/vbx_hip.h"
 #include "vbx_kernels.hpp"
 #include "vbx_scan.hpp"
+#include "vbx_scan_wide.hpp"
 #include "vbx_chunk_loglik.hpp"
 #include "vbx_chunk_post.hpp"
 #include "vbx_linkage.hpp"
@@ -286,6 +287,23 @@ template <typename R, int SP> void launch_scan(vbx_batch* b, const BatchView<R>&
     }
 }
 
+// 64 < S <= 256: the same three steps with operators that live in HBM (vbx_scan_wide.hpp)
+template <typename R, int SP> void launch_scan_wide(vbx_batch* b, const BatchView<R>& v) {
+    hipStream_t st = b->ctx->stream;
+    {
+        LaunchScope ls(b, VBX_K_FB);
+        hipLaunchKernelGGL((scan1_wide_kernel<R, SP>), dim3(b->ntiles_total, SP / ScanWideCfg<R, SP>::CB), dim3(256), 0, st, v);
+    }
+    {
+        LaunchScope ls(b, VBX_K_FB_AUX);
+        hipLaunchKernelGGL((scan2_wide_kernel<R, SP>), dim3(b->n_rec, 2), dim3(1024), 0, st, v);
+    }
+    {
+        LaunchScope ls(b, VBX_K_FB);
+        hipLaunchKernelGGL((scan3_wide_kernel<R, SP>), dim3(b->ntiles_total, 2), dim3(64), 0, st, v);
+    }
+}
+
 template <typename R> bool fused_loglik_available(const vbx_batch* b) {
     if (!b->use_chunked || b->fuse < 2) return false;
     switch (b->Sp) {
@@ -314,6 +332,8 @@ template <typename R> void launch_fb(vbx_batch* b, double eps, bool fused_post =
             case 16: launch_scan<R, 16>(b, v, fused_post, fused_loglik); return;
             case 32: launch_scan<R, 32>(b, v, fused_post, fused_loglik); return;
             case 64: launch_scan<R, 64>(b, v, fused_post, fused_loglik); return;
+            case 128: launch_scan_wide<R, 128>(b, v); return;
+            case 256: launch_scan_wide<R, 256>(b, v); return;
             default: break;
         }
     }
@@ -431,16 +451,14 @@ void scratch_put(vbx_ctx* ctx, void* p, size_t) { ctx_free(ctx, p); }
 int choose_fb_algo(vbx_batch* b, bool step_api_logs) {
     int maxtiles = 0;
     for (auto& rd : b->recs) maxtiles = std::max(maxtiles, rd.ntiles);
-    bool chunked = b->Sp <= 64 && (b->fb_algo == VBX_FB_CHUNKED || (b->fb_algo == VBX_FB_AUTO && maxtiles >= 3));
+    bool chunked = b->fb_algo == VBX_FB_CHUNKED || (b->fb_algo == VBX_FB_AUTO && maxtiles >= 3);
     if (step_api_logs) chunked = false;      // lfw/lbw reconstruction uses the sequential kernel's scales
-    if (b->fb_algo == VBX_FB_CHUNKED && b->Sp > 64)
-        FAIL(b->ctx, VBX_ERR_UNSUPPORTED, "chunked scan supports S <= 64 (got padded S = %d)", b->Sp);
     if (chunked && !b->d_op) {
         const size_t rs = b->rsize, nt = (size_t)b->ntiles_total, sp = (size_t)b->Sp;
-        int rc = dmalloc_bytes(b->ctx, &b->d_op, 2 * nt * sp * sp * rs);          // two scan chunks per tile
-        if (rc == VBX_OK) rc = dmalloc(b->ctx, &b->d_opexp, 2 * nt * sp);
-        if (rc == VBX_OK) rc = dmalloc_bytes(b->ctx, &b->d_fbound, 2 * nt * sp * rs);
-        if (rc == VBX_OK) rc = dmalloc_bytes(b->ctx, &b->d_gbound, 2 * nt * sp * rs);
+        int rc = dmalloc_bytes(b->ctx, &b->d_op, nt * sp * sp * rs);
+        if (rc == VBX_OK) rc = dmalloc(b->ctx, &b->d_opexp, nt * sp);
+        if (rc == VBX_OK) rc = dmalloc_bytes(b->ctx, &b->d_fbound, nt * sp * rs);
+        if (rc == VBX_OK) rc = dmalloc_bytes(b->ctx, &b->d_gbound, nt * sp * rs);
         if (rc == VBX_OK) rc = dmalloc(b->ctx, &b->d_tllpart, nt);
         if (rc == VBX_OK) rc = dmalloc_bytes(b->ctx, &b->d_sfw, (size_t)b->sum_T * rs);
         if (rc == VBX_OK) rc = dmalloc_bytes(b->ctx, &b->d_dump, 1024 * rs);
@@ -463,7 +481,7 @@ int choose_fb_algo(vbx_batch* b, bool step_api_logs) {
     }
     // two-level walk over the chunk boundaries: groups of ~sqrt(K) chunks once the flat chain gets long
     int group = 1;
-    if (chunked) {
+    if (chunked && b->Sp <= 64) {            // (the wide scan walks the flat chain)
         if (b->scan_group >= 2) group = b->scan_group;
         else if (b->scan_group == 0 && maxchunks >= b->two_level_from)
             group = std::max(4, (int)std::lround(std::sqrt((double)maxchunks)));
