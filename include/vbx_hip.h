@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VBX_ABI_VERSION 2
+#define VBX_ABI_VERSION 3
 
 /* error codes */
 #define VBX_OK 0
@@ -183,6 +183,11 @@ int vbx_run(vbx_ctx* ctx, const vbx_problem* problem, vbx_result* result);
 int vbx_forward_backward(vbx_ctx* ctx, int64_t T, int32_t S, const double* lls, const double* pi,
                          const double* ip, double loopProb, int precision, int fb_algo, double* gamma,
                          double* tll, double* entered, double* lfw, double* lbw);
+/* forward_backward (VBx.py:146-175) for ANY transition matrix tr [S][S] (row i: from state i) and initial-state
+ * probabilities ip [S]; eps = 1e-8 is added to both as VBx.py:158,163 do.  lls [T][S] -> gamma [T][S] (state
+ * posteriors), tll, lfw [T][S], lbw [T][S]; any output pointer may be NULL.  One dependent S x S mat-vec per frame. */
+int vbx_forward_backward_dense(vbx_ctx* ctx, int64_t T, int32_t S, const double* lls, const double* tr, const double* ip,
+                               int precision, double* gamma, double* tll, double* lfw, double* lbw);
 /* M-step (VBx.py:95-96): gamma [T][S], X [T][D], Phi [D] -> alpha, invL [S][D]. */
 int vbx_mstep(vbx_ctx* ctx, int64_t T, int32_t S, int32_t D, const double* X, const double* Phi,
               const double* gamma, double Fa, double Fb, int precision, double* alpha, double* invL);

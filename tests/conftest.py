@@ -36,3 +36,8 @@ def synth_cases():
 @pytest.fixture(scope='session')
 def fb_cases():
     return _group(np.load(os.path.join(GOLDEN, 'fb_cases.npz')))
+
+
+@pytest.fixture(scope='session')
+def fb_dense_cases():
+    return _group(np.load(os.path.join(GOLDEN, 'fb_dense_cases.npz')))

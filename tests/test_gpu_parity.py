@@ -154,8 +154,32 @@ def test_module_level_forward_backward(fb_cases):
     post, tll, lfw, lbw = vbx_amd.forward_backward(c['lls'], tr, c['pi'])
     np.testing.assert_allclose(post, c['post'], rtol=0, atol=1e-9)
     np.testing.assert_allclose(tll, c['tll'], rtol=1e-11)
-    with pytest.raises(NotImplementedError):
-        vbx_amd.forward_backward(c['lls'], np.random.default_rng(0).random((S, S)), c['pi'])
+
+
+@pytest.mark.parametrize('precision,tol', [('fp64', 1e-9), ('fp32', 2e-5)])
+def test_forward_backward_with_arbitrary_transition_matrices(fb_dense_cases, precision, tol):
+    """vbx_amd.forward_backward takes any transition matrix, like VBx.py:146-175 (dense kernel, vbx_fb_dense.hpp):
+    dense Dirichlet rows, mostly-zero rows, a left-to-right chain, S up to 130, one frame -- against the reference's
+    own outputs.  log-domain outputs are compared where they are not at the floor the eps of VBx.py:158 sets."""
+    import vbx_amd
+    for name, c in fb_dense_cases.items():
+        post, tll, lfw, lbw = vbx_amd.forward_backward(c['lls'], c['tr'], c['ip'], precision=precision)
+        assert post.shape == c['post'].shape and post.dtype == np.float64
+        np.testing.assert_allclose(post, c['post'], rtol=0, atol=tol, err_msg=name)
+        np.testing.assert_allclose(tll, c['tll'], rtol=1e-11 if precision == 'fp64' else 1e-6, err_msg=name)
+        scale = np.abs(c['lfw']).max()
+        np.testing.assert_allclose(lfw, c['lfw'], rtol=0, atol=(1e-9 if precision == 'fp64' else 2e-5) * scale, err_msg=name)
+        np.testing.assert_allclose(lbw, c['lbw'], rtol=0, atol=(1e-9 if precision == 'fp64' else 2e-5) * max(1.0, np.abs(c['lbw']).max()),
+                                   err_msg=name)
+    # a matrix of the form VBx() builds still takes the kernels of the EM loop, and both paths agree
+    c = fb_dense_cases['dense_T300_S31']
+    S = len(c['ip'])
+    tr = np.eye(S) * 0.9 + 0.1 * c['ip']
+    a = vbx_amd.forward_backward(c['lls'], tr, c['ip'], precision=precision)
+    from vbx_amd import _capi
+    b = _capi.default_context().forward_backward_dense(c['lls'], tr, c['ip'], precision=precision)
+    np.testing.assert_allclose(a[0], b[0], rtol=0, atol=tol)
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-11 if precision == 'fp64' else 1e-6)
 
 
 # ------------------------------------------------------------------------------------ VBx()

@@ -126,39 +126,40 @@ def DER(q, ref, expected=True, xentropy=False):
 
 
 def _split_transition(tr):
-    """tr = loopProb*I + 1 (x) off  ->  (loopProb, off[S]); raises if tr is not of that form."""
-    tr = np.asarray(tr, dtype=np.float64)
+    """tr = loopProb*I + 1 (x) off  ->  (loopProb, off[S]), or None if tr is not of that form (VBx.py:98 builds
+    exactly this form; the kernels of the EM loop exploit it)."""
     S = tr.shape[0]
-    if tr.shape != (S, S):
-        raise ValueError('tr must be square')
     if S == 1:
         return 0.0, tr[0].copy()
     off = np.where(np.eye(S, dtype=bool), np.nan, tr)
     col = np.nanmean(off, axis=0)
     if not np.allclose(np.nan_to_num(off - col), 0.0, rtol=0, atol=1e-12 * max(1.0, np.abs(tr).max())):
-        raise NotImplementedError('vbx_amd.forward_backward supports transition matrices of the form '
-                                  'I*loopProb + (1-loopProb)*pi (VBx.py:98) only')
+        return None
     diag = np.diag(tr) - col
     if not np.allclose(diag, diag[0], rtol=0, atol=1e-12):
-        raise NotImplementedError('vbx_amd.forward_backward: non-constant self-loop probability')
-    return float(diag[0]), col
+        return None
+    lp = float(diag[0])
+    if not 0.0 <= lp <= 1.0 or (lp == 1.0 and np.any(col != 0.0)):
+        return None
+    return lp, col
 
 
 def forward_backward(lls, tr, ip, *, precision='fp64', device=None):
-    """HMM state posteriors for the transition structure VBx() uses.  Same signature and
-    return tuple as VBx.py:146-175: ``(post[T,S], tll, lfw[T,S], lbw[T,S])``."""
+    """HMM state posteriors.  Same signature and return tuple as VBx.py:146-175: ``(post[T,S], tll, lfw[T,S],
+    lbw[T,S])``, for any transition matrix: the structure VBx() itself builds (``I*loopProb + (1-loopProb)*pi``,
+    VBx.py:98) runs on the kernels of the EM loop, everything else on the dense kernel (vbx_fb_dense.hpp)."""
     lls = np.asarray(lls, dtype=np.float64)
     ip = np.asarray(ip, dtype=np.float64)
-    lp, off = _split_transition(tr)
-    if not 0.0 <= lp <= 1.0:
-        raise NotImplementedError('self-loop probability outside [0, 1]')
-    if lp < 1.0:
-        pi_eff = off / (1.0 - lp)
-    elif np.any(off != 0.0):
-        raise NotImplementedError('loopProb == 1 with non-zero off-diagonal transitions')
-    else:
-        pi_eff = np.zeros_like(off)
+    tr = np.asarray(tr, dtype=np.float64)
+    if lls.ndim != 2 or tr.shape != (lls.shape[1], lls.shape[1]) or ip.shape != (lls.shape[1],):
+        raise ValueError('forward_backward: lls [T][S], tr [S][S], ip [S] expected')
     ctx = _capi.default_context(device)
+    split = _split_transition(tr)
+    if split is None:
+        post, tll, lfw, lbw = ctx.forward_backward_dense(lls, tr, ip, precision=precision)
+        return post, np.float64(tll), lfw, lbw
+    lp, off = split
+    pi_eff = off / (1.0 - lp) if lp < 1.0 else np.zeros_like(off)
     post, tll, _entered, lfw, lbw = ctx.forward_backward(lls, pi_eff, lp, ip=ip, precision=precision,
                                                          want_logs=True)
     return post, np.float64(tll), lfw, lbw

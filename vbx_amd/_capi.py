@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     'vbx_abi_version', 'vbx_create', 'vbx_destroy', 'vbx_last_error', 'vbx_device_info',
     'vbx_batch_create', 'vbx_batch_destroy', 'vbx_batch_set_option', 'vbx_batch_set_recording',
     'vbx_batch_run', 'vbx_batch_get_result', 'vbx_batch_last_run_ms', 'vbx_batch_kernel_times',
-    'vbx_run', 'vbx_forward_backward', 'vbx_mstep', 'vbx_loglik',
+    'vbx_run', 'vbx_forward_backward', 'vbx_forward_backward_dense', 'vbx_mstep', 'vbx_loglik',
     'vbx_cos_similarity', 'vbx_scores_upload', 'vbx_scores_count', 'vbx_scores_get', 'vbx_scores_get_condensed',
     'vbx_linkage_average', 'vbx_fcluster_distance', 'vbx_ark_index', 'vbx_gather_rows', 'vbx_batch_streams',
     'vbx_scores_two_gmm_calib',
@@ -77,6 +77,7 @@ def load():
     lib.vbx_run.argtypes = [vp, vp, vp]
     lib.vbx_forward_backward.argtypes = [vp, i64, i32, vp, vp, vp, dbl, C.c_int, C.c_int, vp, C.POINTER(dbl),
                                          vp, vp, vp]
+    lib.vbx_forward_backward_dense.argtypes = [vp, i64, i32, vp, vp, vp, C.c_int, vp, C.POINTER(dbl), vp, vp]
     lib.vbx_mstep.argtypes = [vp, i64, i32, i32, vp, vp, vp, dbl, dbl, C.c_int, vp, vp]
     lib.vbx_loglik.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, dbl, C.c_int, vp]
     lib.vbx_cos_similarity.argtypes = [vp, i64, i32, vp, C.POINTER(vp)]
@@ -169,6 +170,20 @@ class Context:
                                                   C.byref(tll), _ptr(entered), _ptr(lfw), _ptr(lbw)),
                    'vbx_forward_backward')
         return gamma, tll.value, entered, lfw, lbw
+
+    def forward_backward_dense(self, lls, tr, ip, precision='fp64', want_logs=True):
+        """forward_backward (VBx.py:146-175) for any S x S transition matrix."""
+        lls, tr, ip = _f64(lls), _f64(tr), _f64(ip)
+        T, S = lls.shape
+        assert tr.shape == (S, S) and ip.shape == (S,)
+        gamma = np.empty((T, S))
+        lfw = np.empty((T, S)) if want_logs else None
+        lbw = np.empty((T, S)) if want_logs else None
+        tll = C.c_double()
+        self.check(self._lib.vbx_forward_backward_dense(self._h, T, S, _ptr(lls), _ptr(tr), _ptr(ip),
+                                                        precision_code(precision), _ptr(gamma), C.byref(tll),
+                                                        _ptr(lfw), _ptr(lbw)), 'vbx_forward_backward_dense')
+        return gamma, tll.value, lfw, lbw
 
     def mstep(self, X, Phi, gamma, Fa, Fb, precision='fp64'):
         X, Phi, gamma = _f64(X), _f64(Phi), _f64(gamma)

@@ -8,6 +8,7 @@
 #include "vbx_kernels.hpp"
 #include "vbx_scan.hpp"
 #include "vbx_scan_wide.hpp"
+#include "vbx_fb_dense.hpp"
 #include "vbx_chunk_loglik.hpp"
 #include "vbx_chunk_post.hpp"
 #include "vbx_linkage.hpp"
@@ -1439,6 +1440,107 @@ int vbx_forward_backward(vbx_ctx* ctx, int64_t T, int32_t S, const double* lls, 
                                         : fb_step_impl<float>(b, T, S, lls, gamma, tll, entered, lfw, lbw);
     vbx_batch_destroy(b);
     return rc;
+}
+
+extern "C++" {
+namespace {
+template <typename R>
+int fb_dense_impl(vbx_ctx* ctx, int64_t T, int32_t S, const double* lls, const double* tr, const double* ip, double* gamma,
+                  double* tll, double* lfw, double* lbw) {
+    int Sp = 16;
+    while (Sp < S) Sp *= 2;
+    const size_t cells = (size_t)T * Sp;
+    std::vector<R> bm(cells, (R)0), m0((size_t)Sp * Sp, (R)0), m1((size_t)Sp * Sp, (R)0), v0(Sp, (R)0);
+    std::vector<double> mr((size_t)T);
+    for (int64_t t = 0; t < T; ++t) {
+        double m = -INFINITY;
+        for (int s = 0; s < S; ++s) m = std::max(m, lls[(size_t)t * S + s]);
+        mr[(size_t)t] = m;
+        for (int s = 0; s < S; ++s) bm[(size_t)t * Sp + s] = (R)std::exp(lls[(size_t)t * S + s] - m);
+    }
+    for (int i = 0; i < S; ++i) {
+        v0[i] = (R)(ip[i] + 1e-8);                                   // VBx.py:163
+        for (int j = 0; j < S; ++j) {
+            const R a = (R)(tr[(size_t)i * S + j] + 1e-8);           // VBx.py:158
+            m0[(size_t)i * Sp + j] = a;                              // forward: M[k][o] = A[k][o]
+            m1[(size_t)j * Sp + i] = a;                              // backward: M[k][o] = A[o][k]
+        }
+    }
+    R *d_m0 = nullptr, *d_m1 = nullptr, *d_b = nullptr, *d_v0 = nullptr, *d_ah = nullptr, *d_bh = nullptr, *d_fs = nullptr, *d_bs = nullptr;
+    int rc = dmalloc(ctx, &d_m0, m0.size());
+    if (rc == VBX_OK) rc = dmalloc(ctx, &d_m1, m1.size());
+    if (rc == VBX_OK) rc = dmalloc(ctx, &d_b, cells);
+    if (rc == VBX_OK) rc = dmalloc(ctx, &d_v0, (size_t)Sp);
+    if (rc == VBX_OK) rc = dmalloc(ctx, &d_ah, cells);
+    if (rc == VBX_OK) rc = dmalloc(ctx, &d_bh, cells);
+    if (rc == VBX_OK) rc = dmalloc(ctx, &d_fs, (size_t)T);
+    if (rc == VBX_OK) rc = dmalloc(ctx, &d_bs, (size_t)T);
+    auto release = [&]() {
+        for (void* p : {(void*)d_m0, (void*)d_m1, (void*)d_b, (void*)d_v0, (void*)d_ah, (void*)d_bh, (void*)d_fs, (void*)d_bs}) ctx_free(ctx, p);
+    };
+    if (rc != VBX_OK) { release(); return rc; }
+    hipStream_t st = ctx->stream;
+    hipError_t e = hipMemcpyAsync(d_m0, m0.data(), sizeof(R) * m0.size(), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_m1, m1.data(), sizeof(R) * m1.size(), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_b, bm.data(), sizeof(R) * cells, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_v0, v0.data(), sizeof(R) * Sp, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+#define VBX_FB_DENSE(SP_) hipLaunchKernelGGL((fb_dense_kernel<R, SP_>), dim3(2), dim3(FbDenseCfg<SP_>::kThreads), 0, st, \
+                                             d_m0, d_m1, d_b, d_v0, d_ah, d_bh, d_fs, d_bs, (int)T, (int)S)
+        switch (Sp) {
+            case 16: VBX_FB_DENSE(16); break;
+            case 32: VBX_FB_DENSE(32); break;
+            case 64: VBX_FB_DENSE(64); break;
+            case 128: VBX_FB_DENSE(128); break;
+            default: VBX_FB_DENSE(256); break;
+        }
+#undef VBX_FB_DENSE
+        e = hipGetLastError();
+    }
+    std::vector<R> ah(cells), bh(cells), fs((size_t)T), bs((size_t)T);
+    if (e == hipSuccess) e = hipMemcpyAsync(ah.data(), d_ah, sizeof(R) * cells, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(bh.data(), d_bh, sizeof(R) * cells, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(fs.data(), d_fs, sizeof(R) * (size_t)T, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(bs.data(), d_bs, sizeof(R) * (size_t)T, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    release();
+    if (e != hipSuccess) FAIL(ctx, VBX_ERR_HIP, "forward_backward (dense): %s", hipGetErrorString(e));
+    // lfw[t] = log ahat[t] + sum_{u<=t} (log s_u + m_u);  lbw[t] = log bhat[t] + sum_{u>=t, u<T-1} log q_u + sum_{u>t} m_u
+    double cum = 0.0;
+    for (int64_t t = 0; t < T; ++t) {
+        cum += std::log((double)fs[(size_t)t]) + mr[(size_t)t];
+        if (lfw)
+            for (int s = 0; s < S; ++s) lfw[(size_t)t * S + s] = std::log((double)ah[(size_t)t * Sp + s]) + cum;
+    }
+    if (tll) *tll = cum;
+    if (lbw) {
+        double back = 0.0;
+        for (int64_t t = T - 1; t >= 0; --t) {
+            if (t < T - 1) back += std::log((double)bs[(size_t)t]) + mr[(size_t)t + 1];
+            for (int s = 0; s < S; ++s) lbw[(size_t)t * S + s] = std::log((double)bh[(size_t)t * Sp + s]) + back;
+        }
+    }
+    if (gamma)
+        for (int64_t t = 0; t < T; ++t) {
+            double tot = 0.0;
+            for (int s = 0; s < S; ++s) tot += (double)ah[(size_t)t * Sp + s] * (double)bh[(size_t)t * Sp + s];
+            for (int s = 0; s < S; ++s)
+                gamma[(size_t)t * S + s] = (double)ah[(size_t)t * Sp + s] * (double)bh[(size_t)t * Sp + s] / tot;
+        }
+    return VBX_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+int vbx_forward_backward_dense(vbx_ctx* ctx, int64_t T, int32_t S, const double* lls, const double* tr, const double* ip,
+                               int precision, double* gamma, double* tll, double* lfw, double* lbw) {
+    if (!ctx) return VBX_ERR_INVALID;
+    if (!lls || !tr || !ip || T <= 0 || S <= 0) FAIL(ctx, VBX_ERR_INVALID, "vbx_forward_backward_dense: bad argument");
+    if (S > VBX_MAX_SPEAKERS) FAIL(ctx, VBX_ERR_UNSUPPORTED, "S=%d exceeds VBX_MAX_SPEAKERS=%d", S, VBX_MAX_SPEAKERS);
+    if (precision != VBX_PREC_FP32 && precision != VBX_PREC_FP64) FAIL(ctx, VBX_ERR_INVALID, "unknown precision %d", precision);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return precision == VBX_PREC_FP64 ? fb_dense_impl<double>(ctx, T, S, lls, tr, ip, gamma, tll, lfw, lbw)
+                                      : fb_dense_impl<float>(ctx, T, S, lls, tr, ip, gamma, tll, lfw, lbw);
 }
 
 int vbx_mstep(vbx_ctx* ctx, int64_t T, int32_t S, int32_t D, const double* X, const double* Phi, const double* gamma,
