@@ -195,6 +195,28 @@ int vbx_mstep(vbx_ctx* ctx, int64_t T, int32_t S, int32_t D, const double* X, co
 int vbx_loglik(vbx_ctx* ctx, int64_t T, int32_t S, int32_t D, const double* X, const double* Phi,
                const double* alpha, const double* invL, double Fa, int precision, double* log_p);
 
+/* ---- the steps of the driver either side of VBx(), for all x-vectors of an archive at once -------------------------
+ * vbhmm.py:125-129  xproj = l2_norm( l2_norm(x - mean1) lda - mean2 )       [n][Dl]       input of cos_similarity
+ * vbhmm.py:153      fea   = (xproj - plda_mu) plda_tr^T [:, :fea_dim]        [n][fea_dim]  input of VBx()
+ * Both stay resident in HBM (vbx_xvectors); x [n][Din] x_dtype, mean1 [Din], lda [Din][Dl], mean2 [Dl],
+ * plda_mu [Dl], plda_tr [Dl][Dl] (row k = k-th output dim, i.e. the array vbhmm.py:113 calls plda_tr): f64. */
+typedef struct vbx_xvectors vbx_xvectors;
+int vbx_xvectors_project(vbx_ctx* ctx, int64_t n, int32_t Din, int32_t Dl, int32_t fea_dim, const void* x, int x_dtype,
+                         const double* mean1, const double* lda, const double* mean2, const double* plda_mu,
+                         const double* plda_tr, vbx_xvectors** out);
+/* rows [row0, row0 + nrows) of xproj (which = 0, [nrows][Dl]) or fea (which = 1, [nrows][fea_dim]) to the host. */
+int vbx_xvectors_get(vbx_xvectors* xv, int which, int64_t row0, int64_t nrows, double* out);
+int vbx_xvectors_destroy(vbx_xvectors* xv);
+/* cos_similarity (diarization_lib.py:190-213) of the resident rows [row0, row0 + T) of xproj: nothing is uploaded. */
+int vbx_cos_similarity_resident(vbx_ctx* ctx, vbx_xvectors* xv, int64_t row0, int64_t T, struct vbx_scores** out);
+/* Recording b of a batch from resident rows of fea and the AHC labels [T] (in [0, S[b])): the initial responsibilities
+ * softmax(init_smoothing * onehot(labels)) of vbhmm.py:150-152 are built on the device, pi0 = 1/S (VBx.py:76). */
+int vbx_batch_set_recording_resident(vbx_batch* batch, int b, const vbx_xvectors* xv, int64_t row0, const int32_t* labels,
+                                     double init_smoothing, const double* Phi, double loopProb, double Fa, double Fb);
+/* vbhmm.py:160-162: np.argsort(-gamma, axis=1)[:, 0] and [:, 1] of recording b, [T] each (second: -1 when S == 1);
+ * equal responsibilities keep their index order (numpy leaves the order of ties unspecified).  Either may be NULL. */
+int vbx_batch_get_labels(vbx_batch* batch, int b, int32_t* first, int32_t* second);
+
 /* ---- score stage of the AHC initialisation (next row upstream of VBx(): vbhmm.py:135-138) -------------
  * cos_similarity(x)            /root/reference/VBx/diarization_lib.py:190-213
  * twoGMMcalib_lin(s, niters)   /root/reference/VBx/diarization_lib.py:13-31

@@ -53,18 +53,44 @@ def _check_rttm(paths, recs=RECS):
         assert open(os.path.join(paths['out'] + '2nd', rec + '.rttm'), 'rb').read() == g['rttm2_' + rec].tobytes(), rec
 
 
-def _oracle_batch(items, maxIters, epsilon, **hyper):
-    from oracle import vbx_oracle                               # checker standing in for the GPU
-    return [vbx_oracle.VBx(it['X'], it['Phi'], pi=it['pi'], gamma=it['gamma'], maxIters=maxIters, epsilon=epsilon,
-                           **hyper) for it in items]
+class OracleStages:
+    """The four stage methods of vbx_amd.vbhmm.DeviceStages on the CPU checkers (oracle/, NumPy restatements of
+    vbhmm.py:125-129,150-153,160-162): what stands in for the GPU in the CPU test-suite."""
 
+    def __init__(self):
+        self.vb_calls = 0
 
-def _oracle_scores(x):
-    from oracle import ahc_oracle
-    m = ahc_oracle.cos_similarity(x)
-    thr, _ = ahc_oracle.twoGMMcalib_lin(m.ravel())
-    from scipy.spatial.distance import squareform
-    return squareform(-m, checks=False), float(thr)
+    def project(self, recordings, models, lda_dim):
+        from vbx_amd.vbhmm import l2_norm
+        self.x = [l2_norm(models['lda'].T.dot(l2_norm(r[2] - models['mean1']).transpose()).transpose() - models['mean2'])
+                  for r in recordings]                                                        # vbhmm.py:129
+        self.fea = [(x - models['plda_mu']).dot(models['plda_tr'].T)[:, :lda_dim] for x in self.x]   # vbhmm.py:153
+        self.Phi = models['plda_psi'][:lda_dim]
+
+    def scores(self, k):
+        from oracle import ahc_oracle
+        from scipy.spatial.distance import squareform
+        m = ahc_oracle.cos_similarity(self.x[k])
+        thr, _ = ahc_oracle.twoGMMcalib_lin(m.ravel())
+        return squareform(-m, checks=False), float(thr)
+
+    def vb(self, ks, labels, init_smoothing, maxIters, epsilon, precision, **hyper):
+        from oracle import vbx_oracle                               # checker standing in for the GPU
+        from scipy.special import softmax
+        self.vb_calls += 1
+        out = []
+        for k, lab in zip(ks, labels):
+            qinit = np.zeros((len(lab), np.max(lab) + 1))
+            qinit[range(len(lab)), lab] = 1.0
+            qinit = softmax(qinit * init_smoothing, axis=1)                                   # vbhmm.py:150-152
+            q, _sp, L = vbx_oracle.VBx(self.fea[k], self.Phi, pi=qinit.shape[1], gamma=qinit, maxIters=maxIters,
+                                       epsilon=epsilon, **hyper)
+            order = np.argsort(-q, axis=1)                                                    # vbhmm.py:160-162
+            out.append((order[:, 0], order[:, 1] if q.shape[1] > 1 else None, len(L)))
+        return out
+
+    def close(self):
+        pass
 
 
 # ---- formats ----------------------------------------------------------------------------------------------------
@@ -170,7 +196,7 @@ def test_driver_reproduces_the_reference_rttm_with_oracle_stages(tmp_path, capsy
     from vbx_amd import vbhmm
     paths = _write_inputs(tmp_path)
     args = vbhmm.build_parser().parse_args(_argv(paths))
-    state, timing = vbhmm.diarize(args, run_batch=_oracle_batch, score_stage=_oracle_scores)
+    state, timing = vbhmm.diarize(args, stages=OracleStages())
     assert capsys.readouterr().out.split() == list(RECS)                 # vbhmm.py:121 prints each recording
     assert list(state) == list(RECS) and timing['recordings'] == 3 and timing['xvectors'] == 1025
     assert all(st['n_iters'] >= 2 for st in state.values())
@@ -183,15 +209,36 @@ def test_driver_ahc_only_and_argument_checks(tmp_path):
     argv = _argv(paths)
     argv[1] = 'AHC'
     args = vbhmm.build_parser().parse_args(argv)
-    called = []
-    state, _ = vbhmm.diarize(args, run_batch=lambda *a, **k: called.append(1), score_stage=_oracle_scores, log=lambda *_: None)
-    assert not called and all(st['n_iters'] == 0 and st['labels2nd'] is None for st in state.values())
+    stages = OracleStages()
+    state, _ = vbhmm.diarize(args, stages=stages, log=lambda *_: None)
+    assert not stages.vb_calls and all(st['n_iters'] == 0 and st['labels2nd'] is None for st in state.values())
     assert sorted(os.listdir(paths['out'])) == [r + '.rttm' for r in RECS] and not os.path.exists(paths['out'] + '2nd')
     args.loopP = 1.5
     with pytest.raises(AssertionError):                                    # vbhmm.py:103
-        vbhmm.diarize(args, run_batch=_oracle_batch, score_stage=_oracle_scores, log=lambda *_: None)
+        vbhmm.diarize(args, stages=OracleStages(), log=lambda *_: None)
     with pytest.raises(SystemExit):
         vbhmm.build_parser().parse_args(['--init', 'VB'])
+
+
+def test_driver_leaves_out_only_the_recording_it_cannot_take(tmp_path):
+    """A recording whose VB-HMM stage fails (here: one the stage object refuses) costs only itself: the others are
+    diarized and written, then the error names it."""
+    from vbx_amd import vbhmm
+    from vbx_amd._capi import VbxError
+    paths = _write_inputs(tmp_path)
+    args = vbhmm.build_parser().parse_args(_argv(paths))
+
+    class Picky(OracleStages):
+        def vb(self, ks, labels, *a, **k):
+            if 1 in ks:                                   # recB: in the batch, and again alone
+                raise VbxError('recording refused')
+            return super().vb(ks, labels, *a, **k)
+    with pytest.raises(RuntimeError, match='recB'):
+        vbhmm.diarize(args, stages=Picky(), log=lambda *_: None)
+    assert sorted(os.listdir(paths['out'])) == ['recA.rttm', 'recC.rttm']
+    want = np.load(GOLD)
+    for rec in ('recA', 'recC'):
+        assert open(os.path.join(paths['out'], rec + '.rttm'), 'rb').read() == want['rttm_' + rec].tobytes()
 
 
 def _free_port():
@@ -211,7 +258,7 @@ def _worker(rank, world, port, tmp):
         paths = {k: os.path.join(tmp, v) for k, v in dict(ark='split3.ark', seg='split3.seg', plda='plda',
                                                           transform='transform.npz', out='rttm').items()}
         args = vbhmm.build_parser().parse_args(td._argv(paths))
-        state, timing = vbhmm.diarize(args, run_batch=td._oracle_batch, score_stage=td._oracle_scores, log=lambda *_: None)
+        state, timing = vbhmm.diarize(args, stages=td.OracleStages(), log=lambda *_: None)
         assert (timing['rank'], timing['world']) == (rank, world)
         with open(os.path.join(tmp, f'rank{rank}.txt'), 'w') as fd:
             fd.write(' '.join(state))
@@ -246,6 +293,57 @@ def test_driver_reproduces_the_reference_rttm_on_the_gpu(tmp_path, capsys):
     paths32 = dict(paths, out=os.path.join(str(tmp_path), 'rttm32'))
     assert vbhmm.main(_argv(paths32, ['--precision', 'fp32'])) == 0
     _check_rttm(paths32)
+
+
+@pytest.mark.gpu
+def test_device_stages_against_what_the_reference_driver_computed(tmp_path):
+    """The steps either side of VBx() on the device against the values captured from the UNCHANGED reference driver
+    (tests/golden/frontend_split3.npz, make_golden_frontend.py): projected x-vectors (vbhmm.py:125-129), PLDA
+    projection (vbhmm.py:153), first / second speaker of every x-vector after the batched VB-HMM started from the
+    reference's AHC labels (vbhmm.py:160-162), and the initial responsibilities built on the device from those labels
+    (vbhmm.py:150-152), checked through one EM iteration against the oracle started from the reference's own qinit."""
+    from vbx_amd import vbhmm, _capi
+    from oracle import vbx_oracle
+    paths = _write_inputs(tmp_path)
+    args = vbhmm.build_parser().parse_args(_argv(paths))
+    models = vbhmm.load_models(args.xvec_transform, args.plda_file)
+    recordings = vbhmm._read_recordings(args.xvec_ark_file)
+    ref = np.load(os.path.join(os.path.dirname(GOLD), 'frontend_split3.npz'))
+    stages = vbhmm.DeviceStages()
+    stages.project(recordings, models, args.lda_dim)
+    ks, labels = [], []
+    for k, rec in enumerate(RECS):
+        T = len(recordings[k][1])
+        xproj = stages.xv.get('xproj', stages.row0[k], T)
+        fea = stages.xv.get('fea', stages.row0[k], T)
+        np.testing.assert_allclose(xproj, ref[rec + '/xproj'], rtol=0, atol=1e-14, err_msg=rec)
+        np.testing.assert_allclose(fea, ref[rec + '/fea'], rtol=0, atol=1e-11, err_msg=rec)     # (|fea| up to ~10; the mean goes through the product)
+        ks.append(k)
+        labels.append(np.argmax(ref[rec + '/qinit'], axis=1))            # the reference's AHC labels
+    # device qinit + batch + device arg-sort == the reference's VBx() call on ITS fea / qinit, label by label
+    out = stages.vb(ks, labels, init_smoothing=args.init_smoothing, maxIters=40, epsilon=1e-6, precision='fp64',
+                    loopProb=args.loopP, Fa=args.Fa, Fb=args.Fb)
+    for rec, (first, second, n_iters) in zip(RECS, out):
+        assert np.array_equal(first, ref[rec + '/labels1st']), rec
+        assert np.array_equal(second, ref[rec + '/labels2nd']), rec
+    # one iteration from the device-built initial responsibilities == the oracle from the reference's qinit
+    batch = _capi.Batch(stages.ctx, [stages.T[0]], [ref['recA/qinit'].shape[1]], args.lda_dim, precision='fp64', max_iters=1)
+    batch.set_recording_resident(0, stages.xv, 0, labels[0], args.init_smoothing, stages.Phi, args.loopP, args.Fa, args.Fb)
+    batch.run(1, -np.inf)
+    g, p, L = vbx_oracle.VBx(ref['recA/fea'], ref['recA/Phi'], pi=ref['recA/qinit'].shape[1], gamma=ref['recA/qinit'], maxIters=1,
+                             epsilon=-1e300, loopProb=args.loopP, Fa=args.Fa, Fb=args.Fb)
+    res = batch.result(0, want_model=False)
+    batch.close()
+    stages.close()
+    np.testing.assert_allclose(res['gamma'], g, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(res['Li'], [L[0][0]], rtol=1e-11)
+
+
+def test_top2_ties_keep_their_index_order():
+    """(host-side statement of the tie rule the device arg-sort follows: a stable sort of -q)"""
+    q = np.array([[0.5, 0.5, 0.0], [0.2, 0.4, 0.4], [0.0, 0.0, 1.0]])
+    order = np.argsort(-q, axis=1, kind='stable')
+    assert order[:, 0].tolist() == [0, 1, 2] and order[:, 1].tolist() == [1, 2, 0]
 
 
 # ---- native average linkage (host code of the library: no GPU needed) -------------------------------------------

@@ -77,29 +77,20 @@ def main():
                 'value': a.recordings * a.xvectors / wall, 'recordings_per_s': a.recordings / wall, 'seconds': wall,
                 'config': {'workload': f'{a.recordings} recordings x {a.xvectors} x-vectors (256-d), lda 128, Fa 0.3 Fb 17 loopP 0.99, '
                                        f'VB-HMM {a.precision}', 'speakers_init': [int(len(set(st['labels1st']))) for st in state.values()][:8]},
-                'stages_s': {k: round(timing[k], 4) for k in ('read', 'ahc', 'vb', 'rttm')},
+                'stages_s': {k: round(timing[k], 4) for k in ('read', 'project', 'ahc', 'vb', 'rttm')},
                 'vb_iterations': [st['n_iters'] for st in state.values()][:8]}
         if a.cpu_recordings > 0:
-            from oracle import ahc_oracle, vbx_oracle        # checker, timed as the CPU baseline (one thread)
-
-            def oracle_batch(items, maxIters, epsilon, **hyper):
-                return [vbx_oracle.VBx(it['X'], it['Phi'], pi=it['pi'], gamma=it['gamma'], maxIters=maxIters,
-                                       epsilon=epsilon, **hyper) for it in items]
-
-            def oracle_scores(x):
-                m = ahc_oracle.cos_similarity(x)
-                thr, _ = ahc_oracle.twoGMMcalib_lin(m.ravel())
-                from scipy.spatial.distance import squareform
-                return squareform(-m, checks=False), float(thr)
+            sys.path.insert(0, os.path.join(REPO, 'tests'))
+            from test_driver import OracleStages            # the CPU checkers behind the driver's stage interface (one thread)
 
             small = make_archive(os.path.join(tmp), a.cpu_recordings, a.xvectors)          # same seed: the first recordings
             args = vbhmm.build_parser().parse_args(argv_for(small, os.path.join(tmp, 'cpu')))
             t0 = time.perf_counter()
-            _, tc = vbhmm.diarize(args, run_batch=oracle_batch, score_stage=oracle_scores, **quiet)
+            _, tc = vbhmm.diarize(args, stages=OracleStages(), **quiet)
             cw = time.perf_counter() - t0
             line['cpu_baseline'] = {'value': a.cpu_recordings * a.xvectors / cw, 'unit': 'x-vectors/s', 'cores': 1, 'kind': 'port',
                                     'sample': f'{a.cpu_recordings} of the same recordings through the same driver with the oracle '
-                                              f'stages ({cw:.1f} s)', 'stages_s': {k: round(tc[k], 4) for k in ('read', 'ahc', 'vb', 'rttm')}}
+                                              f'stages ({cw:.1f} s)', 'stages_s': {k: round(tc[k], 4) for k in ('read', 'project', 'ahc', 'vb', 'rttm')}}
             line['speedup_vs_cpu_baseline'] = line['value'] / line['cpu_baseline']['value']
         print(json.dumps(line))
 

@@ -28,6 +28,8 @@ ABI_SYMBOLS = [
     'vbx_linkage_average', 'vbx_fcluster_distance', 'vbx_ark_index', 'vbx_gather_rows', 'vbx_batch_streams',
     'vbx_scores_two_gmm_calib',
     'vbx_scores_destroy',
+    'vbx_xvectors_project', 'vbx_xvectors_get', 'vbx_xvectors_destroy', 'vbx_cos_similarity_resident',
+    'vbx_batch_set_recording_resident', 'vbx_batch_get_labels',
 ]
 
 
@@ -92,6 +94,12 @@ def load():
     lib.vbx_gather_rows.argtypes = [vp, i64, vp, i64, i64, vp]
     lib.vbx_scores_two_gmm_calib.argtypes = [vp, i32, C.POINTER(dbl), vp]
     lib.vbx_scores_destroy.argtypes = [vp]
+    lib.vbx_xvectors_project.argtypes = [vp, i64, i32, i32, i32, vp, C.c_int, vp, vp, vp, vp, vp, C.POINTER(vp)]
+    lib.vbx_xvectors_get.argtypes = [vp, C.c_int, i64, i64, vp]
+    lib.vbx_xvectors_destroy.argtypes = [vp]
+    lib.vbx_cos_similarity_resident.argtypes = [vp, vp, i64, i64, C.POINTER(vp)]
+    lib.vbx_batch_set_recording_resident.argtypes = [vp, C.c_int, vp, i64, vp, dbl, vp, dbl, dbl, dbl]
+    lib.vbx_batch_get_labels.argtypes = [vp, C.c_int, vp, vp]
     for name in ABI_SYMBOLS:
         fn = getattr(lib, name)          # AttributeError here = the .so does not export the ABI
         if name in ('vbx_scores_count', 'vbx_ark_index'):
@@ -204,6 +212,49 @@ class Context:
         return out
 
 
+class XVectors:
+    """The x-vectors of an archive after the driver's projections, resident in HBM (vbx_xvectors): ``xproj`` (the rows
+    cos_similarity works on, vbhmm.py:125-129) and ``fea`` (the input of VBx(), vbhmm.py:153)."""
+
+    def __init__(self, ctx: Context, x, mean1, lda, mean2, plda_mu, plda_tr, fea_dim):
+        self.ctx, self._lib = ctx, ctx._lib
+        x = np.ascontiguousarray(x)
+        if x.dtype != np.float32:
+            x = np.ascontiguousarray(x, dtype=np.float64)
+        mean1, lda, mean2, plda_mu, plda_tr = _f64(mean1), _f64(lda), _f64(mean2), _f64(plda_mu), _f64(plda_tr)
+        n, din = x.shape
+        dl = lda.shape[1]
+        assert lda.shape == (din, dl) and mean1.shape == (din,) and mean2.shape == (dl,) and plda_mu.shape == (dl,)
+        assert plda_tr.shape == (dl, dl) and 0 < fea_dim <= dl
+        h = C.c_void_p()
+        ctx.check(self._lib.vbx_xvectors_project(ctx._h, n, din, dl, int(fea_dim), _ptr(x),
+                                                 VBX_F32 if x.dtype == np.float32 else VBX_F64, _ptr(mean1), _ptr(lda),
+                                                 _ptr(mean2), _ptr(plda_mu), _ptr(plda_tr), C.byref(h)),
+                  'vbx_xvectors_project')
+        self._h, self.n, self.dl, self.fea_dim = h, n, dl, int(fea_dim)
+
+    def get(self, which, row0=0, nrows=None):
+        """rows of 'xproj' or 'fea' as a float64 array (tests; the driver never needs them on the host)."""
+        nrows = self.n - row0 if nrows is None else nrows
+        out = np.empty((nrows, self.dl if which == 'xproj' else self.fea_dim))
+        self.ctx.check(self._lib.vbx_xvectors_get(self._h, 0 if which == 'xproj' else 1, int(row0), int(nrows), _ptr(out)),
+                       'vbx_xvectors_get')
+        return out
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.vbx_xvectors_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        if sys.is_finalizing():
+            return
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Scores:
     """A vector of float64 scores resident in HBM (vbx_scores): the T x T cosine similarities of the AHC
     initialisation, or any scores handed to the two-Gaussian calibration."""
@@ -216,6 +267,14 @@ class Scores:
         x = _f64(x)
         h = C.c_void_p()
         ctx.check(ctx._lib.vbx_cos_similarity(ctx._h, x.shape[0], x.shape[1], _ptr(x), C.byref(h)), 'vbx_cos_similarity')
+        return cls(ctx, h)
+
+    @classmethod
+    def cos_similarity_resident(cls, ctx: Context, xv: 'XVectors', row0, T):
+        """cos_similarity of rows [row0, row0 + T) of the projected x-vectors already in HBM."""
+        h = C.c_void_p()
+        ctx.check(ctx._lib.vbx_cos_similarity_resident(ctx._h, xv._h, int(row0), int(T), C.byref(h)),
+                  'vbx_cos_similarity_resident')
         return cls(ctx, h)
 
     @classmethod
@@ -320,6 +379,30 @@ class Batch:
             self._h, int(b), _ptr(X), VBX_F32 if X.dtype == np.float32 else VBX_F64, _ptr(Phi), _ptr(pi0),
             _ptr(gamma0), VBX_F32 if gamma0.dtype == np.float32 else VBX_F64, _ptr(alpha0), _ptr(invL0),
             float(loopProb), float(Fa), float(Fb)), 'vbx_batch_set_recording')
+
+    def set_recording_resident(self, b, xv: 'XVectors', row0, labels, init_smoothing, Phi, loopProb, Fa, Fb):
+        """Recording b from resident rows of ``xv.fea`` and the AHC labels: initial responsibilities
+        softmax(init_smoothing * onehot(labels)) built on the device, uniform priors (vbhmm.py:150-158)."""
+        labels = np.ascontiguousarray(labels, dtype=np.int32)
+        Phi = _f64(Phi)
+        assert labels.shape == (self.T[b],) and Phi.shape == (self.D,)
+        self.ctx.check(self._lib.vbx_batch_set_recording_resident(
+            self._h, int(b), xv._h, int(row0), _ptr(labels), float(init_smoothing), _ptr(Phi), float(loopProb),
+            float(Fa), float(Fb)), 'vbx_batch_set_recording_resident')
+
+    def labels(self, b):
+        """(first, second) speaker of every frame of recording b: np.argsort(-gamma, axis=1)[:, 0 / 1] computed on the
+        device (vbhmm.py:160-162); second is None for a single speaker."""
+        first = np.empty(self.T[b], dtype=np.int32)
+        second = np.empty(self.T[b], dtype=np.int32)
+        self.ctx.check(self._lib.vbx_batch_get_labels(self._h, int(b), _ptr(first), _ptr(second)), 'vbx_batch_get_labels')
+        return first.astype(np.int64), (second.astype(np.int64) if self.S[b] > 1 else None)
+
+    def n_iters(self, b):
+        n, w = C.c_int(), C.c_int()
+        self.ctx.check(self._lib.vbx_batch_get_result(self._h, int(b), None, None, None, 0, C.byref(n), C.byref(w), None, None),
+                       'vbx_batch_get_result')
+        return n.value
 
     def run(self, iters: int, epsilon: float = -np.inf):
         eps = float(epsilon)

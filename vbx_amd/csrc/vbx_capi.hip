@@ -13,6 +13,7 @@
 #include "vbx_chunk_post.hpp"
 #include "vbx_linkage.hpp"
 #include "vbx_ahc.hpp"
+#include "vbx_frontend.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -836,6 +837,115 @@ int set_recording_impl(vbx_batch* b, int rec, const void* X, int x_dtype, const 
 }  // namespace
 }  // extern "C++"
 
+extern "C++" {
+namespace {
+// recording `rec` from rows already in HBM: fea [T][D] f64 (vbx_xvectors) and the AHC labels; the initial
+// responsibilities are built on the device (vbhmm.py:150-152), pi0 = 1/S (VBx.py:76: pi given as an int)
+template <typename R>
+int set_recording_resident_impl(vbx_batch* b, int rec, const double* d_fea, const int32_t* labels, double hi, double lo,
+                                const double* Phi) {
+    vbx_ctx* ctx = b->ctx;
+    RecDesc& rd = b->recs[rec];
+    const int D = b->D, Dp = b->Dp, Sp = b->Sp, S = rd.S;
+    const long long T = rd.T;
+    std::vector<double> phi(Dp, 0.0), sphi(Dp, 0.0);
+    for (int d = 0; d < D; ++d) {
+        if (!(Phi[d] > 0.0)) FAIL(ctx, VBX_ERR_INVALID, "Phi[%d] must be positive", d);
+        phi[d] = Phi[d];
+        sphi[d] = std::sqrt(Phi[d]);
+    }
+    for (long long t = 0; t < T; ++t)
+        if (labels[t] < 0 || labels[t] >= S) FAIL(ctx, VBX_ERR_INVALID, "label %d of frame %lld outside [0, %d)", labels[t], t, S);
+    HIPCHK(ctx, hipMemcpyAsync(b->d_phi + (size_t)rec * Dp, phi.data(), sizeof(double) * Dp, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(b->d_sqrt_phi, sphi.data(), sizeof(double) * Dp, hipMemcpyHostToDevice, ctx->stream));
+    {
+        LaunchScope ls(b, VBX_K_PREP);
+        hipLaunchKernelGGL((prep_kernel<R, double>), dim3(rd.ntiles), dim3(256), 0, ctx->stream, d_fea, (const double*)b->d_sqrt_phi,
+                           (R*)b->d_rho + rd.row0 * Dp, b->d_gtile + rd.tile0, rd.T, D, Dp);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    std::vector<double> gt(rd.ntiles);
+    HIPCHK(ctx, hipMemcpyAsync(gt.data(), b->d_gtile + rd.tile0, sizeof(double) * rd.ntiles, hipMemcpyDeviceToHost, ctx->stream));
+    // labels -> staging (the x staging block is free: fea is already on the device) -> gamma
+    if (b->xstage_bytes < sizeof(int32_t) * (size_t)T) FAIL(ctx, VBX_ERR_STATE, "staging block too small for the labels");
+    HIPCHK(ctx, hipMemcpyAsync(b->d_xstage, labels, sizeof(int32_t) * (size_t)T, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL((vbx::qinit_kernel<R>), dim3((unsigned)((T * Sp + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const int*)b->d_xstage, (R*)b->d_gamma + rd.row0 * Sp, T, S, Sp, hi, lo);
+    std::vector<double> pip(Sp, 0.0);
+    for (int s = 0; s < S; ++s) pip[s] = 1.0 / S;
+    HIPCHK(ctx, hipMemcpyAsync(b->d_pi + (size_t)rec * Sp, pip.data(), sizeof(double) * Sp, hipMemcpyHostToDevice, ctx->stream));
+    rd.has_model = 0;
+    RecState st;
+    std::memset(&st, 0, sizeof st);
+    HIPCHK(ctx, hipMemcpyAsync(b->d_state + rec, &st, sizeof st, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(b->d_tile_done + rd.tile0, 0, sizeof(int) * rd.ntiles, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipGetLastError());
+    double gsum = 0.0;
+    for (double g : gt) gsum += g;
+    rd.gsum = gsum;
+    return VBX_OK;
+}
+
+template <typename R>
+int get_labels_impl(vbx_batch* b, int rec, int32_t* first, int32_t* second) {
+    vbx_ctx* ctx = b->ctx;
+    const RecDesc& rd = b->recs[rec];
+    const long long T = rd.T;
+    int* d_lab = nullptr;
+    int rc = dmalloc(ctx, &d_lab, (size_t)2 * T);
+    if (rc != VBX_OK) return rc;
+    hipLaunchKernelGGL((vbx::top2_kernel<R>), dim3((unsigned)((T + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const R*)b->d_gamma + rd.row0 * b->Sp, d_lab, d_lab + T, T, rd.S, b->Sp);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && first) e = hipMemcpyAsync(first, d_lab, sizeof(int32_t) * (size_t)T, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && second) e = hipMemcpyAsync(second, d_lab + T, sizeof(int32_t) * (size_t)T, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    ctx_free(ctx, d_lab);
+    if (e != hipSuccess) FAIL(ctx, VBX_ERR_HIP, "label extraction failed: %s", hipGetErrorString(e));
+    return VBX_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+struct vbx_xvectors;
+static const double* xvectors_fea_rows(const vbx_xvectors* xv, int64_t row0, int64_t T, int D, int device);
+
+static int leaf_set_recording_resident(vbx_batch* b, int rec, const vbx_xvectors* xv, int64_t row0, const int32_t* labels,
+                                       double init_smoothing, const double* Phi, double loopProb, double Fa, double Fb) {
+    if (!b) return VBX_ERR_INVALID;
+    vbx_ctx* ctx = b->ctx;
+    if (rec < 0 || rec >= b->n_rec) FAIL(ctx, VBX_ERR_INVALID, "recording index %d out of range", rec);
+    if (!xv || !labels || !Phi) FAIL(ctx, VBX_ERR_INVALID, "vbx_batch_set_recording_resident: NULL input");
+    if (!(loopProb >= 0.0 && loopProb <= 1.0)) FAIL(ctx, VBX_ERR_INVALID, "loopProb=%g outside [0,1]", loopProb);
+    if (!(Fa > 0.0) || !(Fb > 0.0)) FAIL(ctx, VBX_ERR_INVALID, "Fa and Fb must be positive");
+    RecDesc& rd = b->recs[rec];
+    const double* d_fea = xvectors_fea_rows(xv, row0, rd.T, b->D, ctx->device);
+    if (!d_fea) FAIL(ctx, VBX_ERR_INVALID, "rows [%lld, +%d) x %d dims are not in the resident x-vectors", (long long)row0, rd.T, b->D);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    rd.lp = loopProb;
+    rd.Fa = Fa;
+    rd.Fb = Fb;
+    // softmax(smoothing * onehot) row (vbhmm.py:152, scipy.special.softmax: exp(x - max) / sum)
+    const double z = std::exp(-init_smoothing), den = 1.0 + (rd.S - 1) * z;
+    const double hi = 1.0 / den, lo = z / den;
+    int rc = b->precision == VBX_PREC_FP64 ? set_recording_resident_impl<double>(b, rec, d_fea, labels, hi, lo, Phi)
+                                            : set_recording_resident_impl<float>(b, rec, d_fea, labels, hi, lo, Phi);
+    if (rc != VBX_OK) return rc;
+    b->is_set[rec] = 1;
+    b->recs_dirty = true;
+    b->mpart_valid = false;
+    return VBX_OK;
+}
+
+static int leaf_get_labels(vbx_batch* b, int rec, int32_t* first, int32_t* second) {
+    if (!b) return VBX_ERR_INVALID;
+    if (rec < 0 || rec >= b->n_rec) FAIL(b->ctx, VBX_ERR_INVALID, "recording index %d out of range", rec);
+    HIPCHK(b->ctx, hipSetDevice(b->ctx->device));
+    return b->precision == VBX_PREC_FP64 ? get_labels_impl<double>(b, rec, first, second)
+                                         : get_labels_impl<float>(b, rec, first, second);
+}
+
 static int leaf_set_recording(vbx_batch* b, int rec, const void* X, int x_dtype, const double* Phi, const double* pi0,
                             const void* gamma0, int g_dtype, const double* alpha0, const double* invL0,
                             double loopProb, double Fa, double Fb) {
@@ -1281,6 +1391,25 @@ int vbx_batch_get_result(vbx_batch* b, int rec, double* gamma, double* pi, doubl
     return kid_fail(b, k, leaf_get_result(b->kids[k], b->local_of[rec], gamma, pi, Li, li_cap, n_iters, warned, alpha, invL));
 }
 
+int vbx_batch_set_recording_resident(vbx_batch* b, int rec, const vbx_xvectors* xv, int64_t row0, const int32_t* labels,
+                                     double init_smoothing, const double* Phi, double loopProb, double Fa, double Fb) {
+    if (!b) return VBX_ERR_INVALID;
+    if (b->kids.empty()) return leaf_set_recording_resident(b, rec, xv, row0, labels, init_smoothing, Phi, loopProb, Fa, Fb);
+    if (rec < 0 || rec >= b->n_rec) FAIL(b->ctx, VBX_ERR_INVALID, "recording index %d out of range", rec);
+    b->any_set = true;
+    const int k = b->kid_of[rec];
+    return kid_fail(b, k, leaf_set_recording_resident(b->kids[k], b->local_of[rec], xv, row0, labels, init_smoothing, Phi,
+                                                      loopProb, Fa, Fb));
+}
+
+int vbx_batch_get_labels(vbx_batch* b, int rec, int32_t* first, int32_t* second) {
+    if (!b) return VBX_ERR_INVALID;
+    if (b->kids.empty()) return leaf_get_labels(b, rec, first, second);
+    if (rec < 0 || rec >= b->n_rec) FAIL(b->ctx, VBX_ERR_INVALID, "recording index %d out of range", rec);
+    const int k = b->kid_of[rec];
+    return kid_fail(b, k, leaf_get_labels(b->kids[k], b->local_of[rec], first, second));
+}
+
 int vbx_batch_last_run_ms(vbx_batch* b, double* total_ms, int* iters_launched) { return leaf_last_run_ms(b, total_ms, iters_launched); }
 
 int vbx_batch_streams(const vbx_batch* b) { return !b ? 0 : b->kids.empty() ? 1 : (int)b->kids.size(); }
@@ -1638,9 +1767,8 @@ int vbx_scores_destroy(vbx_scores* sc) {
 
 int64_t vbx_scores_count(const vbx_scores* sc) { return sc ? sc->n : 0; }
 
-int vbx_cos_similarity(vbx_ctx* ctx, int64_t T, int32_t D, const double* x, vbx_scores** out) {
-    if (!ctx) return VBX_ERR_INVALID;
-    if (!x || !out || T <= 0 || D <= 0) FAIL(ctx, VBX_ERR_INVALID, "vbx_cos_similarity: bad argument");
+// x: host pointer (uploaded) or, with on_device, rows already resident in HBM
+static int cos_similarity_impl(vbx_ctx* ctx, int64_t T, int32_t D, const double* x, bool on_device, vbx_scores** out) {
     if (T > 200000) FAIL(ctx, VBX_ERR_UNSUPPORTED, "T=%lld: the T x T score matrix would not fit the device", (long long)T);
     *out = nullptr;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1650,15 +1778,15 @@ int vbx_cos_similarity(vbx_ctx* ctx, int64_t T, int32_t D, const double* x, vbx_
     sc->ctx = ctx;
     sc->n = (long long)T * T;
     size_t x_bytes = 0, xn_bytes = 0;
-    int rc = scratch_get(ctx, &d_x, (size_t)T * D, &x_bytes);
+    int rc = on_device ? VBX_OK : scratch_get(ctx, &d_x, (size_t)T * D, &x_bytes);
     if (rc == VBX_OK) rc = scratch_get(ctx, &d_xn, (size_t)T * Dp, &xn_bytes);
     if (rc == VBX_OK) rc = scratch_get(ctx, &sc->d_s, (size_t)sc->n, &sc->d_s_bytes);
     hipError_t e = hipSuccess;
     if (rc == VBX_OK) {
-        e = hipMemcpyAsync(d_x, x, sizeof(double) * (size_t)T * D, hipMemcpyHostToDevice, ctx->stream);
+        if (!on_device) e = hipMemcpyAsync(d_x, x, sizeof(double) * (size_t)T * D, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(vbx::cos_norm_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, ctx->stream, d_x, d_xn,
-                               (long long)T, (int)D, Dp);
+            hipLaunchKernelGGL(vbx::cos_norm_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, ctx->stream,
+                               on_device ? x : d_x, d_xn, (long long)T, (int)D, Dp);
             const unsigned nb = (unsigned)((T + 63) / 64);
             hipLaunchKernelGGL(vbx::cos_gemm_kernel, dim3(nb, nb), dim3(256), 0, ctx->stream, d_xn, sc->d_s, (long long)T, Dp);
             e = hipStreamSynchronize(ctx->stream);
@@ -1669,7 +1797,7 @@ int vbx_cos_similarity(vbx_ctx* ctx, int64_t T, int32_t D, const double* x, vbx_
             rc = VBX_ERR_HIP;
         }
     }
-    scratch_put(ctx, d_x, x_bytes);
+    if (!on_device) scratch_put(ctx, d_x, x_bytes);
     scratch_put(ctx, d_xn, xn_bytes);
     if (rc != VBX_OK) {
         vbx_scores_destroy(sc);
@@ -1677,6 +1805,134 @@ int vbx_cos_similarity(vbx_ctx* ctx, int64_t T, int32_t D, const double* x, vbx_
     }
     *out = sc;
     return VBX_OK;
+}
+
+int vbx_cos_similarity(vbx_ctx* ctx, int64_t T, int32_t D, const double* x, vbx_scores** out) {
+    if (!ctx) return VBX_ERR_INVALID;
+    if (!x || !out || T <= 0 || D <= 0) FAIL(ctx, VBX_ERR_INVALID, "vbx_cos_similarity: bad argument");
+    return cos_similarity_impl(ctx, T, D, x, false, out);
+}
+
+// ---- x-vectors of an archive resident in HBM: projections, initial assignments, labels (vbx_frontend.hpp) ------------
+struct vbx_xvectors {
+    vbx_ctx* ctx = nullptr;
+    long long n = 0;
+    int Dl = 0, fea_dim = 0;
+    double *d_xproj = nullptr, *d_fea = nullptr;
+};
+
+static const double* xvectors_fea_rows(const vbx_xvectors* xv, int64_t row0, int64_t T, int D, int device) {
+    if (!xv || row0 < 0 || row0 + T > xv->n || D != xv->fea_dim || xv->ctx->device != device) return nullptr;
+    return xv->d_fea + row0 * xv->fea_dim;
+}
+
+int vbx_xvectors_destroy(vbx_xvectors* xv) {
+    if (!xv) return VBX_OK;
+    (void)hipSetDevice(xv->ctx->device);
+    (void)hipStreamSynchronize(xv->ctx->stream);
+    ctx_free(xv->ctx, xv->d_xproj);
+    ctx_free(xv->ctx, xv->d_fea);
+    delete xv;
+    return VBX_OK;
+}
+
+int vbx_xvectors_project(vbx_ctx* ctx, int64_t n, int32_t Din, int32_t Dl, int32_t fea_dim, const void* x, int x_dtype,
+                         const double* mean1, const double* lda, const double* mean2, const double* plda_mu,
+                         const double* plda_tr, vbx_xvectors** out) {
+    if (!ctx) return VBX_ERR_INVALID;
+    if (!out || !x || !mean1 || !lda || !mean2 || !plda_mu || !plda_tr || n <= 0 || Din <= 0 || Dl <= 0 || fea_dim <= 0 ||
+        fea_dim > Dl || (x_dtype != VBX_F32 && x_dtype != VBX_F64))
+        FAIL(ctx, VBX_ERR_INVALID, "vbx_xvectors_project: bad argument");
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int Kp = round_up(Din, 4), Np = round_up(Dl, 16), Kp2 = round_up(Dl, 4), Np2 = round_up(fea_dim, 16);
+    // padded operands: lda [Kp][Np]; plda_tr^T [Kp2][Np2] (column k = k-th output dim); the mean of the second product
+    // goes through it: (x - mu) P = x P - mu P
+    std::vector<double> ldap((size_t)Kp * Np, 0.0), ptp((size_t)Kp2 * Np2, 0.0), mup(Np2, 0.0), m2p(Np, 0.0);
+    for (int k = 0; k < Din; ++k)
+        for (int c = 0; c < Dl; ++c) ldap[(size_t)k * Np + c] = lda[(size_t)k * Dl + c];
+    for (int c = 0; c < Dl; ++c) m2p[c] = mean2[c];
+    for (int k = 0; k < fea_dim; ++k) {
+        double acc = 0.0;
+        for (int d = 0; d < Dl; ++d) {
+            ptp[(size_t)d * Np2 + k] = plda_tr[(size_t)k * Dl + d];
+            acc += plda_mu[d] * plda_tr[(size_t)k * Dl + d];
+        }
+        mup[k] = acc;
+    }
+    vbx_xvectors* xv = new vbx_xvectors();
+    xv->ctx = ctx;
+    xv->n = n;
+    xv->Dl = Dl;
+    xv->fea_dim = fea_dim;
+    const size_t esz = x_dtype == VBX_F64 ? 8 : 4;
+    void* d_x = nullptr;
+    double *d_y1 = nullptr, *d_m1 = nullptr, *d_lda = nullptr, *d_m2 = nullptr, *d_pt = nullptr, *d_mu = nullptr;
+    int rc = dmalloc_bytes(ctx, &d_x, (size_t)n * Din * esz);
+    if (rc == VBX_OK) rc = dmalloc(ctx, &d_y1, (size_t)n * Kp);
+    if (rc == VBX_OK) rc = dmalloc(ctx, &d_m1, (size_t)Din);
+    if (rc == VBX_OK) rc = dmalloc(ctx, &d_lda, ldap.size());
+    if (rc == VBX_OK) rc = dmalloc(ctx, &d_m2, m2p.size());
+    if (rc == VBX_OK) rc = dmalloc(ctx, &d_pt, ptp.size());
+    if (rc == VBX_OK) rc = dmalloc(ctx, &d_mu, mup.size());
+    if (rc == VBX_OK) rc = dmalloc(ctx, &xv->d_xproj, (size_t)n * Kp2);
+    if (rc == VBX_OK) rc = dmalloc(ctx, &xv->d_fea, (size_t)n * fea_dim);
+    hipError_t e = hipSuccess;
+    if (rc == VBX_OK) {
+        hipStream_t st = ctx->stream;
+        e = hipMemcpyAsync(d_x, x, (size_t)n * Din * esz, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_m1, mean1, sizeof(double) * Din, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_lda, ldap.data(), sizeof(double) * ldap.size(), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_m2, m2p.data(), sizeof(double) * m2p.size(), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_pt, ptp.data(), sizeof(double) * ptp.size(), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_mu, mup.data(), sizeof(double) * mup.size(), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) {
+            const dim3 rows((unsigned)((n + 3) / 4)), blocks((unsigned)((n + 63) / 64));
+            if (x_dtype == VBX_F64)
+                hipLaunchKernelGGL((vbx::xv_center_norm_kernel<double>), rows, dim3(256), 0, st, (const double*)d_x, d_m1, d_y1, (long long)n, (int)Din, (int)Din, Kp);
+            else
+                hipLaunchKernelGGL((vbx::xv_center_norm_kernel<float>), rows, dim3(256), 0, st, (const float*)d_x, d_m1, d_y1, (long long)n, (int)Din, (int)Din, Kp);
+            hipLaunchKernelGGL(vbx::xv_gemm_kernel, blocks, dim3(256), 0, st, d_y1, d_lda, d_m2, xv->d_xproj, (long long)n, Kp, Np, (int)Dl, Kp2);
+            // (the columns Dl .. Kp2 of xproj must be zero for the second product)
+            hipLaunchKernelGGL((vbx::xv_center_norm_kernel<double>), rows, dim3(256), 0, st, xv->d_xproj, (const double*)nullptr, xv->d_xproj, (long long)n, (int)Dl, Kp2, Kp2);
+            hipLaunchKernelGGL(vbx::xv_gemm_kernel, blocks, dim3(256), 0, st, xv->d_xproj, d_pt, d_mu, xv->d_fea, (long long)n, Kp2, Np2, (int)fea_dim, (int)fea_dim);
+            e = hipStreamSynchronize(st);
+        }
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) {
+            ctx->err = std::string("x-vector projection failed: ") + hipGetErrorString(e);
+            rc = VBX_ERR_HIP;
+        }
+    }
+    for (void* p : {d_x, (void*)d_y1, (void*)d_m1, (void*)d_lda, (void*)d_m2, (void*)d_pt, (void*)d_mu}) ctx_free(ctx, p);
+    if (rc != VBX_OK) {
+        vbx_xvectors_destroy(xv);
+        return rc;
+    }
+    *out = xv;
+    return VBX_OK;
+}
+
+int vbx_xvectors_get(vbx_xvectors* xv, int which, int64_t row0, int64_t nrows, double* out) {
+    if (!xv || !out || row0 < 0 || nrows < 0 || row0 + nrows > xv->n || (which != 0 && which != 1)) return VBX_ERR_INVALID;
+    vbx_ctx* ctx = xv->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (which == 1) {
+        HIPCHK(ctx, hipMemcpy(out, xv->d_fea + row0 * xv->fea_dim, sizeof(double) * (size_t)nrows * xv->fea_dim, hipMemcpyDeviceToHost));
+    } else {
+        const int ld = round_up(xv->Dl, 4);
+        HIPCHK(ctx, hipMemcpy2D(out, sizeof(double) * xv->Dl, xv->d_xproj + row0 * ld, sizeof(double) * ld, sizeof(double) * xv->Dl,
+                                (size_t)nrows, hipMemcpyDeviceToHost));
+    }
+    return VBX_OK;
+}
+
+int vbx_cos_similarity_resident(vbx_ctx* ctx, vbx_xvectors* xv, int64_t row0, int64_t T, vbx_scores** out) {
+    if (!ctx) return VBX_ERR_INVALID;
+    if (!xv || !out || T <= 0 || row0 < 0 || row0 + T > xv->n || xv->ctx->device != ctx->device)
+        FAIL(ctx, VBX_ERR_INVALID, "vbx_cos_similarity_resident: bad argument");
+    const int ld = round_up(xv->Dl, 4);               // (the padding columns are zero: part of the rows, no effect on the scores)
+    return cos_similarity_impl(ctx, T, ld, xv->d_xproj + row0 * ld, true, out);
 }
 
 int vbx_scores_upload(vbx_ctx* ctx, int64_t n, const double* s, vbx_scores** out) {

@@ -6,15 +6,17 @@ MI355X path:
         --xvec-transform transform.h5 --plda-file plda --threshold -0.015 --lda-dim 128 --Fa 0.3 --Fb 17 --loopP 0.99
 
 The reference walks the recordings of the archive one after another (vbhmm.py:120) and runs everything on one
-CPU thread.  Here the loop is split into three stages:
+CPU thread.  Here the loop is split into stages:
 
-  1. per recording: x-vector projection (vbhmm.py:125-129), AHC initialisation -- similarity matrix, threshold
-     calibration and the condensed negated matrix on the GPU, average-linkage clustering on the host in worker
-     threads (a chain of T dependent nearest-neighbour steps: nothing for a GPU to do) -- and the PLDA projection
-     ``fea`` (vbhmm.py:153);
-  2. ALL recordings of this rank in one ``vbx_batch``: one launch sequence per EM iteration for the whole
-     archive, convergence per recording on the device (vbhmm.py:154-158 call, batched);
-  3. per recording: labels, merging of adjacent segments and the RTTM file (vbhmm.py:160-179).
+  0. ALL x-vectors of this rank go to the device once; the projections of vbhmm.py:125-129 and the PLDA projection
+     ``fea`` of vbhmm.py:153 are computed there for the whole archive and stay resident;
+  1. per recording: AHC initialisation -- similarity matrix of the resident rows, threshold calibration and the
+     condensed negated matrix on the GPU, average-linkage clustering on the host in worker threads (a chain of T
+     dependent nearest-neighbour steps: nothing for a GPU to do);
+  2. ALL recordings of this rank in one ``vbx_batch``: initial responsibilities from the AHC labels on the device
+     (vbhmm.py:150-152), one launch sequence per EM iteration for the whole archive, convergence per recording on the
+     device (vbhmm.py:154-158 call, batched), first / second speaker by a device arg-sort (vbhmm.py:160-162);
+  3. per recording, as soon as its labels exist: merging of adjacent segments and the RTTM file (vbhmm.py:166-179).
 
 Under ``torchrun`` (one process per GPU) the recordings are dealt to the ranks by cost; every rank writes the
 RTTM files of its own recordings and the ranks only meet in a barrier at the end.  Same flags, same files, same
@@ -32,8 +34,7 @@ import numpy as np
 from .kaldi_formats import (read_plda, read_vec_flt_ark_grouped, read_xvec_transform, read_xvector_timing_dict,
                             write_rttm)
 
-__all__ = ['main', 'diarize', 'tune_host_process', 'load_models', 'project_xvectors', 'ahc_init', 'cluster', 'device_score_stage',
-           'merge_adjacent_labels', 'l2_norm']
+__all__ = ['main', 'diarize', 'DeviceStages', 'tune_host_process', 'load_models', 'cluster', 'merge_adjacent_labels', 'l2_norm']
 
 
 def l2_norm(vec_or_matrix):
@@ -71,35 +72,14 @@ def load_models(xvec_transform, plda_file):
     return dict(mean1=mean1, mean2=mean2, lda=lda, plda_mu=plda_mu, plda_psi=acvar[::-1], plda_tr=wccn.T[::-1])
 
 
-def project_xvectors(x, models):
-    """vbhmm.py:129: centre, length-normalise, LDA, centre, length-normalise."""
-    return l2_norm(models['lda'].T.dot(l2_norm(x - models['mean1']).transpose()).transpose() - models['mean2'])
-
-
-def device_score_stage(x):
-    """Score stage of the AHC initialisation on the GPU (vbhmm.py:135-139): the cosine-similarity matrix of the rows
-    of ``x``, the threshold of its two-Gaussian calibration, and the negated matrix in the condensed form the
-    clustering consumes (``squareform(-scr_mx, checks=False)``).  The T x T matrix never leaves the device: only
-    the threshold and the T (T - 1) / 2 upper-triangle entries come back.  No host fallback: without the HIP
-    library this raises."""
-    from . import _capi
-    xx = np.ascontiguousarray(x, dtype=np.float64)
-    scores = _capi.Scores.cos_similarity(_capi.default_context(None), xx)
-    try:
-        thr, _ = scores.two_gmm_calib(20, want_llr=False)
-        cond = scores.get_condensed(xx.shape[0], -1.0)
-    finally:
-        scores.close()
-    return cond, float(thr)
-
-
 def cluster(cond, thr, threshold):
     """Average-linkage clustering of the condensed negated similarities, cut at the calibrated threshold
     (vbhmm.py:140-146) -> integer cluster label per x-vector.  The linkage is the library's native host routine
-    (``vbx_linkage_average``: nearest-neighbour chain, the linkage matrix of SciPy / fastcluster bit for bit; the cut
-    is ``vbx_fcluster_distance``): a chain
-    of T dependent steps over cache-resident rows, nothing for a GPU to do -- but it holds no interpreter lock, so the
-    driver clusters several recordings at a time next to the GPU score stage of the following ones."""
+    (``vbx_linkage_average``: nearest-neighbour chain, SciPy's linkage matrix bit for bit -- SciPy is the stand-in for
+    the un-installed fastcluster, whose average-linkage update may differ from it in the last bit; the cut is
+    ``vbx_fcluster_distance``): a chain of T dependent steps over cache-resident rows, nothing for a GPU to do -- but it
+    holds no interpreter lock, so the driver clusters several recordings at a time next to the GPU score stage of the
+    following ones."""
     from . import _capi
     lin_mat = _capi.linkage_average(cond)
     adjust = abs(lin_mat[:, 2].min())
@@ -107,10 +87,65 @@ def cluster(cond, thr, threshold):
     return _capi.fcluster_distance(lin_mat, -(thr + threshold) + adjust).astype(np.int64) - 1
 
 
-def ahc_init(x, threshold, score_stage=device_score_stage):
-    """Kaldi-like AHC of the projected x-vectors (vbhmm.py:135-146) -> (labels, calibrated threshold)."""
-    cond, thr = score_stage(x)
-    return cluster(cond, thr, threshold), thr
+class DeviceStages:
+    """The device side of the driver (no host fallback: without the HIP library every method raises).
+
+    project   every x-vector of this rank goes up ONCE; the projections of vbhmm.py:125-129 and the PLDA projection of
+              vbhmm.py:153 run on the device for all recordings together and stay resident (vbx_xvectors)
+    scores    per recording: cosine-similarity matrix of its resident rows, two-Gaussian calibration, and the condensed
+              negated matrix for the host clustering (vbhmm.py:135-139) -- the T x T matrix never leaves the device
+    vb        ALL recordings in one ``vbx_batch``: initial responsibilities built on the device from the AHC labels
+              (vbhmm.py:150-152), one launch sequence per EM iteration for the whole archive, convergence per recording
+              on the device (vbhmm.py:154-158), first / second speaker by a device arg-sort (vbhmm.py:160-162): only
+              labels come back
+    """
+
+    def __init__(self, device=None):
+        from . import _capi
+        self._capi = _capi
+        self.ctx = _capi.default_context(device)
+        self.xv = None
+
+    def project(self, recordings, models, lda_dim):
+        self.T = [len(r[1]) for r in recordings]
+        self.row0 = np.concatenate([[0], np.cumsum(self.T)]).astype(np.int64)
+        self.Phi = np.ascontiguousarray(models['plda_psi'][:lda_dim])
+        self.lda_dim = lda_dim
+        if not recordings:
+            return
+        x = np.concatenate([np.asarray(r[2]) for r in recordings])
+        self.xv = self._capi.XVectors(self.ctx, x, models['mean1'], models['lda'], models['mean2'], models['plda_mu'],
+                                      models['plda_tr'], lda_dim)
+
+    def scores(self, k):
+        sc = self._capi.Scores.cos_similarity_resident(self.ctx, self.xv, self.row0[k], self.T[k])
+        try:
+            thr, _ = sc.two_gmm_calib(20, want_llr=False)
+            cond = sc.get_condensed(self.T[k], -1.0)
+        finally:
+            sc.close()
+        return cond, float(thr)
+
+    def vb(self, ks, labels, init_smoothing, maxIters, epsilon, precision, loopProb, Fa, Fb):
+        """-> [(labels1st, labels2nd or None, iterations)] for the recordings ``ks`` with AHC labels ``labels``."""
+        S = [int(np.max(lab)) + 1 for lab in labels]
+        batch = self._capi.Batch(self.ctx, [self.T[k] for k in ks], S, self.lda_dim, precision=precision, max_iters=maxIters)
+        try:
+            for j, (k, lab) in enumerate(zip(ks, labels)):
+                batch.set_recording_resident(j, self.xv, self.row0[k], lab, init_smoothing, self.Phi, loopProb, Fa, Fb)
+            batch.run(maxIters, epsilon)
+            out = []
+            for j in range(len(ks)):
+                first, second = batch.labels(j)
+                out.append((first, second, batch.n_iters(j)))
+            return out
+        finally:
+            batch.close()
+
+    def close(self):
+        if self.xv is not None:
+            self.xv.close()
+            self.xv = None
 
 
 def tune_host_process():
@@ -154,12 +189,32 @@ def _rank_world():
     return int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
 
 
-def diarize(args, run_batch=None, score_stage=device_score_stage, log=print):
-    """The whole archive.  ``run_batch(items, maxIters, epsilon, **hyper)`` defaults to ``vbx_amd.batch.VBx_batch``
-    and ``score_stage`` to the GPU score stage (the CPU test-suite injects its checkers for both).  Returns ``{recording: dict(labels1st, labels2nd, n_iters, thr, seconds...)}`` for
-    the recordings of this rank."""
-    from scipy.special import softmax
-    from .batch import VBx_batch, shard_recordings
+def _write_rttm_files(args, file_name, st, segs_dict):
+    """vbhmm.py:166-179 for one recording."""
+    assert np.all(segs_dict[file_name][0] == st['seg_names'])                 # vbhmm.py:166
+    start, end = segs_dict[file_name][1].T
+    starts, ends, out_labels = merge_adjacent_labels(start, end, st['labels1st'])
+    os.makedirs(args.out_rttm_dir, exist_ok=True)
+    with open(os.path.join(args.out_rttm_dir, f'{file_name}.rttm'), 'w') as fp:
+        write_rttm(fp, file_name, out_labels, starts, ends)
+    if args.output_2nd and args.init.endswith('VB') and st['labels2nd'] is not None:
+        starts, ends, out_labels2 = merge_adjacent_labels(start, end, st['labels2nd'])
+        second = f'{args.out_rttm_dir}2nd'
+        os.makedirs(second, exist_ok=True)
+        with open(os.path.join(second, f'{file_name}.rttm'), 'w') as fp:
+            write_rttm(fp, file_name, out_labels2, starts, ends)
+
+
+def diarize(args, stages=None, log=print):
+    """The whole archive.  ``stages`` defaults to ``DeviceStages()`` (the CPU test-suite injects an object with the same
+    four methods built on its checkers).  Returns ``({recording: dict(labels1st, labels2nd, n_iters, thr)}, timing)``
+    for the recordings of this rank.
+
+    A recording the device path cannot take (more than ``VBX_MAX_SPEAKERS`` = 256 AHC clusters, or one whose batch
+    fails) does not take the archive down with it: every other recording is diarized and written, then a
+    ``RuntimeError`` names the ones left out.  RTTM files are written as soon as their labels exist."""
+    from .batch import shard_recordings
+    from ._capi import MAX_SPEAKERS, VbxError
     assert 0 <= args.loopP <= 1, f'Expecting loopP between 0 and 1, got {args.loopP} instead.'
     t_start = time.perf_counter()
     segs_dict = read_xvector_timing_dict(args.segments_file)
@@ -170,83 +225,90 @@ def diarize(args, run_batch=None, score_stage=device_score_stage, log=print):
         assignment = shard_recordings([float(len(r[1])) ** 2 for r in recordings], world)
         recordings = [r for k, r in enumerate(recordings) if assignment[k] == rank]
     t_read = time.perf_counter()
+    want_vb = args.init.endswith('VB')
+    own_stages = stages is None
+    if own_stages:
+        stages = DeviceStages()
+    failed = {}
+    try:
+        # ---- stage 0: every x-vector of this rank to the device, projections for all recordings at once ---------------
+        stages.project(recordings, models, args.lda_dim)
+        t_proj = time.perf_counter()
 
-    # ---- stage 1: projections and AHC initialisation -------------------------------------------------------------
-    # A few recordings at a time, each on a worker thread from its projection to its initial assignments: NumPy's
-    # matrix products, the native clustering and the device calls all run without the interpreter lock; the GPU
-    # score stage (one stream, a ctx is not thread-safe) is taken in turns.
-    import threading
-    from concurrent.futures import ThreadPoolExecutor
-    gpu_turn = threading.Lock()
+        # ---- stage 1: AHC initialisation -----------------------------------------------------------------------------
+        # A few recordings at a time on worker threads: the native clustering and the device calls run without the
+        # interpreter lock; the GPU score stage (one stream, a ctx is not thread-safe) is taken in turns.
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        gpu_turn = threading.Lock()
 
-    def prepare(rec):
-        file_name, seg_names, xvecs = rec
-        x = project_xvectors(xvecs, models)
-        with gpu_turn:
-            cond, thr = score_stage(x)
-        labels1st = cluster(cond, thr, args.threshold)
-        del cond
-        st = dict(labels1st=labels1st, labels2nd=None, thr=thr, n_iters=0, seg_names=seg_names)
-        item = None
-        if args.init.endswith('VB'):
-            qinit = np.zeros((len(labels1st), np.max(labels1st) + 1))
-            qinit[range(len(labels1st)), labels1st] = 1.0
-            qinit = softmax(qinit * args.init_smoothing, axis=1)
-            fea = (x - models['plda_mu']).dot(models['plda_tr'].T)[:, :args.lda_dim]
-            item = dict(X=fea, Phi=models['plda_psi'][:args.lda_dim], pi=qinit.shape[1], gamma=qinit)
-        return file_name, st, item
+        def prepare(k):
+            file_name, seg_names, _ = recordings[k]
+            with gpu_turn:
+                cond, thr = stages.scores(k)
+            labels1st = cluster(cond, thr, args.threshold)
+            del cond
+            st = dict(labels1st=labels1st, labels2nd=None, thr=thr, n_iters=0, seg_names=seg_names)
+            if not want_vb:
+                _write_rttm_files(args, file_name, st, segs_dict)        # AHC only: the result is final
+            return file_name, st
 
-    # short recordings: the Python glue between the native calls limits the useful threads (measured 64 x 1025
-    # x-vectors: 3-4 threads 0.15 s, 6: 0.18 s, 12: 0.35 s); long ones are dominated by the clustering (T^2) and want more
-    longest = max((len(r[1]) for r in recordings), default=0)
-    n_workers = int(os.environ.get('VBX_AMD_DRIVER_THREADS', '8' if longest >= 2500 else '4'))
-    n_workers = max(1, min(n_workers, (os.cpu_count() or 2) - 1))
-    items, state = [], {}
-    for rec in recordings:
-        log(rec[0])                                               # vbhmm.py:121
-    with tune_host_process(), ThreadPoolExecutor(max_workers=n_workers) as pool:
-        for file_name, st, item in pool.map(prepare, recordings):      # results in archive order
-            if item is not None:
-                st['item'] = len(items)
-                items.append(item)
-            state[file_name] = st
-    t_ahc = time.perf_counter()
+        # short recordings: the Python glue between the native calls limits the useful threads (measured 64 x 1025
+        # x-vectors: 3-4 threads 0.15 s, 6: 0.18 s, 12: 0.35 s); long ones are dominated by the clustering (T^2) and want more
+        longest = max((len(r[1]) for r in recordings), default=0)
+        n_workers = int(os.environ.get('VBX_AMD_DRIVER_THREADS', '8' if longest >= 2500 else '4'))
+        n_workers = max(1, min(n_workers, (os.cpu_count() or 2) - 1))
+        state = {}
+        for rec in recordings:
+            log(rec[0])                                               # vbhmm.py:121
+        with tune_host_process(), ThreadPoolExecutor(max_workers=n_workers) as pool:
+            for file_name, st in pool.map(prepare, range(len(recordings))):      # results in archive order
+                state[file_name] = st
+        t_ahc = time.perf_counter()
 
-    # ---- stage 2: every recording of this rank in one batch ------------------------------------------------------
-    if items:
-        hyper = dict(loopProb=args.loopP, Fa=args.Fa, Fb=args.Fb)
-        if run_batch is None:
-            results = VBx_batch(items, maxIters=40, epsilon=1e-6, precision=getattr(args, 'precision', 'fp64'), **hyper)
-        else:
-            results = run_batch(items, 40, 1e-6, **hyper)
-        for st in state.values():
-            q, _sp, L = results[st['item']]
-            order = np.argsort(-q, axis=1)
-            st['labels1st'] = order[:, 0]
-            st['labels2nd'] = order[:, 1] if q.shape[1] > 1 else None
-            st['n_iters'] = len(L)
-    t_vb = time.perf_counter()
+        # ---- stage 2: every recording of this rank in one batch ------------------------------------------------------
+        if want_vb and recordings:
+            hyper = dict(loopProb=args.loopP, Fa=args.Fa, Fb=args.Fb)
+            common = dict(init_smoothing=args.init_smoothing, maxIters=40, epsilon=1e-6,
+                          precision=getattr(args, 'precision', 'fp64'), **hyper)
+            names = [r[0] for r in recordings]
+            ks = []
+            for k, name in enumerate(names):
+                n_clusters = int(np.max(state[name]['labels1st'])) + 1
+                if n_clusters > MAX_SPEAKERS:
+                    failed[name] = f'AHC left {n_clusters} clusters, the device path takes at most {MAX_SPEAKERS}'
+                else:
+                    ks.append(k)
 
-    # ---- stage 3: RTTM --------------------------------------------------------------------------------------------
-    for file_name, st in state.items():
-        assert np.all(segs_dict[file_name][0] == st['seg_names'])                 # vbhmm.py:166
-        start, end = segs_dict[file_name][1].T
-        starts, ends, out_labels = merge_adjacent_labels(start, end, st['labels1st'])
-        os.makedirs(args.out_rttm_dir, exist_ok=True)
-        with open(os.path.join(args.out_rttm_dir, f'{file_name}.rttm'), 'w') as fp:
-            write_rttm(fp, file_name, out_labels, starts, ends)
-        if args.output_2nd and args.init.endswith('VB') and st['labels2nd'] is not None:
-            starts, ends, out_labels2 = merge_adjacent_labels(start, end, st['labels2nd'])
-            second = f'{args.out_rttm_dir}2nd'
-            os.makedirs(second, exist_ok=True)
-            with open(os.path.join(second, f'{file_name}.rttm'), 'w') as fp:
-                write_rttm(fp, file_name, out_labels2, starts, ends)
-        del st['seg_names']
-        st.pop('item', None)
+            def finish(k, result):
+                st = state[names[k]]
+                st['labels1st'], st['labels2nd'], st['n_iters'] = result
+                _write_rttm_files(args, names[k], st, segs_dict)
+
+            try:
+                for k, result in zip(ks, stages.vb(ks, [state[names[k]]['labels1st'] for k in ks], **common)):
+                    finish(k, result)
+            except VbxError as exc:          # one recording at a time, so that a bad one only costs itself
+                log(f'batched VB-HMM failed ({exc}); retrying the recordings one by one')
+                for k in ks:
+                    try:
+                        finish(k, stages.vb([k], [state[names[k]]['labels1st']], **common)[0])
+                    except VbxError as exc_k:
+                        failed[names[k]] = str(exc_k)
+        t_vb = time.perf_counter()
+    finally:
+        if own_stages:
+            stages.close()
+    for name in failed:
+        state.pop(name, None)
+    for st in state.values():
+        st.pop('seg_names', None)
     t_end = time.perf_counter()
-    timing = dict(read=t_read - t_start, ahc=t_ahc - t_read, vb=t_vb - t_ahc, rttm=t_end - t_vb, total=t_end - t_start,
-                  recordings=len(state), xvectors=int(sum(len(st['labels1st']) for st in state.values())),
+    timing = dict(read=t_read - t_start, project=t_proj - t_read, ahc=t_ahc - t_proj, vb=t_vb - t_ahc, rttm=t_end - t_vb,
+                  total=t_end - t_start, recordings=len(state), xvectors=int(sum(len(st['labels1st']) for st in state.values())),
                   rank=rank, world=world)
+    if failed:
+        raise RuntimeError('no RTTM written for: ' + '; '.join(f'{k} ({v})' for k, v in failed.items()))
     return state, timing
 
 
