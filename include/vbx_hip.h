@@ -236,6 +236,12 @@ int vbx_scores_get(vbx_scores* sc, int64_t offset, int64_t count, double* out);
  * scale = -1.  out: [T (T - 1) / 2]. */
 int vbx_scores_get_condensed(vbx_scores* sc, int64_t T, double scale, double* out);
 
+/* vbhmm.py:139-141 on the device: average linkage of the distances -S, S = the T x T matrix of similarities held by sc,
+ * by a nearest-neighbour chain that one persistent workgroup walks on the matrix where it lies (no condensed copy, no
+ * PCIe traffic but the T - 1 merges).  Z [T - 1][4]: the linkage matrix vbx_linkage_average gives for
+ * squareform(-S), bit for bit.  CONSUMES the scores: afterwards sc holds the distances of the merged clusters. */
+int vbx_scores_linkage_average(vbx_scores* sc, int64_t T, double* Z);
+
 /* Average-linkage clustering of n observations from their condensed distance vector [n (n - 1) / 2] (host code;
  * nearest-neighbour chain, see vbx_linkage.hpp for why it is not a kernel): vbhmm.py:140-141
  * `fastcluster.linkage(scr_mx, method='average')`.  Z: [n - 1][4] = (cluster a, cluster b, distance, members), the

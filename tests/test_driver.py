@@ -67,12 +67,16 @@ class OracleStages:
         self.fea = [(x - models['plda_mu']).dot(models['plda_tr'].T)[:, :lda_dim] for x in self.x]   # vbhmm.py:153
         self.Phi = models['plda_psi'][:lda_dim]
 
-    def scores(self, k):
+    def ahc(self, k, threshold):
         from oracle import ahc_oracle
+        from scipy.cluster.hierarchy import fcluster, linkage
         from scipy.spatial.distance import squareform
         m = ahc_oracle.cos_similarity(self.x[k])
         thr, _ = ahc_oracle.twoGMMcalib_lin(m.ravel())
-        return squareform(-m, checks=False), float(thr)
+        lin_mat = linkage(squareform(-m, checks=False), method='average')                     # vbhmm.py:139-141
+        adjust = abs(lin_mat[:, 2].min())
+        lin_mat[:, 2] += adjust
+        return fcluster(lin_mat, -(thr + threshold) + adjust, criterion='distance') - 1, float(thr)   # vbhmm.py:142-146
 
     def vb(self, ks, labels, init_smoothing, maxIters, epsilon, precision, **hyper):
         from oracle import vbx_oracle                               # checker standing in for the GPU
@@ -337,6 +341,36 @@ def test_device_stages_against_what_the_reference_driver_computed(tmp_path):
     stages.close()
     np.testing.assert_allclose(res['gamma'], g, rtol=0, atol=1e-9)
     np.testing.assert_allclose(res['Li'], [L[0][0]], rtol=1e-11)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['cosine', 'ties', 'es2005a'])
+def test_device_linkage_is_the_host_linkage_bit_for_bit(kind):
+    """vbx_scores_linkage_average (nearest-neighbour chain walked by one workgroup on the score matrix in HBM) against
+    vbx_linkage_average on the condensed matrix the device hands out (itself SciPy's linkage bit for bit, see below):
+    same merges, same numbering, same distances to the last bit -- random cosine similarities, similarities with
+    massive exact ties (few distinct integer-valued x-vectors), the example recording."""
+    from vbx_amd import _capi
+    ctx = _capi.default_context()
+    rng = np.random.default_rng(11)
+    xs = []
+    if kind == 'cosine':
+        xs = [rng.standard_normal((n, 16)) for n in (2, 3, 5, 64, 257, 1000, 2500)]
+    elif kind == 'ties':
+        for n in (7, 40, 300, 1200):
+            base = rng.integers(-1, 2, size=(6, 8)).astype(float) + 0.5           # six distinct directions: duplicates galore
+            xs.append(base[rng.integers(0, 6, n)])
+    else:
+        xs = [np.load(GOLD)['xvecs'][:400].astype(np.float64), np.load(GOLD)['xvecs'].astype(np.float64)]
+    for x in xs:
+        n = len(x)
+        sc = _capi.Scores.cos_similarity(ctx, x)
+        cond = sc.get_condensed(n, -1.0)
+        got = sc.linkage_average(n)
+        sc.close()
+        want = _capi.linkage_average(cond)
+        assert got.shape == want.shape and np.array_equal(got, want), (kind, n, np.argwhere(got != want)[:3])
+        assert np.array_equal(np.signbit(got), np.signbit(want))
 
 
 def test_top2_ties_keep_their_index_order():

@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     'vbx_batch_create', 'vbx_batch_destroy', 'vbx_batch_set_option', 'vbx_batch_set_recording',
     'vbx_batch_run', 'vbx_batch_get_result', 'vbx_batch_last_run_ms', 'vbx_batch_kernel_times',
     'vbx_run', 'vbx_forward_backward', 'vbx_forward_backward_dense', 'vbx_mstep', 'vbx_loglik',
-    'vbx_cos_similarity', 'vbx_scores_upload', 'vbx_scores_count', 'vbx_scores_get', 'vbx_scores_get_condensed',
+    'vbx_cos_similarity', 'vbx_scores_upload', 'vbx_scores_count', 'vbx_scores_get', 'vbx_scores_get_condensed', 'vbx_scores_linkage_average',
     'vbx_linkage_average', 'vbx_fcluster_distance', 'vbx_ark_index', 'vbx_gather_rows', 'vbx_batch_streams',
     'vbx_scores_two_gmm_calib',
     'vbx_scores_destroy',
@@ -87,6 +87,7 @@ def load():
     lib.vbx_scores_count.argtypes = [vp]
     lib.vbx_scores_get.argtypes = [vp, i64, i64, vp]
     lib.vbx_scores_get_condensed.argtypes = [vp, i64, dbl, vp]
+    lib.vbx_scores_linkage_average.argtypes = [vp, i64, vp]
     lib.vbx_linkage_average.argtypes = [i64, vp, vp]
     lib.vbx_fcluster_distance.argtypes = [i64, vp, dbl, vp]
     lib.vbx_ark_index.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp]
@@ -302,6 +303,13 @@ class Scores:
         self.ctx.check(self._lib.vbx_scores_get_condensed(self._h, int(T), float(scale), _ptr(out)),
                        'vbx_scores_get_condensed')
         return out
+
+    def linkage_average(self, T):
+        """``linkage(squareform(-S), 'average')`` for the T x T similarities held here, computed on the device (the scores
+        are consumed); the linkage matrix [T - 1][4], bit for bit what ``linkage_average`` gives on the host."""
+        Z = np.empty((max(int(T) - 1, 0), 4))
+        self.ctx.check(self._lib.vbx_scores_linkage_average(self._h, int(T), _ptr(Z)), 'vbx_scores_linkage_average')
+        return Z
 
     def two_gmm_calib(self, niters=20, want_llr=True):
         thr = C.c_double()

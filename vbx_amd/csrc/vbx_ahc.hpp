@@ -188,4 +188,157 @@ __global__ __launch_bounds__(256) void gmm_llr_kernel(const double* __restrict__
     }
 }
 
+// ---- average linkage on the score matrix where it lies ------------------------------------------------------------
+// vbhmm.py:139-141: fastcluster.linkage(squareform(-scr_mx), method='average').  The nearest-neighbour chain of
+// vbx_linkage.hpp (SciPy's nn_chain, same operations in the same order -> the same merges to the last bit) walked by ONE
+// persistent workgroup of 1024 threads on the T x T matrix in HBM: a chain step is a row scan (arg-min with SciPy's
+// tie rules: the previous element of the chain, then the lowest index), a merge rewrites one row and one column.  No
+// launch per step, nothing crosses PCIe but the T - 1 merges.  Several recordings = several workgroups on several
+// streams.
+
+// D = -S (distances), +inf on the diagonal; in place.
+__global__ __launch_bounds__(256) void linkage_prepare_kernel(double* __restrict__ D, long long T) {
+    const long long i = blockIdx.x;
+    double* __restrict__ row = D + i * T;
+    for (long long j = threadIdx.x; j < T; j += 256) row[j] = j == i ? (double)INFINITY : -row[j];
+}
+
+struct ChainMergeDev { int a, b; double d; };          // same layout as vbx::ChainMerge of the host code
+
+// (n_a d_a + n_b d_b) / (n_a + n_b) with every operation rounded on its own, as SciPy and the host code compute it
+// (hipcc contracts a * b + c into a fused multiply-add by default, also through __dmul_rn / __dadd_rn)
+__device__ __forceinline__ double average_update(double fa, double da, double fb, double db, double fs) {
+#pragma clang fp contract(off)
+    const double pa = fa * da;
+    const double pb = fb * db;
+    const double sum = pa + pb;
+    return sum / fs;
+}
+
+__global__ __launch_bounds__(1024) void nn_chain_kernel(double* __restrict__ D, int n, int* __restrict__ size,
+                                                         int* __restrict__ chain, ChainMergeDev* __restrict__ merges) {
+    __shared__ double wmin[16];
+    __shared__ int widx[16];
+    __shared__ int s_x, s_pred, s_merge, s_a, s_b, s_na, s_nb;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double inf = (double)INFINITY;
+    for (int i = tid; i < n; i += 1024) size[i] = 1;
+    // thread 0 keeps the chain: its length, the two top elements and their distance stay in registers (a push knows
+    // them: d(y, x) = d(x, y), the matrix is kept symmetric), the rest lives in `chain`; after a merge the new top pair
+    // is read back -- a chain step itself costs the row fetch and two barriers, no other dependent memory access
+    int chain_length = 0, first_live = 0, top = 0, pred = -1;
+    double top_pred_dist = inf;
+    __syncthreads();
+    for (int k = 0; k < n - 1; ++k) {
+        if (tid == 0) {
+            if (chain_length == 0) {
+                while (size[first_live] == 0) ++first_live;  // the lowest live index starts a chain
+                chain[0] = first_live;
+                chain_length = 1;
+                top = first_live;
+                pred = -1;
+                top_pred_dist = inf;
+            }
+            s_x = top;
+        }
+        while (true) {                                   // go down the chain
+            __syncthreads();
+            const int x = s_x;
+            const double* __restrict__ row = D + (long long)x * n;
+            // first index of the minimum over the live clusters (`dist < current_min` of a scan in index order)
+            // (every load of a round is issued before the first compare: a dependent load per entry made a step
+            //  cost as many L2 round trips as a thread has entries -- 10 us at T = 10 000)
+            double m = inf;
+            int mi = 0x7fffffff;
+            constexpr int U = 8;
+            for (int i0 = tid; i0 < n; i0 += U * 1024) {
+                double v[U];
+                int live[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int i = min(i0 + u * 1024, n - 1);
+                    v[u] = row[i];
+                    live[u] = size[i];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int i = i0 + u * 1024;
+                    const double w = (i < n && live[u] > 0) ? v[u] : inf;     // (the diagonal holds +inf)
+                    if (w < m) { m = w; mi = i; }
+                }
+            }
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const double ov = __shfl_xor(m, off, 64);
+                const int oi = __shfl_xor(mi, off, 64);
+                if (ov < m || (ov == m && oi < mi)) { m = ov; mi = oi; }
+            }
+            if (lane == 0) { wmin[wave] = m; widx[wave] = mi; }
+            __syncthreads();
+            if (tid == 0) {
+#pragma unroll
+                for (int w = 1; w < 16; ++w)
+                    if (wmin[w] < m || (wmin[w] == m && widx[w] < mi)) { m = wmin[w]; mi = widx[w]; }
+                double cur = top_pred_dist;                          // the previous element wins ties
+                int y = pred;
+                if (m < cur) { cur = m; y = mi; }
+                if (chain_length > 1 && y == pred) {                 // x and y are reciprocal nearest neighbours
+                    chain_length -= 2;
+                    const int a = x < y ? x : y, b = x < y ? y : x;
+                    s_a = a; s_b = b; s_na = size[a]; s_nb = size[b];
+                    merges[k] = ChainMergeDev{a, b, cur};
+                    s_merge = 1;
+                } else {
+                    chain[chain_length++] = y;
+                    pred = x;
+                    top = y;
+                    top_pred_dist = cur;
+                    s_x = y;
+                    s_merge = 0;
+                }
+            }
+            __syncthreads();
+            if (s_merge) break;
+        }
+        // a is dropped, b becomes the merged cluster: d(i, a u b) = (n_a d(i,a) + n_b d(i,b)) / (n_a + n_b), every
+        // operation rounded on its own like the host code (no fused multiply-add)
+        const int a = s_a, b = s_b;
+        const double fa = (double)s_na, fb = (double)s_nb, fs = (double)(s_na + s_nb);
+        const double* __restrict__ ra = D + (long long)a * n;
+        double* __restrict__ rb = D + (long long)b * n;
+        {
+            constexpr int U = 8;
+            for (int i0 = tid; i0 < n; i0 += U * 1024) {
+                double va[U], vb[U];
+                int live[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int i = min(i0 + u * 1024, n - 1);
+                    va[u] = ra[i];
+                    vb[u] = rb[i];
+                    live[u] = size[i];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int i = i0 + u * 1024;
+                    if (i >= n || i == a || i == b || live[u] == 0) continue;
+                    const double v = average_update(fa, va[u], fb, vb[u], fs);
+                    rb[i] = v;
+                    D[(long long)i * n + b] = v;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            size[a] = 0;
+            size[b] = s_na + s_nb;
+            if (chain_length >= 1) {                     // the pair on top of what is left of the chain
+                top = chain[chain_length - 1];
+                pred = chain_length > 1 ? chain[chain_length - 2] : -1;
+                top_pred_dist = pred >= 0 ? D[(long long)top * n + pred] : inf;
+            }
+        }
+    }
+}
+
 }  // namespace vbx

@@ -2009,6 +2009,36 @@ int vbx_fcluster_distance(int64_t n, const double* Z, double t, int32_t* labels)
     return VBX_OK;
 }
 
+int vbx_scores_linkage_average(vbx_scores* sc, int64_t T, double* Z) {
+    if (!sc || !Z || T < 1 || (long long)T * T != sc->n || T > 0x7fffffffLL / 2) return VBX_ERR_INVALID;
+    if (T == 1) return VBX_OK;
+    vbx_ctx* ctx = sc->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int *d_size = nullptr, *d_chain = nullptr;
+    vbx::ChainMergeDev* d_merges = nullptr;
+    int rc = dmalloc(ctx, &d_size, (size_t)T);
+    if (rc == VBX_OK) rc = dmalloc(ctx, &d_chain, (size_t)T);
+    if (rc == VBX_OK) rc = dmalloc(ctx, &d_merges, (size_t)(T - 1));
+    std::vector<vbx::ChainMerge> merges((size_t)(T - 1));
+    static_assert(sizeof(vbx::ChainMerge) == sizeof(vbx::ChainMergeDev), "merge record layout");
+    hipError_t e = hipSuccess;
+    if (rc == VBX_OK) {
+        hipStream_t st = ctx->stream;
+        hipLaunchKernelGGL(vbx::linkage_prepare_kernel, dim3((unsigned)T), dim3(256), 0, st, sc->d_s, (long long)T);
+        hipLaunchKernelGGL(vbx::nn_chain_kernel, dim3(1), dim3(1024), 0, st, sc->d_s, (int)T, d_size, d_chain, d_merges);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(merges.data(), d_merges, sizeof(vbx::ChainMerge) * merges.size(), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    ctx_free(ctx, d_size);
+    ctx_free(ctx, d_chain);
+    ctx_free(ctx, d_merges);
+    if (rc != VBX_OK) return rc;
+    if (e != hipSuccess) FAIL(ctx, VBX_ERR_HIP, "device linkage failed: %s", hipGetErrorString(e));
+    vbx::finish_linkage(T, merges.data(), Z);
+    return VBX_OK;
+}
+
 int vbx_scores_get_condensed(vbx_scores* sc, int64_t T, double scale, double* out) {
     if (!sc) return VBX_ERR_INVALID;
     vbx_ctx* ctx = sc->ctx;

@@ -10,11 +10,11 @@
 //   from the chain; after n - 1 merges sort them by distance (stable) and relabel through a union-find so that
 //   row k of Z = (smaller id, larger id, distance, members), new clusters numbered n, n + 1, ... in sorted order.
 //
-// Why this is not a GPU kernel: n - 1 merges, each a handful of DEPENDENT steps over one row of the distance
-// matrix (n <= a few thousand x-vectors: 8 n bytes, L1/L2-resident on a CPU core) -- 3 n steps of ~1 us of work
-// each would be 3 n kernel-scale latencies on the device.  What the device does contribute is the input (the
-// condensed negated similarity matrix, vbx_scores_get_condensed).  Recordings are independent: the driver runs
-// one clustering per host thread (the entry point holds no lock and no global state).
+// This host version serves callers that bring their own condensed matrix (and is the model the device version is
+// tested against bit for bit).  The driver uses the device version (vbx_ahc.hpp, nn_chain_kernel: one persistent
+// workgroup walks the chain on the score matrix where it lies in HBM -- no kernel launch per step, and the T^2 / 2
+// doubles of the condensed matrix never cross PCIe): 3 ms here vs the device at T = 1 000, but 0.6 s vs 0.1 s at
+// T = 10 000 and 2.6 s vs 0.4 s at T = 20 000, where the README of the reference (README.md:24) puts the pain.
 //
 // Working storage is the full matrix (rows contiguous: every scan and update streams), n^2 doubles.  The arithmetic
 // on live entries is exactly SciPy's (same operations in the same order), so Z is reproduced bit for bit.
@@ -28,6 +28,9 @@
 #include <vector>
 
 namespace vbx {
+
+struct ChainMerge { int a, b; double d; };          // clusters a < b merged at distance d (b keeps the merged cluster)
+inline void finish_linkage(int64_t n, const ChainMerge* merges, double* Z);
 
 inline void average_linkage(int64_t n, const double* cond, double* Z) {
     if (n < 2) return;
@@ -65,8 +68,7 @@ inline void average_linkage(int64_t n, const double* cond, double* Z) {
     std::vector<double> dead((size_t)n, 0.0);                   // 0 for a live cluster, +inf for a dead one
     std::vector<int64_t> chain((size_t)n), row_version((size_t)n, 0);
     int64_t chain_length = 0, first_live = 0;
-    struct Merge { int64_t a, b; double d; };
-    std::vector<Merge> merges((size_t)(n - 1));
+    std::vector<ChainMerge> merges((size_t)(n - 1));
     std::vector<int64_t> stamp((size_t)n, 0);                  // merge count at which a cluster's row was last rewritten
     std::vector<int64_t> todo((size_t)n);
     auto refresh = [&](int64_t r, int64_t k) {                  // entries of the live clusters rewritten since row r was
@@ -138,7 +140,7 @@ inline void average_linkage(int64_t n, const double* cond, double* Z) {
         refresh(y, k);                                          // (y was scanned before the merges that shortened the chain)
         if (x > y) std::swap(x, y);
         const int nx = size[(size_t)x], ny = size[(size_t)y];
-        merges[(size_t)k] = Merge{x, y, current_min};
+        merges[(size_t)k] = ChainMerge{(int)x, (int)y, current_min};
         size[(size_t)x] = 0;                                    // x is dropped, y becomes the merged cluster
         size[(size_t)y] = nx + ny;
         dead[(size_t)x] = inf;
@@ -149,6 +151,13 @@ inline void average_linkage(int64_t n, const double* cond, double* Z) {
         stamp[(size_t)y] = k + 1;
         row_version[(size_t)y] = k + 1;
     }
+    finish_linkage(n, merges.data(), Z);
+}
+
+// Second half of the algorithm, shared with the device chain (vbx_ahc.hpp nn_chain_kernel): the n - 1 merges in the
+// order the chain found them -> Z.
+inline void finish_linkage(int64_t n, const ChainMerge* merges_in, double* Z) {
+    const ChainMerge* merges = merges_in;
     // stable sort by distance, then cluster ids through a union-find (labels n, n + 1, ... in sorted order)
     std::vector<int64_t> order((size_t)(n - 1));
     std::iota(order.begin(), order.end(), (int64_t)0);
@@ -168,7 +177,7 @@ inline void average_linkage(int64_t n, const double* cond, double* Z) {
         return root;
     };
     for (int64_t k = 0; k < n - 1; ++k) {
-        const Merge& m = merges[(size_t)order[(size_t)k]];
+        const ChainMerge& m = merges[(size_t)order[(size_t)k]];
         const int64_t ra = find(m.a), rb = find(m.b);
         double* z = Z + 4 * k;
         z[0] = (double)std::min(ra, rb);

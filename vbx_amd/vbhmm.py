@@ -11,8 +11,8 @@ CPU thread.  Here the loop is split into stages:
   0. ALL x-vectors of this rank go to the device once; the projections of vbhmm.py:125-129 and the PLDA projection
      ``fea`` of vbhmm.py:153 are computed there for the whole archive and stay resident;
   1. per recording: AHC initialisation -- similarity matrix of the resident rows, threshold calibration and the
-     condensed negated matrix on the GPU, average-linkage clustering on the host in worker threads (a chain of T
-     dependent nearest-neighbour steps: nothing for a GPU to do);
+     average-linkage nearest-neighbour chain on the device (one persistent workgroup per recording, several recordings
+     side by side on their own streams), the cut of the dendrogram on the host;
   2. ALL recordings of this rank in one ``vbx_batch``: initial responsibilities from the AHC labels on the device
      (vbhmm.py:150-152), one launch sequence per EM iteration for the whole archive, convergence per recording on the
      device (vbhmm.py:154-158 call, batched), first / second speaker by a device arg-sort (vbhmm.py:160-162);
@@ -34,7 +34,7 @@ import numpy as np
 from .kaldi_formats import (read_plda, read_vec_flt_ark_grouped, read_xvec_transform, read_xvector_timing_dict,
                             write_rttm)
 
-__all__ = ['main', 'diarize', 'DeviceStages', 'tune_host_process', 'load_models', 'cluster', 'merge_adjacent_labels', 'l2_norm']
+__all__ = ['main', 'diarize', 'DeviceStages', 'tune_host_process', 'load_models', 'cluster', 'cut_linkage', 'merge_adjacent_labels', 'l2_norm']
 
 
 def l2_norm(vec_or_matrix):
@@ -72,19 +72,24 @@ def load_models(xvec_transform, plda_file):
     return dict(mean1=mean1, mean2=mean2, lda=lda, plda_mu=plda_mu, plda_psi=acvar[::-1], plda_tr=wccn.T[::-1])
 
 
-def cluster(cond, thr, threshold):
-    """Average-linkage clustering of the condensed negated similarities, cut at the calibrated threshold
-    (vbhmm.py:140-146) -> integer cluster label per x-vector.  The linkage is the library's native host routine
-    (``vbx_linkage_average``: nearest-neighbour chain, SciPy's linkage matrix bit for bit -- SciPy is the stand-in for
-    the un-installed fastcluster, whose average-linkage update may differ from it in the last bit; the cut is
-    ``vbx_fcluster_distance``): a chain of T dependent steps over cache-resident rows, nothing for a GPU to do -- but it
-    holds no interpreter lock, so the driver clusters several recordings at a time next to the GPU score stage of the
-    following ones."""
+def cut_linkage(lin_mat, thr, threshold):
+    """vbhmm.py:142-146: the linkage matrix shifted to non-negative distances and cut at the calibrated threshold ->
+    integer cluster label per x-vector (``vbx_fcluster_distance``: SciPy's fcluster(criterion='distance'), native)."""
     from . import _capi
-    lin_mat = _capi.linkage_average(cond)
+    if len(lin_mat) == 0:
+        return np.zeros(1, dtype=np.int64)
     adjust = abs(lin_mat[:, 2].min())
     lin_mat[:, 2] += adjust
     return _capi.fcluster_distance(lin_mat, -(thr + threshold) + adjust).astype(np.int64) - 1
+
+
+def cluster(cond, thr, threshold):
+    """Average-linkage clustering of condensed negated similarities held on the HOST, cut at the calibrated threshold
+    (vbhmm.py:140-146): ``vbx_linkage_average`` (nearest-neighbour chain, SciPy's linkage matrix bit for bit -- SciPy is
+    the stand-in for the un-installed fastcluster, whose average-linkage update may differ from it in the last bit).
+    The driver itself clusters on the device (``DeviceStages.ahc``); this serves callers with their own matrix."""
+    from . import _capi
+    return cut_linkage(_capi.linkage_average(cond), thr, threshold)
 
 
 class DeviceStages:
@@ -92,8 +97,10 @@ class DeviceStages:
 
     project   every x-vector of this rank goes up ONCE; the projections of vbhmm.py:125-129 and the PLDA projection of
               vbhmm.py:153 run on the device for all recordings together and stay resident (vbx_xvectors)
-    scores    per recording: cosine-similarity matrix of its resident rows, two-Gaussian calibration, and the condensed
-              negated matrix for the host clustering (vbhmm.py:135-139) -- the T x T matrix never leaves the device
+    ahc       per recording: cosine-similarity matrix of its resident rows, two-Gaussian calibration and the
+              average-linkage nearest-neighbour chain, all on the T x T matrix where it lies in HBM (vbhmm.py:135-141);
+              the T - 1 merges come back and are cut on the host (vbhmm.py:142-146).  Every driver thread has its own
+              context (device stream), so the chains of several recordings run side by side on different CUs
     vb        ALL recordings in one ``vbx_batch``: initial responsibilities built on the device from the AHC labels
               (vbhmm.py:150-152), one launch sequence per EM iteration for the whole archive, convergence per recording
               on the device (vbhmm.py:154-158), first / second speaker by a device arg-sort (vbhmm.py:160-162): only
@@ -101,10 +108,21 @@ class DeviceStages:
     """
 
     def __init__(self, device=None):
+        import threading
         from . import _capi
         self._capi = _capi
         self.ctx = _capi.default_context(device)
         self.xv = None
+        self._local = threading.local()
+        self._thread_ctxs = []
+
+    def _thread_ctx(self):
+        """A context (= a HIP stream) of its own for every driver thread: a ctx is not thread-safe."""
+        ctx = getattr(self._local, 'ctx', None)
+        if ctx is None:
+            ctx = self._local.ctx = self._capi.Context(self.ctx.device)
+            self._thread_ctxs.append(ctx)
+        return ctx
 
     def project(self, recordings, models, lda_dim):
         self.T = [len(r[1]) for r in recordings]
@@ -117,14 +135,22 @@ class DeviceStages:
         self.xv = self._capi.XVectors(self.ctx, x, models['mean1'], models['lda'], models['mean2'], models['plda_mu'],
                                       models['plda_tr'], lda_dim)
 
-    def scores(self, k):
-        sc = self._capi.Scores.cos_similarity_resident(self.ctx, self.xv, self.row0[k], self.T[k])
+    # The chain costs ~3 us per step on the device whatever T is (3 T steps), the host routine ~3 ns per matrix entry:
+    # the device wins from T ~ 3000 (measured: T = 1025 12 vs 3 ms, T = 4000 on par, T = 10 000 0.1 vs 0.6 s)
+    DEVICE_LINKAGE_FROM = int(os.environ.get('VBX_AMD_DEVICE_LINKAGE_FROM', '3000'))
+
+    def ahc(self, k, threshold):
+        """-> (AHC labels of recording k, calibrated threshold)."""
+        sc = self._capi.Scores.cos_similarity_resident(self._thread_ctx(), self.xv, self.row0[k], self.T[k])
         try:
             thr, _ = sc.two_gmm_calib(20, want_llr=False)
-            cond = sc.get_condensed(self.T[k], -1.0)
+            if self.T[k] >= self.DEVICE_LINKAGE_FROM:
+                lin_mat = sc.linkage_average(self.T[k])
+            else:                                     # short recording: the host chain beats the device's step latency
+                lin_mat = self._capi.linkage_average(sc.get_condensed(self.T[k], -1.0)) if self.T[k] > 1 else np.empty((0, 4))
         finally:
             sc.close()
-        return cond, float(thr)
+        return cut_linkage(lin_mat, thr, threshold), float(thr)
 
     def vb(self, ks, labels, init_smoothing, maxIters, epsilon, precision, loopProb, Fa, Fb):
         """-> [(labels1st, labels2nd or None, iterations)] for the recordings ``ks`` with AHC labels ``labels``."""
@@ -146,6 +172,9 @@ class DeviceStages:
         if self.xv is not None:
             self.xv.close()
             self.xv = None
+        for ctx in self._thread_ctxs:
+            ctx.close()
+        self._thread_ctxs = []
 
 
 def tune_host_process():
@@ -236,27 +265,21 @@ def diarize(args, stages=None, log=print):
         t_proj = time.perf_counter()
 
         # ---- stage 1: AHC initialisation -----------------------------------------------------------------------------
-        # A few recordings at a time on worker threads: the native clustering and the device calls run without the
-        # interpreter lock; the GPU score stage (one stream, a ctx is not thread-safe) is taken in turns.
-        import threading
+        # A few recordings at a time on worker threads, each with its own device stream: the device calls run without
+        # the interpreter lock and the nearest-neighbour chains of different recordings run on different CUs.
         from concurrent.futures import ThreadPoolExecutor
-        gpu_turn = threading.Lock()
 
         def prepare(k):
             file_name, seg_names, _ = recordings[k]
-            with gpu_turn:
-                cond, thr = stages.scores(k)
-            labels1st = cluster(cond, thr, args.threshold)
-            del cond
+            labels1st, thr = stages.ahc(k, args.threshold)
             st = dict(labels1st=labels1st, labels2nd=None, thr=thr, n_iters=0, seg_names=seg_names)
             if not want_vb:
                 _write_rttm_files(args, file_name, st, segs_dict)        # AHC only: the result is final
             return file_name, st
 
-        # short recordings: the Python glue between the native calls limits the useful threads (measured 64 x 1025
-        # x-vectors: 3-4 threads 0.15 s, 6: 0.18 s, 12: 0.35 s); long ones are dominated by the clustering (T^2) and want more
-        longest = max((len(r[1]) for r in recordings), default=0)
-        n_workers = int(os.environ.get('VBX_AMD_DRIVER_THREADS', '8' if longest >= 2500 else '4'))
+        # the Python glue between the native calls limits the useful threads for short recordings; every thread holds a
+        # T x T score matrix on the device while it works (T = 20 000: 3.2 GB)
+        n_workers = int(os.environ.get('VBX_AMD_DRIVER_THREADS', '6'))
         n_workers = max(1, min(n_workers, (os.cpu_count() or 2) - 1))
         state = {}
         for rec in recordings:
