@@ -107,8 +107,20 @@ def test_transition_structure_detection():
     pi = np.array([0.2, 0.5, 0.3])
     lp, off = _split_transition(np.eye(3) * 0.9 + 0.1 * pi)
     assert np.isclose(lp, 0.9) and np.allclose(off, 0.1 * pi)
-    with pytest.raises(NotImplementedError):
-        _split_transition(np.array([[0.5, 0.5, 0.0], [0.1, 0.8, 0.1], [0.3, 0.3, 0.4]]))
+    # anything else goes to the dense kernel (vbx_forward_backward_dense): no structure to exploit
+    assert _split_transition(np.array([[0.5, 0.5, 0.0], [0.1, 0.8, 0.1], [0.3, 0.3, 0.4]])) is None
+    assert _split_transition(np.diag([0.9, 0.8, 0.7]) + 0.1 * pi) is None          # self-loop probability not constant
+    assert _split_transition(np.eye(3) * 1.5 - 0.5 * pi) is None                   # loopProb outside [0, 1]
+
+
+def test_batch_api_rejects_arguments_it_would_ignore():
+    from vbx_amd.batch import _normalise
+    rec = dict(X=np.zeros((4, 3)), Phi=np.ones(3), pi=2, gamma=np.full((4, 2), 0.5))
+    assert _normalise(rec, dict(Fa=0.3))['Fa'] == 0.3
+    with pytest.raises(TypeError, match='maxIters'):
+        _normalise(dict(rec, maxIters=3), {})
+    with pytest.raises(TypeError, match='looprob'):
+        _normalise(rec, dict(looprob=0.5))
 
 
 def test_drop_in_module_exports_reference_names():

@@ -56,7 +56,9 @@ def load():
         except Exception as exc:  # a stale-but-present library is still usable on a box without hipcc
             if not os.path.exists(path):
                 raise VbxError(f'libvbx_hip.so is not built and cannot be built here: {exc}') from exc
-    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')      # before the HIP runtime starts (see vbx_capi.hip)
+    want = os.environ.get('VBX_AMD_HW_QUEUES') or '8'       # before the HIP runtime starts (see vbx_capi.hip); '0': hands off
+    if want != '0':
+        os.environ.setdefault('GPU_MAX_HW_QUEUES', want)
     lib = C.CDLL(path)
     vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     lib.vbx_abi_version.restype = C.c_int

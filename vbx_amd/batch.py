@@ -32,6 +32,11 @@ def shard_recordings(costs, world_size: int):
 def _normalise(rec, defaults):
     """rec: dict with X, Phi and optional VBx() keyword arguments -> full argument dict."""
     kw = dict(loopProb=0.9, Fa=1.0, Fb=1.0, pi=10, gamma=None, alphaQInit=1.0, alpha=None, invL=None)
+    for where in (defaults, rec):
+        bad = set(where) - set(kw) - {'X', 'Phi'}
+        if bad:            # maxIters / epsilon are per batch; anything else is a typo that would be ignored silently
+            raise TypeError(f'VBx_batch: unexpected per-recording argument(s) {sorted(bad)} (maxIters and epsilon '
+                            'apply to the whole batch)')
     kw.update(defaults)
     kw.update({k: v for k, v in rec.items() if k not in ('X', 'Phi')})
     X = np.asarray(rec['X'])
@@ -48,17 +53,20 @@ def _normalise(rec, defaults):
                 Fb=kw['Fb'], alpha=kw['alpha'], invL=kw['invL'])
 
 
-def run_shard_hip(items, maxIters, epsilon, precision='fp32', device=None):
-    """Run normalised recordings on the local GPU, one vbx_batch per feature dimension."""
+def run_shard_hip(items, maxIters, epsilon, precision=None, device=None):
+    """Run normalised recordings on the local GPU, one vbx_batch per feature dimension.  ``precision=None`` is
+    VBx()'s rule (VBX_AMD_PRECISION, else fp32 only when every X of the batch is float32)."""
     from . import _capi
+    from .VBx import _pick_precision
     ctx = _capi.default_context(device)
     results = [None] * len(items)
     by_dim = {}
     for k, it in enumerate(items):
         by_dim.setdefault(it['X'].shape[1], []).append(k)
     for D, idx in by_dim.items():
+        prec = {_pick_precision(precision, items[k]['X']) for k in idx}
         batch = _capi.Batch(ctx, [items[k]['X'].shape[0] for k in idx], [len(items[k]['pi']) for k in idx], D,
-                            precision=precision, max_iters=maxIters)
+                            precision='fp64' if 'fp64' in prec else prec.pop(), max_iters=maxIters)
         try:
             for j, k in enumerate(idx):
                 it = items[k]
@@ -72,13 +80,15 @@ def run_shard_hip(items, maxIters, epsilon, precision='fp32', device=None):
     return results
 
 
-def VBx_batch(recordings, maxIters=10, epsilon=1e-4, precision='fp32', device=None, return_model=False,
+def VBx_batch(recordings, maxIters=10, epsilon=1e-4, precision=None, device=None, return_model=False,
               **defaults):
     """``[VBx(**rec, maxIters=..., epsilon=...) for rec in recordings]`` on one GPU, in one batch.
 
     Each recording is a dict with ``X`` and ``Phi`` plus any of VBx()'s keyword arguments;
-    ``defaults`` supplies shared hyper-parameters.  Returns a list of ``(gamma, pi, Li[, alpha,
-    invL])`` tuples in input order (same types as the reference returns, VBx.py:126)."""
+    ``defaults`` supplies shared hyper-parameters; ``maxIters`` and ``epsilon`` apply to the whole batch.  ``precision``
+    follows VBx(): fp64 kernels unless every X is float32 (or VBX_AMD_PRECISION / the argument says otherwise), so the
+    numerics and iteration counts are those of one VBx() call per recording.  Returns a list of ``(gamma, pi, Li[,
+    alpha, invL])`` tuples in input order (same types as the reference returns, VBx.py:126)."""
     items = [_normalise(r, defaults) for r in recordings]
     if maxIters <= 0:
         return [(it['gamma'], it['pi'], []) + ((it['alpha'], it['invL']) if return_model else ())
@@ -96,7 +106,7 @@ def _as_tuple(res, return_model):
     return out
 
 
-def VBx_batch_distributed(recordings, maxIters=10, epsilon=1e-4, precision='fp32', return_model=False,
+def VBx_batch_distributed(recordings, maxIters=10, epsilon=1e-4, precision=None, return_model=False,
                           run_shard=None, gather=True, **defaults):
     """Shard ``recordings`` over the ranks of the initialised ``torch.distributed`` group.
 

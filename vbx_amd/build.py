@@ -38,13 +38,23 @@ def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the library if it is missing or older than its sources; return its path."""
     if not force and not is_stale():
         return LIB
-    cmd = [_hipcc()] + FLAGS + ['-o', LIB + '.tmp'] + SOURCES
-    if verbose:
-        print(' '.join(cmd))
-    res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError('hipcc failed:\n' + res.stdout + res.stderr)
-    os.replace(LIB + '.tmp', LIB)
+    # every rank of a torchrun job may find the library stale at once: one builds (file lock), the others wait and
+    # then find it fresh; the output goes to a name of its own and is moved into place atomically
+    import fcntl
+    with open(os.path.join(CSRC, '.build.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not is_stale():
+            return LIB
+        tmp = f'{LIB}.{os.getpid()}.tmp'
+        cmd = [_hipcc()] + FLAGS + ['-o', tmp] + SOURCES
+        if verbose:
+            print(' '.join(cmd))
+        res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+        if res.returncode != 0:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+            raise RuntimeError('hipcc failed:\n' + res.stdout + res.stderr)
+        os.replace(tmp, LIB)
     return LIB
 
 

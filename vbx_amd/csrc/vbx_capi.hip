@@ -41,7 +41,14 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // streams on one queue run one after the other (measured: a 4-stream group drops from 211 k to 168 k
 // recording-iterations/s when any other stream exists in the process).  Ask for eight before the runtime starts --
 // if it has already started (another library initialised HIP first) this does nothing.
-static const int g_hw_queues_set = setenv("GPU_MAX_HW_QUEUES", "8", 0);
+// The override is the library's only process-wide side effect; VBX_AMD_HW_QUEUES=0 switches it off (the host application
+// keeps whatever it configured), VBX_AMD_HW_QUEUES=<n> asks for another number.  A value the application has already
+// put into GPU_MAX_HW_QUEUES is never overwritten.
+static const int g_hw_queues_set = [] {
+    const char* want = std::getenv("VBX_AMD_HW_QUEUES");
+    if (!want || !*want) want = "8";
+    return std::strcmp(want, "0") == 0 ? 0 : setenv("GPU_MAX_HW_QUEUES", want, 0);
+}();
 
 struct vbx_ctx {
     int device = 0;
@@ -60,7 +67,8 @@ struct vbx_ctx {
     // process).
     std::vector<std::pair<hipStream_t, bool>> group_streams;   // (stream, in use)
     bool recycle = true;                                       // false for the private ctx of a stream-group kid
-};
+    std::mutex alloc_mutex;                                    // the block lists: a scores object may be closed by whichever
+};                                                             // thread the interpreter's garbage collector runs on
 
 #define HIPCHK(ctx_, call)                                                                    \
     do {                                                                                       \
@@ -403,6 +411,7 @@ void launch_prep(vbx_batch* b, const RecDesc& rd) {
 
 // A block of at least `bytes` bytes: the smallest spare one that fits (and is at most twice too large), else a new one.
 int ctx_alloc(vbx_ctx* ctx, void** p, size_t bytes) {
+    std::lock_guard<std::mutex> lock(ctx->alloc_mutex);
     bytes = std::max<size_t>(bytes, 16);
     if (ctx->recycle) {
         int best = -1;
@@ -427,6 +436,7 @@ int ctx_alloc(vbx_ctx* ctx, void** p, size_t bytes) {
 // use (every user of the list runs on that stream or has waited for it); beyond 4 GB / 256 spares the block is freed.
 void ctx_free(vbx_ctx* ctx, void* p) {
     if (!p) return;
+    std::lock_guard<std::mutex> lock(ctx->alloc_mutex);
     auto it = ctx->live.find(p);
     const size_t bytes = it == ctx->live.end() ? 0 : it->second;
     if (it != ctx->live.end()) ctx->live.erase(it);
@@ -1221,13 +1231,11 @@ static int group_build(vbx_batch* b, int K) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     for (int k = 0; k < K; ++k) {
         std::sort(members[k].begin(), members[k].end());
-        vbx_ctx* kc = new vbx_ctx(*ctx);
-        kc->err.clear();
-        kc->spare.clear();
-        kc->spare_bytes = 0;
-        kc->live.clear();
+        vbx_ctx* kc = new vbx_ctx();                // the parent's device and stream, block lists of its own
+        kc->device = ctx->device;
+        kc->stream = ctx->stream;
+        kc->prop = ctx->prop;
         kc->recycle = false;
-        kc->group_streams.clear();
         if (k > 0) {
             kc->stream = nullptr;
             for (auto& gs : ctx->group_streams)

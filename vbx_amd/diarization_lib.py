@@ -9,7 +9,8 @@ Both functions keep the reference's signatures, return types and error behaviour
 kernels (f64 MFMA for the similarity matrix, one streaming kernel per EM pass).  The score matrix stays
 resident in HBM between the two calls: ``cos_similarity`` remembers the device copy of the array it
 returns, and ``twoGMMcalib_lin`` recognises that array (or a flat view of it, as ``.ravel()`` gives)
-and calibrates the resident copy instead of uploading 8*T*T bytes again.  There is no CPU fallback.
+and calibrates the resident copy instead of uploading 8*T*T bytes again.  The returned matrix is read-only for that
+reason (``scr_mx.copy()`` gives an editable one, which is uploaded like any other array).  There is no CPU fallback.
 """
 from __future__ import annotations
 
@@ -49,6 +50,8 @@ def _find_resident(s):
                 if all(scores.get(int(k), 1)[0] == flat[k] for k in probe[:8]) and \
                         np.array_equal(scores.get(int(probe[-1]), 1), flat[probe[-1]:probe[-1] + 1]):
                     return scores
+                _resident.pop(id(base), None)          # someone forced a write: the device copy is stale for good
+                scores.close()
             return None
         base = base.base
     return None
@@ -67,7 +70,8 @@ def cos_similarity(x, *, device=None):
     scores = _capi.Scores.cos_similarity(ctx, x)
     out = np.empty((x.shape[0], x.shape[0]))        # owns its memory: views of it (ravel) have it as .base
     scores.get(out=out)
-    _remember(out, scores)
+    out.flags.writeable = False     # the device copy stands for this array: an in-place edit must not go unnoticed
+    _remember(out, scores)          # (callers that want to edit the scores take a copy, which is then uploaded)
     return out
 
 

@@ -187,9 +187,13 @@ def tune_host_process():
       * the matrix products of one recording are tiny (1000 x 256 x 128): a 64-thread BLAS pool costs more to wake
         than it saves.
 
-    Returns a context manager that limits the BLAS pools (a no-op without ``threadpoolctl``)."""
+    Returns a context manager that limits the BLAS pools (a no-op without ``threadpoolctl``).  Both are process-wide:
+    an application that embeds ``diarize()`` and manages its own heap / BLAS settings switches them off with
+    ``VBX_AMD_TUNE_HOST=0``."""
     import contextlib
     import ctypes
+    if os.environ.get('VBX_AMD_TUNE_HOST', '1') == '0':
+        return contextlib.nullcontext()
     try:
         libc = ctypes.CDLL(None)
         libc.mallopt(ctypes.c_int(-3), ctypes.c_int(1 << 30))     # M_MMAP_THRESHOLD (glibc clamps it to 32 MB)
