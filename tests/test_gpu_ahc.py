@@ -49,12 +49,20 @@ def test_resident_matrix_is_dropped_when_the_host_copy_changes_or_dies():
     scr = dl.cos_similarity(x)
     assert dl._find_resident(scr.ravel()) is not None
     assert dl._find_resident(scr.ravel()[:100]) is None and dl._find_resident(scr.T) is None
-    scr[0, 0] = 0.25                                                 # host copy edited: must not use the stale device copy
-    assert dl._find_resident(scr.ravel()) is None
-    thr, _ = dl.twoGMMcalib_lin(scr.ravel())
-    np.testing.assert_allclose(thr, ahc_oracle.twoGMMcalib_lin(scr.ravel())[0], rtol=1e-10)
+    with pytest.raises(ValueError):                                  # the device copy stands for this array: read-only
+        scr[0, 0] = 0.25
+    edited = scr.copy()                                              # an editable copy is a new array: uploaded
+    edited[0, 0] = 0.25
+    assert dl._find_resident(edited.ravel()) is None
+    thr, _ = dl.twoGMMcalib_lin(edited.ravel())
+    np.testing.assert_allclose(thr, ahc_oracle.twoGMMcalib_lin(edited.ravel())[0], rtol=1e-10)
+    scr.flags.writeable = True                                       # someone forces a write anyway: the spot check at
+    scr.ravel()[::7] = 0.5                                           # the next use finds it and drops the device copy
     n = len(dl._resident)
-    del scr
+    assert dl._find_resident(scr.ravel()) is None and len(dl._resident) == n - 1
+    scr2 = dl.cos_similarity(x)
+    n = len(dl._resident)
+    del scr2
     gc.collect()
     assert len(dl._resident) == n - 1
 
