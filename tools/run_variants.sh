@@ -1,3 +1,3 @@
-python tools/kbench.py --tag s128 --batch 1 --S 128 2>&1 | tail -1
-python tools/kbench.py --tag s200 --batch 1 --S 200 2>&1 | tail -1
-python tools/kbench.py --tag s200f64 --batch 1 --S 200 --precision fp64 2>&1 | tail -1
+python tools/kbench.py --tag main 2>&1 | tail -1
+python tools/kbench.py --tag main-f64 --precision fp64 2>&1 | tail -1
+python tools/kbench.py --tag single --batch 1 2>&1 | tail -1

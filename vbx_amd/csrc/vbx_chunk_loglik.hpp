@@ -1,8 +1,7 @@
 // vbx_chunk_loglik.hpp -- chunk_loglik: per-frame speaker log-likelihoods and the chunk's transfer operator in one
 // pass over rho (the other per-chunk kernel, chunk_post, is in vbx_chunk_post.hpp).
 #pragma once
-#include <type_traits>
-#include "vbx_scan.hpp"
+#include "vbx_operator.hpp"
 
 namespace vbx {
 
@@ -51,7 +50,6 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)si
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, g = lane >> 4;
     const int t0 = bt.tile_t0[tile];
     const int len = min(kTileFrames, rd.T - t0);
-    const R lp = (R)rd.lp;
 
     VBX_CLOCKS_DECL();
     VBX_STAMP();
@@ -153,135 +151,18 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)si
     __syncthreads();
     VBX_STAMP();
 
-    // ---- phase 2: transfer operators -----------------------------------------------------------------
-    // bt.spt == 2: one operator per half tile (frames [0, 64) and [64, len)), built side by side by two
-    // groups of NOPT threads when the workgroup is wide enough, else one after the other.
+    // ---- phase 2: the chunk's transfer operator, one column per group of PH lanes (vbx_operator.hpp) ------------------
     {
-        constexpr int NOPT = SP * PH;                      // threads that build one operator
-        constexpr int PAR = 256 / NOPT >= 2 ? 2 : 1;       // operators built side by side
-        const int nhalf = bt.spt == 2 ? (len > kScanHalf ? 2 : 1) : 1;
-        const int grp = tid / NOPT, lt = tid % NOPT;
-        for (int h0 = 0; h0 < nhalf; h0 += PAR) {
-            const int half = h0 + grp;
-            if (grp < PAR && half < nhalf) {
-                const int lo = bt.spt == 2 ? half * kScanHalf : 0;
-                const int hi = bt.spt == 2 ? min(len, lo + kScanHalf) : len;
-                const int col = lt / PH, part = lt % PH, j0 = part * NR;
-                // With lp > 0 the recursion runs on z_f = x_f / lp^(transitions so far):
-                //     x <- b (lp x + c sum(x))     becomes     z <- b (z + (c / lp) sum(z)),
-                // one FMA and one product per state instead of three operations; lp^(transitions) goes into the
-                // column's mantissa and exponent at the end.  lp == 0 (or subnormally small) keeps the plain form.
-                const bool scaled = rd.lp >= 0x1p-20;
-                R x[NR], c[NR];
+        constexpr int NOPT = SP * PH;                      // threads that build the operator
+        if (tid < NOPT) {
+            const int col = tid / PH, part = tid % PH, j0 = part * NR;
+            R x[NR];
+            int expo;
+            operator_column<R, SP, PH>(btile, 0, len, t0 == 0, col, part, rd.lp, bt.pi + (long long)rec * SP, rd.S, x, expo);
+            R* __restrict__ dst = bt.op + ((long long)tile * SP + col) * SP + j0;
 #pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    x[r] = (j0 + r == col) ? (R)1 : (R)0;
-                    const double cj = (1.0 - rd.lp) * bt.pi[(long long)rec * SP + j0 + r] + 1e-8;
-                    c[r] = (j0 + r < rd.S) ? (R)(scaled ? cj / rd.lp : cj) : (R)0;
-                }
-                int expo = 0, step = lo;
-                if (t0 + lo == 0) {          // frame 0 of the recording: x <- b_0 * x (VBx.py:163, no transition)
-#pragma unroll
-                    for (int r = 0; r < NR; ++r) x[r] *= btile[j0 + r];
-                    step = 1;
-                }
-                const int transitions = hi - step;
-                auto colsum = [&]() {        // pairwise: packed adds
-                    R v[NR];
-#pragma unroll
-                    for (int r = 0; r < NR; ++r) v[r] = x[r];
-#pragma unroll
-                    for (int w = NR / 2; w >= 1; w >>= 1)
-#pragma unroll
-                        for (int r = 0; r < w; ++r) v[r] += v[r + w];
-                    return column_sum<PH>(v[0]);
-                };
-                auto recursion = [&](auto scaled_tag) {
-                    // written on pairs of states: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 do two per issue slot
-                    using R2 = typename Vec<R>::v2;
-                    constexpr int NP = NR / 2;
-                    static_assert(NR % 4 == 0, "operator lanes hold a multiple of four states");
-                    R2 x2[NP], c2[NP];
-#pragma unroll
-                    for (int p = 0; p < NP; ++p) {
-                        x2[p] = R2{x[2 * p], x[2 * p + 1]};
-                        c2[p] = R2{c[2 * p], c[2 * p + 1]};
-                    }
-                    const R2 lp2 = R2{lp, lp};
-                    auto colsum2 = [&]() {
-                        R2 v[NP];
-#pragma unroll
-                        for (int p = 0; p < NP; ++p) v[p] = x2[p];
-#pragma unroll
-                        for (int w = NP / 2; w >= 1; w >>= 1)
-#pragma unroll
-                            for (int p = 0; p < w; ++p) v[p] += v[p + w];
-                        return column_sum<PH>(v[0].x + v[0].y);
-                    };
-                    auto frame = [&](int f, R sig) {
-                        const R2 sig2 = R2{sig, sig};
-                        const R* row = btile + f * SP + j0;
-#pragma unroll
-                        for (int q = 0; q < NR / 4; ++q) {
-                            const R4 b4 = *reinterpret_cast<const R4*>(row + 4 * q);
-                            const R2 b0 = R2{b4.x, b4.y}, b1 = R2{b4.z, b4.w};
-                            if (decltype(scaled_tag)::value) {
-                                x2[2 * q] = b0 * (c2[2 * q] * sig2 + x2[2 * q]);
-                                x2[2 * q + 1] = b1 * (c2[2 * q + 1] * sig2 + x2[2 * q + 1]);
-                            } else {
-                                x2[2 * q] = b0 * (lp2 * x2[2 * q] + c2[2 * q] * sig2);
-                                x2[2 * q + 1] = b1 * (lp2 * x2[2 * q + 1] + c2[2 * q + 1] * sig2);
-                            }
-                        }
-                    };
-                    auto renorm = [&]() {            // column sum back to [0.5, 1): one exact product per pair
-                        R sig = colsum2();
-                        const int e = rescale_exponent(sig);
-                        expo += e;
-                        const R sc = scale2((R)1, -e);
-                        const R2 sc2 = R2{sc, sc};
-#pragma unroll
-                        for (int p = 0; p < NP; ++p) x2[p] *= sc2;
-                        return sig * sc;
-                    };
-                    for (; step + 4 <= hi; step += 4) {
-                        frame(step, renorm());
-#pragma unroll
-                        for (int k = 1; k < 4; ++k) frame(step + k, colsum2());
-                    }
-                    for (; step < hi; ++step) frame(step, renorm());
-#pragma unroll
-                    for (int p = 0; p < NP; ++p) {
-                        x[2 * p] = x2[p].x;
-                        x[2 * p + 1] = x2[p].y;
-                    }
-                };
-                if (scaled) {
-                    recursion(std::true_type{});
-                    const double l2 = (double)transitions * log2(rd.lp), fl = floor(l2);
-                    const R mant = (R)exp2(l2 - fl);             // lp^transitions = mant * 2^fl, mant in [1, 2)
-                    expo += (int)fl;
-#pragma unroll
-                    for (int r = 0; r < NR; ++r) x[r] *= mant;
-                } else {
-                    recursion(std::false_type{});
-                }
-                {   // final power-of-two normalisation: column sums end in [0.5, 1)
-                    const R sig = colsum();
-                    const int e = rescale_exponent(sig);
-                    expo += e;
-#pragma unroll
-                    for (int r = 0; r < NR; ++r) x[r] = scale2(x[r], -e);
-                    // an all-zero column (b = 0 for its state at frame 0, or a padded state) must never win the
-                    // exponent maximum in scan2
-                    if (!(sig > (R)0)) expo = -(1 << 24);
-                }
-                const long long chunk = (long long)tile * bt.spt + half;
-                R* __restrict__ dst = bt.op + (chunk * SP + col) * SP + j0;
-#pragma unroll
-                for (int r = 0; r < NR; ++r) dst[r] = x[r];
-                if (part == 0) bt.opexp[chunk * SP + col] = expo;
-            }
+            for (int r = 0; r < NR; ++r) dst[r] = x[r];
+            if (part == 0) bt.opexp[(long long)tile * SP + col] = expo;
         }
     }
     VBX_STAMP();

@@ -28,6 +28,15 @@
 // the loop completely brings that to ~25); measured 182 us (two tiles per run), 226 us (three), 277-333 us (five:
 // one balanced round of persistent workgroups also puts the phases of the whole chip in lock-step) against 165 us.
 //
+// Also tried and dropped (round 2): the tile cut into four SUB-CHUNKS of 32 frames that re-run side by side in the four
+// 16-lane rows of the two re-run waves (32 dependent steps instead of 128; elimination runs of the re-run cut to 64 /
+// 32 / 4 frames: 134 / 119 / 107 us).  The vectors at the three inner edges need the sub-chunks' S x S transfer
+// operators; built here from the b tile (vbx_operator.hpp, all four waves) and pushed through by three mat-vecs per
+// direction the kernel took 190 us: the operator build is S^2 FMAs per frame of VALU work -- the same 40-45 us it
+// costs chunk_loglik, chip-wide VALU throughput, not latency -- and the edge chain + two more barriers eat what is
+// left of the gain.  Handing the operators over from chunk_loglik instead would add 16 KB per tile to both kernels'
+// traffic (+20 %) for an estimated 135 us.
+//
 // LDS: 2 regions of kTileFrames x SP + ~3 KB: 35 KB at SP = 32 (f32) -> four workgroups per CU.
 // Instrumentation build: -DVBX_PHASE_CLOCKS (per-workgroup phase stamps, tools/phase_timeline.py).
 #pragma once

@@ -1,0 +1,127 @@
+// vbx_operator.hpp -- one column of the forward transfer operator of a run of frames (VBx.py:167-171 in the linear
+// domain), shared by chunk_loglik (the chunk operators of the boundary walk) and chunk_post (the operators of the four
+// sub-chunks its re-run is cut into).
+//
+//   x <- b_f (lp x + c sum(x))   for f = lo .. hi-1, started from the unit vector e_col
+//
+// PH adjacent lanes share a column and hold NR = SP / PH states each (a multiple of four).  With lp > 0 the recursion
+// runs on z_f = x_f / lp^(transitions so far):  z <- b (z + (c / lp) sum(z)), one FMA and one product per state instead of
+// three operations; lp^(transitions) goes into the column's mantissa and exponent at the end (lp == 0, or subnormally
+// small, keeps the plain form).  The loop is written on pairs of states so that every product, FMA and partial sum
+// is a v_pk_*_f32; columns are rescaled by exact powers of two every four frames (a frame shrinks a column sum by at
+// least min c = 1e-8, so four frames stay inside the f32 range) and the exponent is kept aside.
+#pragma once
+#include <type_traits>
+#include "vbx_scan.hpp"
+
+namespace vbx {
+
+// btile: b of the tile in LDS, [frames][SP].  first_plain: frame lo is frame 0 of the recording (x <- b_0 x, VBx.py:163:
+// no transition).  pi_rec: the recording's priors [SP] (f64).  -> x[NR] (column sums in [0.5, 1)), expo (the column is
+// x * 2^expo; -(1 << 24) for an all-zero column, which must never win an exponent maximum).
+template <typename R, int SP, int PH>
+__device__ __forceinline__ void operator_column(const R* btile, int lo, int hi, bool first_plain, int col, int part,
+                                                double lp_d, const double* __restrict__ pi_rec, int n_spk,
+                                                R (&x)[SP / PH], int& expo) {
+    using R2 = typename Vec<R>::v2;
+    using R4 = typename Vec<R>::v4;
+    constexpr int NR = SP / PH, NP = NR / 2;
+    static_assert(NR % 4 == 0, "operator lanes hold a multiple of four states");
+    const int j0 = part * NR;
+    const R lp = (R)lp_d;
+    const bool scaled = lp_d >= 0x1p-20;
+    R c[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        x[r] = (j0 + r == col) ? (R)1 : (R)0;
+        const double cj = (1.0 - lp_d) * pi_rec[j0 + r] + 1e-8;
+        c[r] = (j0 + r < n_spk) ? (R)(scaled ? cj / lp_d : cj) : (R)0;
+    }
+    expo = 0;
+    int step = lo;
+    if (first_plain) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) x[r] *= btile[lo * SP + j0 + r];
+        step = lo + 1;
+    }
+    const int transitions = hi - step;
+    auto recursion = [&](auto scaled_tag) {
+        R2 x2[NP], c2[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            x2[p] = R2{x[2 * p], x[2 * p + 1]};
+            c2[p] = R2{c[2 * p], c[2 * p + 1]};
+        }
+        const R2 lp2 = R2{lp, lp};
+        auto colsum2 = [&]() {                   // pairwise: packed adds
+            R2 v[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) v[p] = x2[p];
+#pragma unroll
+            for (int w = NP / 2; w >= 1; w >>= 1)
+#pragma unroll
+                for (int p = 0; p < w; ++p) v[p] += v[p + w];
+            return column_sum<PH>(v[0].x + v[0].y);
+        };
+        auto frame = [&](int f, R sig) {
+            const R2 sig2 = R2{sig, sig};
+            const R* row = btile + f * SP + j0;
+#pragma unroll
+            for (int q = 0; q < NR / 4; ++q) {
+                const R4 b4 = *reinterpret_cast<const R4*>(row + 4 * q);
+                const R2 b0 = R2{b4.x, b4.y}, b1 = R2{b4.z, b4.w};
+                if (decltype(scaled_tag)::value) {
+                    x2[2 * q] = b0 * (c2[2 * q] * sig2 + x2[2 * q]);
+                    x2[2 * q + 1] = b1 * (c2[2 * q + 1] * sig2 + x2[2 * q + 1]);
+                } else {
+                    x2[2 * q] = b0 * (lp2 * x2[2 * q] + c2[2 * q] * sig2);
+                    x2[2 * q + 1] = b1 * (lp2 * x2[2 * q + 1] + c2[2 * q + 1] * sig2);
+                }
+            }
+        };
+        auto renorm = [&]() {                    // column sum back to [0.5, 1): one exact product per pair
+            R sig = colsum2();
+            const int e = rescale_exponent(sig);
+            expo += e;
+            const R sc = scale2((R)1, -e);
+            const R2 sc2 = R2{sc, sc};
+#pragma unroll
+            for (int p = 0; p < NP; ++p) x2[p] *= sc2;
+            return sig * sc;
+        };
+        for (; step + 4 <= hi; step += 4) {
+            frame(step, renorm());
+#pragma unroll
+            for (int k = 1; k < 4; ++k) frame(step + k, colsum2());
+        }
+        for (; step < hi; ++step) frame(step, renorm());
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            x[2 * p] = x2[p].x;
+            x[2 * p + 1] = x2[p].y;
+        }
+    };
+    if (scaled) {
+        recursion(std::true_type{});
+        const double l2 = (double)transitions * log2(lp_d), fl = floor(l2);
+        const R mant = (R)exp2(l2 - fl);                     // lp^transitions = mant * 2^fl, mant in [1, 2)
+        expo += (int)fl;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) x[r] *= mant;
+    } else {
+        recursion(std::false_type{});
+    }
+    {   // final power-of-two normalisation: column sums end in [0.5, 1)
+        R v = x[0];
+#pragma unroll
+        for (int r = 1; r < NR; ++r) v += x[r];
+        const R sig = column_sum<PH>(v);
+        const int e = rescale_exponent(sig);
+        expo += e;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) x[r] = scale2(x[r], -e);
+        if (!(sig > (R)0)) expo = -(1 << 24);
+    }
+}
+
+}  // namespace vbx
