@@ -494,9 +494,14 @@ int choose_fb_algo(vbx_batch* b, bool step_api_logs) {
     // two-level walk over the chunk boundaries: groups of ~sqrt(K) chunks once the flat chain gets long
     int group = 1;
     if (chunked && b->Sp <= 64) {            // (the wide scan walks the flat chain)
+        // a handful of recordings: the walk is exposed (nothing else to fill the GPU with), and groups of four cut its
+        // dependent chain from K to K/4 + 4 + 4 steps (T = 10 000, one recording: 28 -> 19 us per iteration); many
+        // recordings: the three launches of the two-level walk cost more than they save until the chain is long
         if (b->scan_group >= 2) group = b->scan_group;
         else if (b->scan_group == 0 && maxchunks >= b->two_level_from)
             group = std::max(4, (int)std::lround(std::sqrt((double)maxchunks)));
+        else if (b->scan_group == 0 && b->n_rec <= 4 && maxchunks >= 32)
+            group = 4;
     }
     if (group != b->sgroup || spt != b->spt || (group > 1 && !b->d_sop)) {
         for (void* p : {(void*)b->d_sop, (void*)b->d_sopexp, (void*)b->d_sup_rec, (void*)b->d_sup_idx}) ctx_free(b->ctx, p);
