@@ -7,7 +7,8 @@ import subprocess
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NAME = 'void vbx::chunk_post_mid_kernel<float, 32>(vbx::BatchView<float>)'
+NAME = 'void vbx::chunk_post_kernel<float, 32, false>(vbx::BatchView<float>)'
+REPLAY = 'void vbx::chunk_post_kernel<float, 32, true>(vbx::BatchView<float>)'
 OTHER = 'void vbx::scan2_kernel<float, 32>(vbx::BatchView<float>, int)'
 
 
@@ -22,6 +23,9 @@ def _db(path, counters):
             for inst in range(2):                                 # two counter rows per launch (two instances)
                 db.execute('insert into pmc_events values (?, ?, ?)', (NAME, cname, val))
                 db.execute('insert into pmc_events values (?, ?, ?)', (OTHER, cname, val / 10))
+    db.execute('insert into kernels values (?, ?, ?)', (REPLAY, 9000, 9000 + 90_000))
+    for cname, val in counters.items():
+        db.execute('insert into pmc_events values (?, ?, ?)', (REPLAY, cname, val / 4))
     db.commit()
     db.close()
 
@@ -36,15 +40,17 @@ def test_kernel_stats_and_pmc_tools(tmp_path):
                     'precision=fp32'], check=True, capture_output=True)
     doc = json.load(open(out))
     assert doc['workload'] == {'batch': 64, 'T': 10000, 'precision': 'fp32'}
-    k = doc['kernels']['chunk_post']                              # variants are filed under their kernel class
+    k = doc['kernels']['chunk_post']                              # (the gamma write-out instance is filed on its own)
     assert k['hbm_read_bytes'] == 2 * 1000 * 1024 and k['hbm_write_bytes'] == 500 * 1024
     assert k['hbm_bytes_per_launch'] == 2 * 1000 * 1024 + 500 * 1024 and 'scan2' in doc['kernels']
+    assert doc['kernels']['chunk_post_replay']['launches_profiled'] == 1
+    assert doc['iteration_hbm_bytes'] == k['hbm_bytes_per_launch'] + doc['kernels']['scan2']['hbm_bytes_per_launch']
     stats = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'rocpd_stats.py'), fetch], check=True,
                            capture_output=True, text=True).stdout
-    row = [line for line in stats.splitlines() if line.startswith('chunk_post_mid_kernel<float, 32>')][0].split()
+    row = [line for line in stats.splitlines() if line.startswith('chunk_post_kernel<float, 32, false>')][0].split()
     assert row[-6:-1] == ['4', '800.0', '200.00', '200.00', '200.00']          # calls, total, avg, min, max (us)
     txt = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'pmc_counters.py'), sq], check=True,
                          capture_output=True, text=True).stdout
-    line = [ln for ln in txt.splitlines() if ln.startswith('chunk_post_mid') and 'mfma_util' in ln][0]
+    line = [ln for ln in txt.splitlines() if ln.startswith('chunk_post') and 'mfma_util' in ln][0]
     # 2 rows x 245 760 busy cycles = 491 520 SIMD-cycles over 1024 SIMDs x 200 us x 2400 cycles/us = 0.001
     assert 'mfma_busy_simd_cycles         491520' in line and 'mfma_util  0.0010' in line and 'active/wave_cycles  0.2500' in line

@@ -1,7 +1,7 @@
-"""Instrumentation: per-workgroup phase timeline of chunk_post_mid / chunk_post_quad (library built with -DVBX_PHASE_CLOCKS).
+"""Instrumentation: per-workgroup phase timeline of chunk_post (library built with -DVBX_PHASE_CLOCKS).
 
-    hipcc ... -DVBX_PHASE_CLOCKS -o vbx_amd/csrc/libvbx_clk.so vbx_capi.hip
-    cp vbx_amd/csrc/libvbx_clk.so vbx_amd/csrc/libvbx_hip.so; VBX_AMD_NO_REBUILD=1 python tools/phase_timeline.py
+    tools/build_variants.sh clk:"-DVBX_PHASE_CLOCKS"
+    VBX_AMD_LIB=vbx_amd/csrc/libvbx_hip_clk.so python tools/phase_timeline.py
 """
 import ctypes as C
 import os
@@ -15,7 +15,6 @@ from vbx_amd.synth import make_recording  # noqa: E402
 
 
 def main(nrec=64, T=10000, S=30, out='gpurun_out/phase_timeline.npy'):
-    variant = int(os.environ.get('VBX_AMD_POST_KERNEL', '1'))
     ctx = _capi.Context(0)
     lib = _capi.load()
     batch = _capi.Batch(ctx, [T] * nrec, [S] * nrec, 128, precision='fp32', max_iters=6)
@@ -26,8 +25,6 @@ def main(nrec=64, T=10000, S=30, out='gpurun_out/phase_timeline.npy'):
         batch.set_recording(j, X, Phi, np.ones(S) / S, g0, 0.99, 0.3, 17.0)
     batch.run(6, -np.inf)
     ntile = nrec * ((T + 127) // 128)
-    if variant == 2:
-        ntile = (ntile + 3) // 4              # one workgroup = four tiles
     buf = np.zeros((8192, 2, 8), np.int64)
     rc = lib.vbx_debug_clocks(buf.ctypes.data_as(C.c_void_p), buf.size)
     assert rc == 0, rc
@@ -46,9 +43,6 @@ def main(nrec=64, T=10000, S=30, out='gpurun_out/phase_timeline.npy'):
     print('median phases:', dict(zip(names, np.median(d, axis=0).astype(int))), 'life', int(np.median(w0[:, 6] - w0[:, 0])))
     w1 = buf[:, 1, :]
     print('second recorded wave :', dict(zip(names, np.median(np.diff(w1[:, :7], axis=1), axis=0).astype(int))))
-    if variant == 2:
-        mhz = (w0[:, 3] - w0[:, 1]) / np.maximum(w0[:, 7], 1) * 100.0
-        print('shader clock during the re-run (MHz, from s_memtime / s_memrealtime): median', int(np.median(mhz)), 'min', int(mhz.min()), 'max', int(mhz.max()))
     early = order[:1024]
     late = order[1024:]
     print('first 1024 started :', dict(zip(names, np.median(d[early], axis=0).astype(int))))

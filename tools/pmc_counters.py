@@ -12,8 +12,11 @@ import sys
 
 
 def short(name):
-    m = re.search(r'vbx::(\w+?)(?:_kernel)?<', name)
-    return m.group(1) if m else name[:40]
+    m = re.search(r'vbx::(\w+?)(?:_kernel)?<([^>]*)>', name)
+    if not m:
+        return name[:40]
+    # the gamma write-out is an instance of chunk_post_kernel (<R, SP, true>) but not part of an iteration
+    return 'chunk_post_replay' if m.group(1) == 'chunk_post' and m.group(2).rstrip().endswith('true') else m.group(1)
 
 
 def main(path, out=None):

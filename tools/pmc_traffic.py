@@ -16,10 +16,14 @@ import sys
 
 
 def short(name):
-    m = re.search(r'vbx::(\w+?)(?:_kernel)?<', name)
-    n = m.group(1) if m else name
-    # the variants of one kernel class share its name (include/vbx_hip.h: VBX_K_CHUNK_POST)
-    return re.sub(r'^chunk_post_(mid|quad)$', 'chunk_post', n)
+    m = re.search(r'vbx::(\w+?)(?:_kernel)?<([^>]*)>', name)
+    if not m:
+        return name
+    # the gamma write-out is an instance of chunk_post_kernel (<R, SP, true>) but not part of an iteration
+    return 'chunk_post_replay' if m.group(1) == 'chunk_post' and m.group(2).rstrip().endswith('true') else m.group(1)
+
+
+ITERATION_KERNELS = ('mstep_fin', 'chunk_loglik', 'scan2', 'scan_compose', 'chunk_post', 'iter_fin')
 
 
 def per_kernel(path, counter):
@@ -49,7 +53,9 @@ def main(fetch_db, write_db, out, *kv):
     for item in kv:
         key, val = item.split('=', 1)
         workload[key] = int(val) if val.lstrip('-').isdigit() else val
-    doc = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), per-launch averages',
+    iteration = sum(kernels[k]['hbm_bytes_per_launch'] for k in ITERATION_KERNELS if k in kernels)
+    doc = {'iteration_hbm_bytes': iteration, 'iteration_kernels': [k for k in ITERATION_KERNELS if k in kernels],
+           'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), per-launch averages',
            'corrections': 'KiB -> bytes; FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM); WRITE_SIZE as reported',
            'workload': workload, 'kernels': kernels}
     with open(out, 'w') as fh:

@@ -9,7 +9,7 @@ import sys
 
 def short(name):
     m = re.search(r'vbx::(\w+)<([^>]*)>', name)
-    return f'{m.group(1)}<{m.group(2)}>' if m else name[:70]
+    return f'{m.group(1)}<{m.group(2)}>' if m else name[:70]         # (chunk_post_kernel<.., true> = the gamma write-out)
 
 
 def main(path, out=None):

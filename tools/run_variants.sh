@@ -1,4 +1,4 @@
-for b in 1 2 4 8; do python tools/kbench.py --tag "b$b" --batch $b --iters 100 2>&1 | tail -1 | python -c "
-import sys,json
-d=json.loads(sys.stdin.read())
-print(d['tag'], d['one_stream_ms_per_iter'], d['kernels_us'])"; done
+python tools/kbench.py --tag T50k --batch 1 --T 50000 --iters 40 2>&1 | tail -1
+python tools/kbench.py --tag T200k --batch 1 --T 200000 --S 50 --iters 20 2>&1 | tail -1
+python tools/kbench.py --tag T200k-f64 --batch 1 --T 200000 --S 50 --iters 20 --precision fp64 2>&1 | tail -1
+python tools/kbench.py --tag b8 --batch 8 --iters 60 2>&1 | tail -1
