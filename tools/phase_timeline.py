@@ -18,6 +18,7 @@ def main(nrec=64, T=10000, S=30, out='gpurun_out/phase_timeline.npy'):
     ctx = _capi.Context(0)
     lib = _capi.load()
     batch = _capi.Batch(ctx, [T] * nrec, [S] * nrec, 128, precision='fp32', max_iters=6)
+    batch.set_option(_capi.OPT_STREAMS, 1)           # tile numbers index the stamp table: one stream group
     X, Phi, _ = make_recording(T, S, seed=1, kappa=0.05)
     g0 = np.random.default_rng(2).gamma(1.0, size=(T, S))
     g0 /= g0.sum(1, keepdims=True)
@@ -31,6 +32,7 @@ def main(nrec=64, T=10000, S=30, out='gpurun_out/phase_timeline.npy'):
     buf = buf[:ntile]
     np.save(out, buf)
     w0 = buf[:, 0, :]
+    w1 = buf[:, 1, :]
     t0 = w0[:, 0].min()
     names = ['stage', 'half1', 'half2', 'wait', 'post', 'mfma']
     d = np.diff(w0[:, :7], axis=1)
@@ -41,8 +43,12 @@ def main(nrec=64, T=10000, S=30, out='gpurun_out/phase_timeline.npy'):
         print(f'blk {k:5d} hw {w0[k, 7]:08x} start {w0[k, 0] - t0:8d} ' +
               ' '.join(f'{n} {v:6d}' for n, v in zip(names, d[k])) + f'  life {w0[k, 6] - w0[k, 0]:7d}')
     print('median phases:', dict(zip(names, np.median(d, axis=0).astype(int))), 'life', int(np.median(w0[:, 6] - w0[:, 0])))
-    w1 = buf[:, 1, :]
     print('second recorded wave :', dict(zip(names, np.median(np.diff(w1[:, :7], axis=1), axis=0).astype(int))))
+    # HW_ID (gfx9 layout): wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13]
+    for nm, w in (('first recorded wave', w0), ('second recorded wave', w1)):
+        hw = w[:, 7]
+        print(nm, 'on SIMD 0..3:', np.bincount((hw >> 4) & 3, minlength=4).tolist(),
+              ' wave slot histogram:', np.bincount(hw & 15, minlength=16).tolist())
     early = order[:1024]
     late = order[1024:]
     print('first 1024 started :', dict(zip(names, np.median(d[early], axis=0).astype(int))))

@@ -1,4 +1,7 @@
-python tools/kbench.py --tag T50k --batch 1 --T 50000 --iters 40 2>&1 | tail -1
-python tools/kbench.py --tag T200k --batch 1 --T 200000 --S 50 --iters 20 2>&1 | tail -1
-python tools/kbench.py --tag T200k-f64 --batch 1 --T 200000 --S 50 --iters 20 --precision fp64 2>&1 | tail -1
-python tools/kbench.py --tag b8 --batch 8 --iters 60 2>&1 | tail -1
+for v in drain0 drain1 drain0 drain1; do
+VBX_AMD_LIB=vbx_amd/csrc/libvbx_hip_$v.so python tools/kbench.py --tag $v --iters 60 2>&1 | tail -1
+done
+for v in clk1; do
+echo "== $v"
+VBX_AMD_LIB=vbx_amd/csrc/libvbx_hip_$v.so python tools/phase_timeline.py 2>&1 | grep -v "^blk\|chunk_loglik" | head -12
+done

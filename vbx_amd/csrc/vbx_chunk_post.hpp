@@ -426,6 +426,7 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
         VBX_STAMP();
 #ifdef VBX_PHASE_CLOCKS
         // plain stores into a module-scope table (printf would fence the whole XCD): read with vbx_debug_clocks()
+        // (one stream group only: tile numbers index the table)
         if (lane == 0 && (wave == 0 || wave == 2) && bt.state[rec].n_iters == 3 && tile < kClockTiles) {
             unsigned hw;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
