@@ -60,8 +60,8 @@ extern "C" {
 #define VBX_OPT_PROFILE 3       /* 0: off; 1: bracket every kernel launch with HIP events;
                                    2*mask: only the kernel classes whose bit (1 << VBX_K_*) is set in mask */
 #define VBX_OPT_CHUNK_FRAMES 4  /* frames per scan chunk for VBX_FB_CHUNKED (0 = auto)         */
-#define VBX_OPT_SCAN_GROUP 6    /* chunks per group of the two-level boundary walk: 0 auto (sqrt of the chunk count
-                                   once a recording has >= 160 chunks), 1 flat chain, >= 2 explicit              */
+#define VBX_OPT_SCAN_GROUP 6    /* chunks per group of the two-level boundary walk: 0 auto (sqrt(chunks / 5) once a
+                                   recording has >= 160 chunks, or >= 32 in a batch of <= 4), 1 flat chain, >= 2 explicit */
 #define VBX_OPT_STREAMS 10      /* HIP streams of a batch: its recordings are dealt to that many sub-batches, one
                                    iteration of each is launched stream after stream, so the latency-bound launches of
                                    one overlap the bandwidth-bound ones of the others.  0 = auto (3 from 24 recordings and

@@ -491,17 +491,20 @@ int choose_fb_algo(vbx_batch* b, bool step_api_logs) {
         maxchunks = 0;
         for (auto& rd : b->recs) maxchunks = std::max(maxchunks, (rd.T + kTileFrames / 2 - 1) / (kTileFrames / 2));
     }
-    // two-level walk over the chunk boundaries: groups of ~sqrt(K) chunks once the flat chain gets long
+    // two-level walk over the chunk boundaries once the flat chain gets long
     int group = 1;
     if (chunked && b->Sp <= 64) {            // (the wide scan walks the flat chain)
         // a handful of recordings: the walk is exposed (nothing else to fill the GPU with), and groups of four cut its
         // dependent chain from K to K/4 + 4 + 4 steps (T = 10 000, one recording: 28 -> 19 us per iteration); many
         // recordings: the three launches of the two-level walk cost more than they save until the chain is long
+        // Group size: a composition step (S x S times S x S) costs about four walk steps, so the chain
+        // g (compose) + K/g (walk) + g (expand) is shortest near g = sqrt(K/5), not sqrt(K) -- measured on one
+        // recording, boundary walk per iteration: T = 200 000 (K = 1563): g = 8/12/16/20/24/32/40 -> 229/191/175/178/
+        // 185/216/253 us; T = 50 000 (K = 391): g = 8/12/16/24 -> 35/37/41/51 us.
+        const int g_auto = std::max(4, (int)std::lround(std::sqrt((double)maxchunks / 5.0)));
         if (b->scan_group >= 2) group = b->scan_group;
-        else if (b->scan_group == 0 && maxchunks >= b->two_level_from)
-            group = std::max(4, (int)std::lround(std::sqrt((double)maxchunks)));
-        else if (b->scan_group == 0 && b->n_rec <= 4 && maxchunks >= 32)
-            group = 4;
+        else if (b->scan_group == 0 && (maxchunks >= b->two_level_from || (b->n_rec <= 4 && maxchunks >= 32)))
+            group = g_auto;
     }
     if (group != b->sgroup || spt != b->spt || (group > 1 && !b->d_sop)) {
         for (void* p : {(void*)b->d_sop, (void*)b->d_sopexp, (void*)b->d_sup_rec, (void*)b->d_sup_idx}) ctx_free(b->ctx, p);

@@ -294,19 +294,24 @@ template <int W> __device__ __forceinline__ int group_max(int v) {
 
 // =======================================================================================
 // scan_compose: the operator of a group of `sgroup` consecutive chunks, P = F_(b-1) ... F_(a+1) F_a.
-// grid = nsup_total, block = 256.  thread = (column i of P, row group rg): RG = 256/SP threads share a
-// column, each keeps RPT = SP/RG of its entries in registers.  One product pushes every column of P through
-// the next chunk operator exactly like scan2 pushes a boundary vector (weights 2^E shifted by the largest
-// exponent on the column's support) but keeps the column's scale as an integer exponent:
-//     P'[:, i] = 2^(e_i + top_i) sum_j (P[j, i] 2^(E_j - top_i)) F[:, j],   renormalised to a sum in [0.5, 1).
-// F and the scaled copy of P (transposed: conflict-free) live in LDS; model: oracle/chunked_scan.py::compose.
+// grid = nsup_total, block = 256.  One product pushes every column of P through the next chunk operator exactly like
+// scan2 pushes a boundary vector (weights 2^E shifted by the largest exponent on the column's support) but keeps the
+// column's scale as an integer exponent:
+//     P'[:, i] = 2^(e_i + top_i) sum_j (P[j, i] 2^(E_j - top_i)) F[:, j],   renormalised to a sum in [0.5, 1),
+// i.e. P' = F W with W[j][i] = P[j, i] 2^(E_j - top_i): an S x S x S product on v_mfma 16x16x4.  Wave w < SP/16 owns the
+// columns [16w, 16w + 16) of P in the accumulator layout (a column is spread over the four 16-lane rows of the wave);
+// F (as fetched: column j contiguous) and W (row j contiguous) live in LDS and both fragments are conflict-free reads.
+// Round 2: the products were S^2 LDS reads per thread on the VALU before (7 us per product at SP = 64, the largest
+// part of the boundary walk of a long recording).  Model: oracle/chunked_scan.py::compose.
 // =======================================================================================
 template <typename R, int SP>
 __global__ __launch_bounds__(256) void scan_compose_kernel(BatchView<R> bt) {
+    using M = Mfma16<R>;
+    using acc_t = typename M::acc_t;
     using R4 = typename Vec<R>::v4;
-    constexpr int RG = 256 / SP, RPT = SP / RG;        // SP = 16 / 32 / 64: RG = 16 / 8 / 4, RPT = 1 / 4 / 16
+    constexpr int NT = SP / 16;                        // 16 x 16 tiles per dimension (SP = 16 / 32 / 64)
     constexpr int VPT = SP * SP / 4 / 256 > 0 ? SP * SP / 4 / 256 : 1;   // 16-byte vectors of an operator per thread
-    constexpr int kNoMass = -(1 << 24);
+    constexpr int kNoMass = -(1 << 24), kNever = -(1 << 28);
     __shared__ __attribute__((aligned(16))) R Fl[SP * SP];
     __shared__ __attribute__((aligned(16))) R Wt[SP * SP];
     __shared__ int eF[SP];
@@ -317,11 +322,18 @@ __global__ __launch_bounds__(256) void scan_compose_kernel(BatchView<R> bt) {
     const int G = bt.sgroup;
     const long long cb0 = (long long)rd.tile0 * bt.spt;
     const long long a = cb0 + (long long)bt.sup_idx[sup] * G, b = min(a + G, cb0 + chunk_count(rd, bt.spt));
-    const int tid = threadIdx.x, i = tid / RG, rg = tid % RG, r0 = rg * RPT;
-    R pv[RPT];
-    int eP = bt.opexp[(long long)a * SP + i];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l16 = lane & 15, g = lane >> 4;
+    const bool mul = wave < NT;                        // the waves that hold columns of P
+    const int i = (mul ? 16 * wave : 0) + l16;         // my column
+    R pv[NT][4];
+    int eP = kNoMass;
+    if (mul) {
+        eP = bt.opexp[(long long)a * SP + i];
 #pragma unroll
-    for (int rr = 0; rr < RPT; ++rr) pv[rr] = bt.op[((long long)a * SP + i) * SP + r0 + rr];
+        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pv[mt][r] = bt.op[((long long)a * SP + i) * SP + 16 * mt + M::row(lane, r)];
+    }
     R4 fr[VPT];
     int efr = 0;
     auto fetch = [&](long long k) {                        // chunk operator k: global -> registers
@@ -339,49 +351,71 @@ __global__ __launch_bounds__(256) void scan_compose_kernel(BatchView<R> bt) {
         if (tid < SP) eF[tid] = efr;
         __syncthreads();
         if (k + 1 < b) fetch(k + 1);                       // next operator in flight during this product
-        // weights of my column, shifted by the largest exponent on its support
-        int tj[RPT], top = -(1 << 28);
+        int top = kNever;
+        bool alive = false;
+        if (mul) {
+            // weights of my column, shifted by the largest exponent on its support
+            int tj[NT][4];
 #pragma unroll
-        for (int rr = 0; rr < RPT; ++rr) {
-            const int e = eF[r0 + rr];
-            tj[rr] = (pv[rr] > (R)0 && e > kNoMass / 2) ? e + exponent_of(pv[rr]) : -(1 << 28);
-            top = max(top, tj[rr]);
+            for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int e = eF[16 * mt + M::row(lane, r)];
+                    tj[mt][r] = (pv[mt][r] > (R)0 && e > kNoMass / 2) ? e + exponent_of(pv[mt][r]) : kNever;
+                    top = max(top, tj[mt][r]);
+                }
+            top = max(top, __shfl_xor(top, 16, 64));
+            top = max(top, __shfl_xor(top, 32, 64));
+            alive = top > -(1 << 27) && eP > kNoMass / 2;
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * mt + M::row(lane, r);
+                    Wt[row * SP + i] = (alive && tj[mt][r] > -(1 << 27)) ? scale2(pv[mt][r], eF[row] - top) : (R)0;
+                }
         }
-        top = group_max<RG>(top);
-        const bool alive = top > -(1 << 27) && eP > kNoMass / 2;
-#pragma unroll
-        for (int rr = 0; rr < RPT; ++rr)
-            Wt[(r0 + rr) * SP + i] = (alive && tj[rr] > -(1 << 27)) ? scale2(pv[rr], eF[r0 + rr] - top) : (R)0;
         __syncthreads();
-        R acc[RPT];
+        if (mul) {
+            acc_t acc[NT];
 #pragma unroll
-        for (int rr = 0; rr < RPT; ++rr) acc[rr] = 0;
+            for (int mt = 0; mt < NT; ++mt) acc[mt] = acc_t{0, 0, 0, 0};
 #pragma unroll 4
-        for (int j = 0; j < SP; ++j) {
-            const R w = Wt[j * SP + i];
+            for (int kk = 0; kk < SP / 4; ++kk) {
+                const R bv = Wt[(4 * kk + g) * SP + i];
 #pragma unroll
-            for (int rr = 0; rr < RPT; ++rr) acc[rr] += Fl[j * SP + r0 + rr] * w;
-        }
-        R sig = acc[0];
+                for (int mt = 0; mt < NT; ++mt) acc[mt] = M::mma(Fl[(4 * kk + g) * SP + 16 * mt + l16], bv, acc[mt]);
+            }
+            R sig = 0;
 #pragma unroll
-        for (int rr = 1; rr < RPT; ++rr) sig += acc[rr];
-        sig = column_sum<RG>(sig);
-        if (alive && sig > (R)0) {
-            const int e = rescale_exponent(sig);
+            for (int mt = 0; mt < NT; ++mt) sig += (acc[mt][0] + acc[mt][1]) + (acc[mt][2] + acc[mt][3]);
+            sig += __shfl_xor(sig, 16, 64);
+            sig += __shfl_xor(sig, 32, 64);
+            if (alive && sig > (R)0) {
+                const int e = rescale_exponent(sig);
 #pragma unroll
-            for (int rr = 0; rr < RPT; ++rr) pv[rr] = scale2(acc[rr], -e);
-            eP += top + e;
-        } else {
+                for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
-            for (int rr = 0; rr < RPT; ++rr) pv[rr] = 0;
-            eP = kNoMass;
+                    for (int r = 0; r < 4; ++r) pv[mt][r] = scale2(acc[mt][r], -e);
+                eP += top + e;
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pv[mt][r] = 0;
+                eP = kNoMass;
+            }
         }
         __syncthreads();                                   // Fl / Wt are rewritten by the next product
     }
-    R* __restrict__ dst = bt.sop + ((long long)sup * SP + i) * SP + r0;
+    if (mul) {
+        R* __restrict__ dst = bt.sop + ((long long)sup * SP + i) * SP;
 #pragma unroll
-    for (int rr = 0; rr < RPT; ++rr) dst[rr] = pv[rr];
-    if (rg == 0) bt.sopexp[(long long)sup * SP + i] = eP;
+        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[16 * mt + M::row(lane, r)] = pv[mt][r];
+        if (g == 0) bt.sopexp[(long long)sup * SP + i] = eP;
+    }
 }
 
 // =======================================================================================
