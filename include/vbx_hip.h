@@ -62,6 +62,9 @@ extern "C" {
 #define VBX_OPT_CHUNK_FRAMES 4  /* frames per scan chunk for VBX_FB_CHUNKED (0 = auto)         */
 #define VBX_OPT_SCAN_GROUP 6    /* chunks per group of the two-level boundary walk: 0 auto (sqrt(chunks / 5) once a
                                    recording has >= 160 chunks, or >= 32 in a batch of <= 4), 1 flat chain, >= 2 explicit */
+#define VBX_OPT_SPLIT_TILES 11  /* fused path: tiles re-run as two halves side by side (four 64-frame chains per tile instead of two
+                                   128-frame ones; chunk_loglik hands the half-tile operators over).  0 = auto (on), 1 = on,
+                                   2 = off; env VBX_AMD_SPLIT_TILES overrides                                             */
 #define VBX_OPT_STREAMS 10      /* HIP streams of a batch: its recordings are dealt to that many sub-batches, one
                                    iteration of each is launched stream after stream, so the latency-bound launches of
                                    one overlap the bandwidth-bound ones of the others.  0 = auto (3 from 24 recordings and

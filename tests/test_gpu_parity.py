@@ -592,15 +592,18 @@ def test_wide_speaker_counts_at_ten_thousand_frames(ctx, S):
     assert timing['fp32'][0] < timing['fp32'][1]            # the chunked scan beats the walk it replaces
 
 
+@pytest.mark.parametrize('split', [1, 2])
 @pytest.mark.parametrize('precision,tol', [('fp64', 2e-8), ('fp32', 2e-5)])
-def test_chunk_post_tile_shapes_against_the_oracle(ctx, precision, tol):
-    """chunk_post (half lattices that meet in the middle of the tile, gamma written by the replay instance) against
-    the oracle, for lengths of full tiles, tails shorter and longer than half a tile, 1, 2, 3, 63, 64, 65 and 127
-    frames (where the backward recursion of a short tile starts); S on both sides of the 16-state padding."""
+def test_chunk_post_tile_shapes_against_the_oracle(ctx, precision, tol, split):
+    """chunk_post (half lattices that meet in the middle, gamma written by the replay instance) against the oracle,
+    for lengths of full tiles, tails shorter and longer than half a tile, 1, 2, 3, 63, 64, 65, 66 and 127 frames
+    (where the backward recursion of a short tile starts, and where a tile gets a second half); S on both sides of
+    the 16-state padding and S = 50 (64 states: chunk_loglik builds the two half-tile operators one after the other).
+    split = 1: tiles re-run as two halves from the half-tile operators of chunk_loglik (the default); 2: as one."""
     from vbx_amd import _capi
     from vbx_amd.synth import make_recording
-    for S in (7, 16, 30):
-        Ts = [1024, 1000, 1100, 1, 64, 129, 2, 3, 63, 65, 127, 128, 191, 300]
+    for S in (7, 16, 30, 50):
+        Ts = [1024, 1000, 1100, 1, 64, 129, 2, 3, 63, 65, 66, 127, 128, 191, 300]
         recs = []
         for k, T in enumerate(Ts):
             X, Phi, _ = make_recording(T, S, seed=150 + k, kappa=0.05)
@@ -608,18 +611,25 @@ def test_chunk_post_tile_shapes_against_the_oracle(ctx, precision, tol):
             recs.append((X, Phi, g0 / g0.sum(1, keepdims=True)))
         batch = _capi.Batch(ctx, Ts, [S] * len(Ts), 128, precision=precision, max_iters=4)
         batch.set_option(_capi.OPT_FB_ALGO, _capi.FB_CHUNKED)
+        batch.set_option(_capi.OPT_SPLIT_TILES, split)
         for j, (X, Phi, g0) in enumerate(recs):
             batch.set_recording(j, X, Phi, np.ones(S) / S, g0, 0.95, 0.3, 17.0)
         batch.run(4, -np.inf)
+        worst = 0.0
         for j, (X, Phi, g0) in enumerate(recs):
             a = batch.result(j, want_model=True)
             gr, pr, Lr, ar, ir = _orc().VBx(X, Phi, loopProb=0.95, Fa=0.3, Fb=17.0, pi=S, gamma=g0, maxIters=4,
                                             epsilon=-1e300, return_model=True)
             key = (S, Ts[j])
-            assert np.abs(a['gamma'] - gr).max() <= tol, (key, np.abs(a['gamma'] - gr).max())
-            assert np.abs(a['pi'] - pr).max() <= tol and rel_err(a['Li'], [r[0] for r in Lr]) <= max(tol, 1e-10), key
-            assert np.abs(a['alpha'] - ar).max() <= tol * max(1.0, np.abs(ar).max()), key
+            # (fifty speakers four iterations into a random start: the EM map amplifies f32 rounding more than at 30,
+            #  with either re-run -- DESIGN section 9)
+            tol_s = tol if S <= 30 else 5 * tol
+            assert np.abs(a['gamma'] - gr).max() <= tol_s, (key, np.abs(a['gamma'] - gr).max())
+            assert np.abs(a['pi'] - pr).max() <= tol_s and rel_err(a['Li'], [r[0] for r in Lr]) <= max(tol, 1e-10), key
+            assert np.abs(a['alpha'] - ar).max() <= tol_s * max(1.0, np.abs(ar).max()), key
+            worst = max(worst, float(np.abs(a['gamma'] - gr).max()))
         batch.close()
+        print(f'S={S} {precision} split={split}: max |gamma - oracle| = {worst:.2e}')
 
 
 def test_converged_recordings_keep_their_results(ctx):

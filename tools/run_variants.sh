@@ -1,4 +1,4 @@
-python -m pytest tests/test_driver.py tests/test_gpu_ahc.py -q -x -m gpu 2>&1 | tail -3
-python tools/bench_driver.py --recordings 4 --xvectors 10000 --cpu-recordings 0 2>&1 | tail -1
-python tools/bench_driver.py --recordings 2 --xvectors 20000 --cpu-recordings 0 2>&1 | tail -1
-python tools/bench_driver.py --recordings 16 --xvectors 4000 --cpu-recordings 0 2>&1 | tail -1
+python -m pytest tests -q -x -m gpu 2>&1 | tail -5
+python bench.py 2>&1 | tail -1 > gpurun_out/r02_bench_split.json
+cat gpurun_out/r02_bench_split.json
+python tools/bench_call.py 2>&1 | tail -4

@@ -131,10 +131,12 @@ struct vbx_batch {
     bool recs_dirty = true;
     // options
     int fb_algo = VBX_FB_AUTO, check_every = 4, chunk_frames = 0, fuse = 2;
+    int split_tiles = 0;                          // option: 0 auto, 1 on, 2 off (VBX_OPT_SPLIT_TILES)
     int64_t profile = 0;                          // bit k: bracket launches of kernel class k with HIP events
     bool mpart_valid = false;                     // mpart/npart hold gamma^T rho of the current gamma (fused path)
     bool gamma_stale = false;                     // fused iterations have run since gamma was last written (run_end replays)
     bool fused_now = false;                       // in effect for the launches being issued: the fused per-chunk kernels
+    bool half_ops_now = false;                    // ... and chunk_loglik builds the half-tile operators chunk_post splits its re-run with
     void* d_gamma0 = nullptr;
     double* d_pi_prev = nullptr;
     // device memory
@@ -152,6 +154,8 @@ struct vbx_batch {
     // chunked scan
     void *d_op = nullptr, *d_fbound = nullptr, *d_gbound = nullptr;
     int* d_opexp = nullptr;
+    void* d_oph = nullptr;                        // half-tile operators of the fused path (chunk_loglik -> chunk_post)
+    int* d_ophexp = nullptr;
     double* d_tllpart = nullptr;
     void* d_sfw = nullptr;
     void* d_dump = nullptr;
@@ -185,6 +189,7 @@ struct vbx_batch {
         v.bias = (R*)d_bias; v.emodel = d_emodel; v.pi = d_pi; v.mpart = (R*)d_mpart;
         v.npart = (R*)d_npart; v.epart = d_epart; v.Li = d_Li; v.epsilon = epsilon;
         v.ip = d_ip ? d_ip : d_pi; v.fw_scale = (R*)d_fw_scale; v.bw_scale = (R*)d_bw_scale;
+        v.oph = fused_now && half_ops_now ? (R*)d_oph : nullptr; v.ophexp = d_ophexp;
         v.op = (R*)d_op; v.opexp = d_opexp; v.fbound = (R*)d_fbound; v.gbound = (R*)d_gbound;
         v.tllpart = use_chunked ? d_tllpart : nullptr; v.sfw = (R*)d_sfw; v.dump = (R*)d_dump;
         v.sop = (R*)d_sop; v.sopexp = d_sopexp; v.sup_rec = d_sup_rec; v.sup_idx = d_sup_idx;
@@ -385,6 +390,10 @@ template <typename R> void launch_iteration(vbx_batch* b, double eps) {
         if (!b->mpart_valid) launch_mstep_acc<R>(b, eps);
         launch_mstep_fin<R>(b, eps);
         const bool fl = fused_loglik_available<R>(b);
+        // half-tile re-runs: most where the chains' latency is exposed (one recording 65 -> 58 us per iteration, fp64
+        // batches -13 %), a few percent with thousands of f32 tiles in flight (there the operator build is
+        // VALU-throughput bound and chunk_loglik pays 5 % for what chunk_post gains) -- never a loss, so on unless asked
+        b->half_ops_now = fl && b->split_tiles != 2;
         if (!fl) launch_loglik<R>(b, eps, false);
         launch_fb<R>(b, eps, true, fl);
         launch_iter_fin<R>(b, eps);
@@ -480,6 +489,12 @@ int choose_fb_algo(vbx_batch* b, bool step_api_logs) {
     const int spt = 1;
     // the forward / backward lattices live in HBM only on the paths that do not keep them in LDS
     const bool fused1 = b->precision == VBX_PREC_FP64 ? fused_available<double>(b) : fused_available<float>(b);
+    if (fused1 && chunked && !b->d_oph) {
+        const size_t nt = (size_t)b->ntiles_total, sp = (size_t)b->Sp;
+        int rc = dmalloc_bytes(b->ctx, &b->d_oph, 2 * nt * sp * sp * b->rsize);
+        if (rc == VBX_OK) rc = dmalloc(b->ctx, &b->d_ophexp, 2 * nt * sp);
+        if (rc != VBX_OK) return rc;
+    }
     if (!fused1 && !b->d_ahat) {
         const size_t cells = (size_t)b->sum_T * b->Sp;
         int rc = dmalloc_bytes(b->ctx, &b->d_ahat, cells * b->rsize);
@@ -636,7 +651,7 @@ static int leaf_destroy(vbx_batch* b) {
                     b->d_bias, b->d_mpart, b->d_npart, b->d_lraw, b->d_emodel, b->d_pi, b->d_epart, b->d_Li,
                     b->d_xstage, b->d_ip, b->d_fw_scale, b->d_bw_scale, b->d_op, b->d_fbound, b->d_gbound,
                     b->d_opexp, b->d_tllpart, b->d_sfw, b->d_dump, b->d_sop, b->d_sopexp, b->d_sup_rec, b->d_sup_idx,
-                    b->d_gamma0, b->d_pi_prev};
+                    b->d_gamma0, b->d_pi_prev, b->d_oph, b->d_ophexp};
     (void)hipStreamSynchronize(b->ctx->stream);               // nothing of this batch may still be running when its
     for (void* p : ptrs) ctx_free(b->ctx, p);                 // blocks go back to the spare list
     if (b->ev_start) (void)hipEventDestroy(b->ev_start);
@@ -779,6 +794,10 @@ static int leaf_set_option(vbx_batch* b, int option, int64_t value) {
             if (value < 0 || value > 2) FAIL(b->ctx, VBX_ERR_INVALID, "fuse must be 0, 1 or 2");
             b->fuse = (int)value;
             b->mpart_valid = false;
+            return VBX_OK;
+        case VBX_OPT_SPLIT_TILES:
+            if (value < 0 || value > 2) FAIL(b->ctx, VBX_ERR_INVALID, "split_tiles must be 0 (auto), 1 (on) or 2 (off)");
+            b->split_tiles = (int)value;
             return VBX_OK;
         case VBX_OPT_TWO_LEVEL_FROM:
             if (value < 2) FAIL(b->ctx, VBX_ERR_INVALID, "two-level threshold must be >= 2 chunks");

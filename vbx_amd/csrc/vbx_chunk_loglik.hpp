@@ -151,18 +151,116 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)si
     __syncthreads();
     VBX_STAMP();
 
-    // ---- phase 2: the chunk's transfer operator, one column per group of PH lanes (vbx_operator.hpp) ------------------
+    // ---- phase 2: transfer operators, one column per group of PH lanes (vbx_operator.hpp) ------------------------------
+    // The tile is cut at frame kTileFrames / 2: P1 (frames before the cut) and P2 (frames from the cut on) are built
+    // side by side by two sets of waves where 2 SP PH <= 256 (one after the other at SP = 64), so the dependent chain
+    // of a column is 64 frames long, and handed to chunk_post (`oph`), which re-runs the two halves of the tile at
+    // the same time: it gets the vectors at the cut from one product with P1 / P2^T each.  The boundary walk
+    // (scan2) keeps working on whole tiles: P = P2 P1 is composed here on v_mfma 16x16x4, exactly as
+    // scan_compose_kernel multiplies chunk operators (weights 2^E shifted by the largest exponent on a column's
+    // support, the column's scale kept as an integer exponent).
     {
-        constexpr int NOPT = SP * PH;                      // threads that build the operator
-        if (tid < NOPT) {
-            const int col = tid / PH, part = tid % PH, j0 = part * NR;
-            R x[NR];
-            int expo;
-            operator_column<R, SP, PH>(btile, 0, len, t0 == 0, col, part, rd.lp, bt.pi + (long long)rec * SP, rd.S, x, expo);
-            R* __restrict__ dst = bt.op + ((long long)tile * SP + col) * SP + j0;
+        constexpr int NOPT = SP * PH;                      // threads that build one operator
+        constexpr int H = kTileFrames / 2;
+        constexpr bool kSideBySide = 2 * NOPT <= 256;
+        constexpr int kNoMass = -(1 << 24), kNever = -(1 << 28);
+        __shared__ int eF[SP], eW[SP];
+        const bool split = bt.oph != nullptr;              // (uniform) off: one operator over the whole tile, as scan1 builds it
+        const bool two = split && len > H;                 // (uniform) the tile has a second half
+        const int my_half = kSideBySide ? tid / NOPT : 0;
+        const int otid = kSideBySide ? tid % NOPT : tid;
+        const int col = otid / PH, part = otid % PH, j0 = part * NR;
+        const bool builder = kSideBySide ? tid < 2 * NOPT : tid < NOPT;
+        R x[2][NR];                                        // [0]: my operator (side by side) or P1; [1]: P2 (SP = 64)
+        int expo[2] = {kNoMass, kNoMass};
+        const double* pi_rec = bt.pi + (long long)rec * SP;
+        auto build = [&](int half, R (&xo)[NR], int& eo) {
+            const int lo = half * H, hi = (half == 0 && split) ? min(len, H) : len;
+            operator_column<R, SP, PH>(btile, lo, hi, t0 + lo == 0, col, part, rd.lp, pi_rec, rd.S, xo, eo);
+            if (bt.oph) {
+                R* __restrict__ dst = bt.oph + (((long long)tile * 2 + half) * SP + col) * SP + j0;
 #pragma unroll
-            for (int r = 0; r < NR; ++r) dst[r] = x[r];
-            if (part == 0) bt.opexp[(long long)tile * SP + col] = expo;
+                for (int r = 0; r < NR; ++r) dst[r] = xo[r];
+                if (part == 0) bt.ophexp[((long long)tile * 2 + half) * SP + col] = eo;
+            }
+        };
+        if (builder) {
+            if (kSideBySide) {
+                if (my_half == 0 || two) build(my_half, x[0], expo[0]);
+            } else {
+                build(0, x[0], expo[0]);
+                if (two) build(1, x[1], expo[1]);
+            }
+        }
+        if (!two) {                                        // P = P1
+            if (builder && my_half == 0) {
+                R* __restrict__ dst = bt.op + ((long long)tile * SP + col) * SP + j0;
+#pragma unroll
+                for (int r = 0; r < NR; ++r) dst[r] = x[0][r];
+                if (part == 0) bt.opexp[(long long)tile * SP + col] = expo[0];
+            }
+        } else {
+            // P = P2 P1.  F = P2 as built (column j contiguous) and W[j][i] = P1[j, i] 2^(E2_j - top_i) go through the
+            // LDS region b has left; wave w < SP/16 multiplies the columns [16w, 16w + 16).
+            using M = Mfma16<R>;
+            R* const Fl = lds;
+            R* const Wt = lds + SP * SP;
+            __syncthreads();                               // every column is built: b is dead
+            const bool holds_p2 = builder && (kSideBySide ? my_half == 1 : true);
+            const bool holds_p1 = builder && my_half == 0;
+            if (holds_p2) {
+                const R (&x2)[NR] = x[kSideBySide ? 0 : 1];
+#pragma unroll
+                for (int r = 0; r < NR; ++r) Fl[col * SP + j0 + r] = x2[r];
+                if (part == 0) eF[col] = expo[kSideBySide ? 0 : 1];
+            }
+            __syncthreads();
+            if (holds_p1) {
+                int tj[NR], top = kNever;
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const int e = eF[j0 + r];
+                    tj[r] = (x[0][r] > (R)0 && e > kNoMass / 2) ? e + exponent_of(x[0][r]) : kNever;
+                    top = max(top, tj[r]);
+                }
+                if (PH >= 2) top = max(top, dpp_mov<0xB1>(top));
+                if (PH >= 4) top = max(top, dpp_mov<0x4E>(top));
+                if (PH >= 8) top = max(top, dpp_mov<0x141>(top));
+                if (PH >= 16) top = max(top, dpp_mov<0x140>(top));
+                const bool alive = top > -(1 << 27) && expo[0] > kNoMass / 2;
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+                    Wt[(j0 + r) * SP + col] = (alive && tj[r] > -(1 << 27)) ? scale2(x[0][r], eF[j0 + r] - top) : (R)0;
+                if (part == 0) eW[col] = alive ? expo[0] + top : kNoMass;
+            }
+            __syncthreads();
+            if (wave < NT) {
+                using acc_t = typename M::acc_t;
+                const int ci = 16 * wave + i;              // my column of P (i = lane & 15, g = lane >> 4)
+                acc_t acc[NT];
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt) acc[mt] = acc_t{0, 0, 0, 0};
+#pragma unroll 4
+                for (int kk = 0; kk < SP / 4; ++kk) {
+                    const R bv = Wt[(4 * kk + g) * SP + ci];
+#pragma unroll
+                    for (int mt = 0; mt < NT; ++mt) acc[mt] = M::mma(Fl[(4 * kk + g) * SP + 16 * mt + i], bv, acc[mt]);
+                }
+                R sig = 0;
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt) sig += (acc[mt][0] + acc[mt][1]) + (acc[mt][2] + acc[mt][3]);
+                sig += __shfl_xor(sig, 16, 64);
+                sig += __shfl_xor(sig, 32, 64);
+                const int ew = eW[ci];
+                const bool ok = ew > kNoMass / 2 && sig > (R)0;
+                const int e = ok ? rescale_exponent(sig) : 0;
+                R* __restrict__ dst = bt.op + ((long long)tile * SP + ci) * SP;
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[16 * mt + M::row(lane, r)] = ok ? scale2(acc[mt][r], -e) : (R)0;
+                if (g == 0) bt.opexp[(long long)tile * SP + ci] = ok ? ew + e : kNoMass;
+            }
         }
     }
     VBX_STAMP();

@@ -4,14 +4,17 @@
 // One workgroup = one chunk (tile of kTileFrames frames):
 //
 //   stage    b of the tile -> LDS region `bl`
-//   re-run   wave 0 forward, wave 1 backward over the tile, unnormalised vectors rescaled by powers of two every
-//            four frames; the two meet in the middle: each direction stores only the half of its lattice that the
-//            OTHER has not produced yet in region `hl`, and everything after the midpoint overwrites rows of b that
-//            both directions have consumed:
-//                rows [0, mid)   : a_f -> hl[f]            (forward, before the midpoint barrier)
-//                                  x_f -> bl[f]            (backward, after the barrier)
-//                rows [mid, len) : x_f -> hl[HALF + f-mid] (backward, before the barrier)
-//                                  a_f -> bl[f]            (forward, after the barrier)
+//   re-run   the tile is cut at frame H = kTileFrames / 2 and each half [lo, hi) is walked by two waves, one
+//            forward from a_(lo-1), one backward from x_(hi-1): unnormalised vectors rescaled by powers of two every
+//            four frames.  The outer vectors are the boundary vectors of the walk (scan2); the ones at the cut are one
+//            product each with the half-tile operators chunk_loglik has left in `oph`:
+//                a_(H-1) = P1 a_in        x_(H-1) = P2^T x_(len-1)
+//            (64 dependent steps per chain instead of 128; a tile of at most H frames, or a batch without `oph`, is one
+//            half walked by waves 0 and 1).  The two chains of a half meet in its middle m: each stores only what the
+//            OTHER has not produced yet in region `r1`, and everything after the crossing overwrites rows of b that
+//            both have consumed:
+//                rows [lo, m) : a_f -> r1[f]  (forward, before the barrier)    x_f -> bl[f]  (backward, after it)
+//                rows [m, hi) : x_f -> r1[f]  (backward, before the barrier)   a_f -> bl[f]  (forward, after it)
 //   post     gamma ~ a x, "entered" statistic, log-likelihood share; gamma -> bl (A operand of the accumulation)
 //   MFMA     C[s][d] = sum_t gamma[t][s] rho[t][d] on v_mfma 16x16x4, rho fetched a quarter of the chunk ahead.
 //
@@ -65,15 +68,15 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
     using R4 = typename Vec<R>::v4;
     constexpr int NREG = SP / 16;                      // states per lane in the re-run
     constexpr int NT = SP / 16;                        // M-tiles (speakers) of the accumulation
-    constexpr int HALF = kTileFrames / 2;
     constexpr int KS = kTileFrames / 4;                // MFMA k-steps per chunk
     constexpr int LAT = kTileFrames * SP;
     constexpr int NST = (LAT / 4 + 255) / 256;         // 16/32-byte vectors of a b tile per thread
     __shared__ __attribute__((aligned(16))) R region[2][LAT];
     __shared__ R sfl[kTileFrames];                     // s_f = sum(a_f) of the stored forward row
     __shared__ R qfl[kTileFrames];                     // q_f: every element of the stored backward row is >= q_f > 0
-    __shared__ R tl_sig[2];
-    __shared__ int tl_expo;
+    __shared__ R tl_sig[2][2];                         // per forward chain: its final and its initial vector sum
+    __shared__ int tl_expo[2];
+    __shared__ __attribute__((aligned(16))) R mv_w[2][SP];   // operands of the two products at the cut
     __shared__ __attribute__((aligned(16))) R c_l[SP];
     __shared__ __attribute__((aligned(16))) R aprev0[SP];
     __shared__ double ent_w[4][SP];
@@ -91,15 +94,58 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
         const int4 td = bt.tile_desc[tile];            // {recording, t0, frames, first row}
         const int rec = td.x, t0 = td.y, len = td.z;
         const long long trow = td.w;
-        const int mid = len / 2;
+        constexpr int H = kTileFrames / 2;
+        constexpr int kNoMass = -(1 << 24), kNever = -(1 << 28);
+        // roles: wave 0 forward / wave 3 backward over the first half, wave 2 forward / wave 1 backward over the second
+        const bool split = bt.oph != nullptr && len > H;   // (uniform)
+        const int half = (split && (wave == 1 || wave == 2)) ? 1 : 0;
+        const bool is_fwd = wave == 0 || (split && wave == 2), is_bwd = wave == 1 || (split && wave == 3);
+        const int lo = half * H, hi = split && half == 0 ? H : len;
+        const int m0 = split ? H / 2 : len / 2, m1 = H + (len - H) / 2;      // where the chains of a half cross
+        const int m = half ? m1 : m0;
+        auto low_part = [&](int f) { return split && f >= H ? f < m1 : f < m0; };   // a_f in r1 and x_f in bl?
         const double lp_d = bt.recs[rec].lp;
         const int n_spk = bt.recs[rec].S;
         const R lp = (R)lp_d;
         const R* __restrict__ rho = bt.rho + (trow - t0) * Dp;
-        R* const bl = region[0];                       // b, then a (rows >= mid) / x (rows < mid), then gamma
-        R* const afh = region[1];                      // a_f,  f < mid
-        R* const bfh = region[1] + HALF * SP;          // x_f,  f >= mid  (row f - mid)
+        R* const bl = region[0];                       // b, then a (rows >= m) / x (rows < m), then gamma
+        R* const r1 = region[1];                       // a_f below the crossing of its half, x_f from it on
         VBX_STAMP();
+        // everything a re-run wave needs from HBM is requested before the b tile, so that it is there when the tile is:
+        // the boundary vector and, for the waves that start at the cut, their quarter of the operator (the four 16-lane
+        // rows of a wave split the sum of the product)
+        constexpr int QS = SP / 4;                         // columns (forward) / rows (backward) per 16-lane row
+        R bnd_v[NREG], opf[QS][NREG], opb[NREG][QS];
+        int ope[NREG];
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) {
+            bnd_v[r] = 0;
+            ope[r] = 0;
+        }
+        if (is_fwd || is_bwd) {
+            const R* __restrict__ bnd = (is_fwd ? bt.fbound : bt.gbound) + (long long)tile * SP + so;
+            load_pack<NREG>(bnd_v, bnd);
+        }
+        if (split && wave >= 2) {
+            const long long o = (long long)tile * 2 + (wave == 2 ? 0 : 1);      // P1 for wave 2, P2 for wave 3
+            const R* __restrict__ op = bt.oph + o * SP * SP;
+            if (wave == 2) {
+#pragma unroll
+                for (int ii = 0; ii < QS; ++ii) load_pack<NREG>(opf[ii], op + (g4 * QS + ii) * SP + so);
+            } else {
+#pragma unroll
+                for (int r = 0; r < NREG; ++r)
+#pragma unroll
+                    for (int q4 = 0; q4 < QS / 4; ++q4) {
+                        R t4[4];
+                        load_pack<4>(t4, op + (so + r) * SP + g4 * QS + 4 * q4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) opb[r][4 * q4 + e] = t4[e];
+                    }
+            }
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) ope[r] = bt.ophexp[o * SP + so + r];
+        }
         stage_to_lds<NST>(reinterpret_cast<R4*>(bl), reinterpret_cast<const R4*>(bt.bmat + trow * SP), len * SP / 4, tid, 256);
         if (tid < SP) {
             const double pj = (REPLAY ? bt.pi_prev : bt.pi)[(long long)rec * SP + tid];
@@ -125,7 +171,7 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
         };
         // forward state
         R a[NREG], sig = 1, sig_in = 1;
-        int expo = 0, ff = 0;
+        int expo = 0, ff = lo;
         auto f_renorm = [&]() {
             const int e = rescale_exponent(sig);
             expo += e;
@@ -133,7 +179,7 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
 #pragma unroll
             for (int r = 0; r < NREG; ++r) a[r] = scale2(a[r], -e);
         };
-        auto f_store = [&](int f) { store_pack<NREG>((f < mid ? afh + f * SP : bl + f * SP) + so, a); sfl[f] = sig; };
+        auto f_store = [&](int f) { store_pack<NREG>((f < m ? r1 : bl) + f * SP + so, a); sfl[f] = sig; };
         auto f_step = [&](const R (&b)[NREG], int f) {
 #pragma unroll
             for (int r = 0; r < NREG; ++r) a[r] = b[r] * (lp * a[r] + c[r] * sig);
@@ -165,8 +211,8 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
         };
         // backward state: x = x_{fb} (unnormalised), produced by consuming rows > fb
         R x[NREG], q = 1;
-        int fb = len - 1;
-        auto b_store = [&](int f) { store_pack<NREG>((f < mid ? bl + f * SP : bfh + (f - mid) * SP) + so, x); qfl[f] = q; };
+        int fb = hi - 1;
+        auto b_store = [&](int f) { store_pack<NREG>((f < m ? bl : r1) + f * SP + so, x); qfl[f] = q; };
         auto b_step = [&](const R (&b)[NREG], bool store) {      // consumes row fb, produces x_{fb-1}
             R u[NREG];
 #pragma unroll
@@ -182,54 +228,108 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
         };
         auto b_renorm = [&]() {
             const int e = rescale_exponent(q);
-            q = scale2(q, -e);                                   // (x_{mid-1} and its q wait in registers for the barrier)
+            q = scale2(q, -e);                                   // (x_{m-1} and its q wait in registers for the barrier)
 #pragma unroll
             for (int r = 0; r < NREG; ++r) x[r] = scale2(x[r], -e);
         };
 
-        if (wave == 0) {
-            const R* __restrict__ bnd = bt.fbound + (long long)tile * SP + so;
+        if (is_fwd) {
+            if (half == 0) {
 #pragma unroll
-            for (int r = 0; r < NREG; ++r) {
-                a[r] = bnd[r];
-                if (!chunk0) aprev0[so + r] = a[r];              // a[t0-1] (any scale) for the statistics of frame t0
-                if (chunk0) a[r] *= bl[so + r];                  // frame 0: a_0 = b_0 (ip + 1e-8), VBx.py:163
+                for (int r = 0; r < NREG; ++r) {
+                    a[r] = bnd_v[r];
+                    if (!chunk0) aprev0[so + r] = a[r];          // a[t0-1] (any scale) for the statistics of frame t0
+                    if (chunk0) a[r] *= bl[so + r];              // frame 0: a_0 = b_0 (ip + 1e-8), VBx.py:163
+                }
+            } else {
+                // a_(H-1) = P1 a_in = sum_i (y_i 2^(E_i)) col_i, weights shifted by the largest exponent on the support of
+                // y (as scan2 pushes a boundary vector through a chunk operator); row g4 of the wave sums its QS columns
+                int tj[NREG], top = kNever;
+#pragma unroll
+                for (int r = 0; r < NREG; ++r) {
+                    tj[r] = (bnd_v[r] > (R)0 && ope[r] > kNoMass / 2) ? ope[r] + exponent_of(bnd_v[r]) : kNever;
+                    top = max(top, tj[r]);
+                }
+                top = allreduce_max<16>(top);
+                R w[NREG];
+#pragma unroll
+                for (int r = 0; r < NREG; ++r) w[r] = tj[r] > -(1 << 27) ? scale2(bnd_v[r], ope[r] - top) : (R)0;
+                if (g4 == 0) store_pack<NREG>(mv_w[0] + so, w);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int r = 0; r < NREG; ++r) a[r] = 0;
+#pragma unroll
+                for (int ii = 0; ii < QS; ++ii) {
+                    const R wi = mv_w[0][g4 * QS + ii];
+#pragma unroll
+                    for (int r = 0; r < NREG; ++r) a[r] += wi * opf[ii][r];
+                }
+#pragma unroll
+                for (int r = 0; r < NREG; ++r) {
+                    a[r] += __shfl_xor(a[r], 16, 64);
+                    a[r] += __shfl_xor(a[r], 32, 64);
+                    if (so + r >= n_spk) a[r] = 0;               // padded speakers carry no mass
+                }
             }
             sig = a[0];
 #pragma unroll
             for (int r = 1; r < NREG; ++r) sig += a[r];
             sig = allreduce_sum<16>(sig);
             sig_in = sig;
-            if (chunk0) {
+            if (chunk0 && half == 0) {
                 f_store(0);                                      // (row 0 of bl if len == 1: b_0 is not needed again)
                 ff = 1;
             }
-            f_run(max(mid, ff));                                 // rows < mid -> afh
-        } else if (wave == 1) {
-            const R* __restrict__ bnd = bt.gbound + (long long)tile * SP + so;
+            f_run(max(m, ff));                                   // rows < m -> r1
+        } else if (is_bwd) {
+            if (half == 1 || !split) {
+#pragma unroll
+                for (int r = 0; r < NREG; ++r) x[r] = bnd_v[r];
+            } else {
+                // x_(H-1) = P2^T x_(len-1):  (F^T g)_j = 2^(E_j) <col_j, g>, outputs rescaled by the largest exponent
+                if (g4 == 0) store_pack<NREG>(mv_w[1] + so, bnd_v);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                int tj[NREG], top = kNever;
+#pragma unroll
+                for (int r = 0; r < NREG; ++r) {
+                    R tot = 0;
+#pragma unroll
+                    for (int ii = 0; ii < QS; ++ii) tot += opb[r][ii] * mv_w[1][g4 * QS + ii];
+                    tot += __shfl_xor(tot, 16, 64);
+                    tot += __shfl_xor(tot, 32, 64);
+                    x[r] = tot;
+                    tj[r] = (tot > (R)0 && ope[r] > kNoMass / 2) ? ope[r] + exponent_of(tot) : kNever;
+                    top = max(top, tj[r]);
+                }
+                top = allreduce_max<16>(top);
+#pragma unroll
+                for (int r = 0; r < NREG; ++r)
+                    x[r] = (tj[r] > -(1 << 27) && so + r < n_spk) ? scale2(x[r], ope[r] - top) : (R)0;
+            }
             R part = 0;
 #pragma unroll
-            for (int r = 0; r < NREG; ++r) {
-                x[r] = bnd[r];
-                part += x[r];
-            }
+            for (int r = 0; r < NREG; ++r) part += x[r];
             part = allreduce_sum<16>(part);
             const int e = rescale_exponent(part);
 #pragma unroll
             for (int r = 0; r < NREG; ++r) x[r] = scale2(x[r], -e);
             q = scale2(part, -e) * (R)(1.0 / SP);                // a positive scale of the row, like q of the steps
-            b_store(len - 1);                                    // -> bfh (len-1 >= mid always)
-            // consume rows len-1 .. max(mid, 1); the outputs with index >= mid go to bfh, the last one (x_{mid-1})
-            // stays in registers until the barrier: its slot in bl still holds b_{mid-1}, which the forward wave
+            b_store(hi - 1);                                     // -> r1 (hi-1 >= m always)
+            // consume rows hi-1 .. max(m, lo+1); the outputs with index >= m go to r1, the last one (x_{m-1})
+            // stays in registers until the barrier: its slot in bl still holds b_{m-1}, which the forward wave
             // may not have consumed yet
-            const int stop = max(mid, 1);
+            const int stop = max(m, lo + 1);
             R cu[4][NREG], nx[4][NREG];
             if (fb - 3 >= stop) load_rows(cu, fb, -1);
             while (fb - 3 >= stop) {                             // a block of four rows fb .. fb-3, all >= stop
                 const bool last_block = fb - 4 < stop;           // its last output is x_{stop-1}
                 if (fb - 7 >= stop) load_rows(nx, fb - 4, -1);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) b_step(cu[k], !(last_block && k == 3) || stop - 1 >= mid);
+                for (int k = 0; k < 4; ++k) b_step(cu[k], !(last_block && k == 3) || stop - 1 >= m);
                 b_renorm();
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
@@ -239,36 +339,36 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
             while (fb >= stop) {
                 R b[NREG];
                 load_pack<NREG>(b, bl + fb * SP + so);
-                b_step(b, fb - 1 >= mid);
+                b_step(b, fb - 1 >= m);
             }
         }
         VBX_STAMP();
-        __syncthreads();                                         // midpoint: rows >= mid of b are consumed by the backward
-                                                                 // wave, rows < mid by the forward wave
-        if (wave == 0) {
-            f_run(len);                                          // rows >= mid -> bl (over b_f, after reading it)
+        __syncthreads();                                         // crossing: rows >= m of each half are consumed by its
+                                                                 // backward wave, rows < m by its forward wave
+        if (is_fwd) {
+            f_run(hi);                                           // rows >= m -> bl (over b_f, after reading it)
             if (lane == 0) {
-                tl_sig[0] = sig;
-                tl_sig[1] = chunk0 ? (R)1 : sig_in;
-                tl_expo = expo;
+                tl_sig[half][0] = sig;
+                tl_sig[half][1] = (chunk0 && half == 0) ? (R)1 : sig_in;
+                tl_expo[half] = expo;
             }
-        } else if (wave == 1 && mid >= 1) {
-            // x = x_{mid-1} is in registers, rows mid-1 .. 1 remain.  Every output x_{f-1} lands on b_{f-1}, the row
+        } else if (is_bwd && m > lo) {
+            // x = x_{m-1} is in registers, rows m-1 .. lo+1 remain.  Every output x_{f-1} lands on b_{f-1}, the row
             // the NEXT step consumes, so rows are always in registers before their slot is written: up to three
             // leading single rows and the first block of four are fetched before the first store.
-            const int n = fb, tail = n & 3;                      // fb == mid - 1
+            const int n = fb - lo, tail = n & 3;                 // fb == m - 1
             R lead[3][NREG], cu[4][NREG], nx[4][NREG];
 #pragma unroll
             for (int k = 0; k < 3; ++k)
                 if (k < tail) load_pack<NREG>(lead[k], bl + (fb - k) * SP + so);
             if (n - tail >= 4) load_rows(cu, fb - tail, -1);
-            b_store(fb);                                         // x_{mid-1} -> bl[mid-1]
+            b_store(fb);                                         // x_{m-1} -> bl[m-1]
 #pragma unroll
             for (int k = 0; k < 3; ++k)
                 if (k < tail) b_step(lead[k], true);
             if (tail) b_renorm();
-            while (fb >= 4) {                                    // blocks of four rows fb .. fb-3 (fb is a multiple of 4 here)
-                if (fb - 4 >= 4) load_rows(nx, fb - 4, -1);
+            while (fb - lo >= 4) {                               // blocks of four rows fb .. fb-3 (fb - lo is a multiple of 4 here)
+                if (fb - lo - 4 >= 4) load_rows(nx, fb - 4, -1);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) b_step(cu[k], true);
                 b_renorm();
@@ -310,11 +410,12 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
                 const bool ok = f < len;
                 const int fr = ok ? f : 0;
                 const R isig = fast_rcp(sfl[fr]), iq = fast_rcp(qfl[fr]);   // (applied one after the other: their product may overflow)
-                const R sp = fr > 0 ? sfl[fr - 1] : tl_sig[1];
+                const R sp = fr > 0 ? sfl[fr - 1] : tl_sig[0][1];
                 R av[NREG], xv[NREG], ap[NREG];
-                load_pack<NREG>(av, (fr < mid ? afh + fr * SP : bl + fr * SP) + so);
-                load_pack<NREG>(xv, (fr < mid ? bl + fr * SP : bfh + (fr - mid) * SP) + so);
-                if (!REPLAY) load_pack<NREG>(ap, (fr == 0 ? aprev0 : fr - 1 < mid ? afh + (fr - 1) * SP : bl + (fr - 1) * SP) + so);
+                const bool lowf = low_part(fr);
+                load_pack<NREG>(av, (lowf ? r1 : bl) + fr * SP + so);
+                load_pack<NREG>(xv, (lowf ? bl : r1) + fr * SP + so);
+                if (!REPLAY) load_pack<NREG>(ap, (fr == 0 ? aprev0 : (low_part(fr - 1) ? r1 : bl) + (fr - 1) * SP) + so);
 #pragma unroll
                 for (int r = 0; r < NREG; ++r) gam[it][r] = (av[r] * isig) * (xv[r] * iq);
                 R sum = gam[it][0];
@@ -351,8 +452,10 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
             }
             double mpartial = 0.0;                             // this chunk's share of the total log-likelihood (VBx.py:173)
             if (tid < len) mpartial = (double)bt.mrow[trow + tid];
-            if (tid == 128)
-                mpartial += log((double)tl_sig[0]) - log((double)tl_sig[1]) + (double)tl_expo * 0.69314718055994530942;
+            if (tid == 128 || (tid == 129 && split)) {         // one term per forward chain
+                const int h = tid - 128;
+                mpartial += log((double)tl_sig[h][0]) - log((double)tl_sig[h][1]) + (double)tl_expo[h] * 0.69314718055994530942;
+            }
             mpartial = block_sum(mpartial, red);               // (its barriers also end pass 1)
             if (tid < SP) {
                 const double e = (ent_w[0][tid] + ent_w[1][tid]) + (ent_w[2][tid] + ent_w[3][tid]);

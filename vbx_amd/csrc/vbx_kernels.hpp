@@ -72,6 +72,9 @@ template <typename R> struct BatchView {
     // chunked scan (VBX_FB_CHUNKED): one chunk = one tile of kTileFrames frames
     R* op;                 // [ntiles_total][Sp][Sp]  forward transfer-operator columns (backward = transpose)
     int* opexp;            // [ntiles_total][Sp]      power-of-two exponent of every column
+    R* oph;                // [ntiles_total][2][Sp][Sp] or null: the operators of the two halves of a tile (fused path:
+                           //                     chunk_loglik -> chunk_post, which re-runs the halves side by side)
+    int* ophexp;           // [ntiles_total][2][Sp]
     R* fbound;             // [ntiles_total][Sp]  forward vector entering the chunk (ahat[t0-1], any scale)
     R* gbound;             // [ntiles_total][Sp]  backward vector at the chunk's last frame (any scale)
     double* tllpart;       // [ntiles_total] or null: sum over the chunk of log s_t + m_t
