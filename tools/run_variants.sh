@@ -1,2 +1,5 @@
-python bench.py 2>&1 | tail -1 > gpurun_out/r02_bench_split.json
-python bench.py --gpus 1 --steps 20 --warmup 5 2>&1 | tail -1 > gpurun_out/r02_bench_split_driver_args.json
+python -m pytest tests/test_driver.py tests/test_gpu_ahc.py tests/test_drop_in_launcher.py -q -x -m gpu 2>&1 | tail -2
+python tools/bench_driver.py --recordings 64 --xvectors 1025 2>&1 | tail -1
+python tools/bench_driver.py --recordings 16 --xvectors 4000 --cpu-recordings 0 2>&1 | tail -1
+python tools/bench_driver.py --recordings 4 --xvectors 10000 --cpu-recordings 0 2>&1 | tail -1
+python tools/bench_driver.py --recordings 2 --xvectors 20000 --cpu-recordings 0 2>&1 | tail -1
