@@ -1,4 +1,5 @@
-"""NumPy model of the chunked parallel scan (vbx_amd/csrc/vbx_scan.hpp)  --  TEST INFRASTRUCTURE.
+"""NumPy model of the chunked parallel scan (vbx_amd/csrc/vbx_scan.hpp, vbx_operator.hpp, the re-run of
+vbx_chunk_post.hpp)  --  TEST INFRASTRUCTURE.
 
 Mirrors the three device kernels step for step (power-of-two column rescaling with integer
 exponents, support-aware weighting in the boundary chain, per-frame normalisation in the
@@ -13,10 +14,6 @@ import numpy as np
 
 EPS = 1e-8
 NEG_BIG = -10 ** 9
-
-
-def _exp2i(e):
-    return e
 
 
 def _rescale_exponent(sig, dtype, clamp=True):
@@ -111,12 +108,16 @@ def compose(op_next, op_prev, dtype):
 
 
 def forward_backward_chunked(lls, pi, loopProb, ip=None, chunk=128, dtype=np.float64, pad_to=None,
-                             zero_column_fix=True, clamp=True, super_group=1):
+                             zero_column_fix=True, clamp=True, super_group=1, split_halves=False):
     """gamma, tll, entered -- same contract as vbx_oracle.fb_linear, computed the chunked way.
     ``pad_to`` appends padded speakers exactly as the device layout does (b = 0, c = 0, no initial
     mass); ``zero_column_fix=False`` reproduces the bug the first device version had.  ``super_group`` > 1 walks
     the chunk boundaries in two levels (compose groups of that many chunk operators, walk the groups, then walk
-    inside every group), as the device does for long recordings."""
+    inside every group), as the device does for long recordings.  ``split_halves`` models the fused kernels of round 2:
+    every chunk longer than half the chunk length gets the operators of its two halves (chunk_loglik), the chunk operator
+    of the boundary walk is their composition, and the re-run (chunk_post) starts the second half's forward recursion
+    from P1 applied to the chunk's forward boundary and the first half's backward recursion from P2^T applied to its
+    backward boundary."""
     lls = np.asarray(lls, dtype=np.float64)
     T, S_true = lls.shape
     pi = np.asarray(pi, dtype=np.float64)
@@ -135,9 +136,17 @@ def forward_backward_chunked(lls, pi, loopProb, ip=None, chunk=128, dtype=np.flo
     starts = list(range(0, T, chunk))
     K = len(starts)
     ops = []
+    halves = {}
+    H = chunk // 2
     for k, t0 in enumerate(starts):
         Bk = B[t0:t0 + chunk]
-        ops.append(scan1(Bk, c, lp, dtype, k == 0, 0, zero_column_fix, clamp))
+        if split_halves and len(Bk) > H:
+            p1 = scan1(Bk[:H], c, lp, dtype, k == 0, 0, zero_column_fix, clamp)
+            p2 = scan1(Bk[H:], c, lp, dtype, False, 0, zero_column_fix, clamp)
+            halves[k] = (p1, p2)
+            ops.append(compose(p2, p1, dtype))
+        else:
+            ops.append(scan1(Bk, c, lp, dtype, k == 0, 0, zero_column_fix, clamp))
     fbound = [None] * K
     gbound = [None] * K
     fbound[0] = ip0
@@ -176,28 +185,41 @@ def forward_backward_chunked(lls, pi, loopProb, ip=None, chunk=128, dtype=np.flo
     ahat = np.empty((T, S), dtype=dtype)
     bhat = np.empty((T, S), dtype=dtype)
     tll = 0.0
-    for k, t0 in enumerate(starts):
-        Bk = B[t0:t0 + chunk]
-        L = len(Bk)
-        x = fbound[k]
-        if k > 0:
+
+    def rerun(t0, Bs, fvec, first, gvec):
+        """Frames t0 .. t0+len(Bs)-1 from the forward vector entering them and the backward vector at their last frame."""
+        nonlocal tll
+        L = len(Bs)
+        x = fvec
+        if not first:
             x = (x / x.sum()).astype(dtype)
         for i in range(L):
-            pre = x if (k == 0 and i == 0) else (lp * x + c).astype(dtype)
-            u = (Bk[i] * pre).astype(dtype)
+            pre = x if (first and i == 0) else (lp * x + c).astype(dtype)
+            u = (Bs[i] * pre).astype(dtype)
             r = u.sum(dtype=dtype)
             x = (u / r).astype(dtype)
             ahat[t0 + i] = x
             tll += float(np.log(np.float64(r))) + float(m[t0 + i])
-        x = gbound[k]
+        x = gvec
         with np.errstate(invalid='ignore', divide='ignore'):
             x = (x / x.sum() * S).astype(dtype)
         bhat[t0 + L - 1] = x
         for i in range(L - 1):
-            u = (Bk[L - 1 - i] * x).astype(dtype)
+            u = (Bs[L - 1 - i] * x).astype(dtype)
             r = (c * u).sum(dtype=dtype)
             x = (u * (lp / r) + dtype(1)).astype(dtype)
             bhat[t0 + L - 2 - i] = x
+
+    for k, t0 in enumerate(starts):
+        Bk = B[t0:t0 + chunk]
+        if k in halves:
+            p1, p2 = halves[k]
+            a_cut = scan2_apply(fbound[k], *p1, dtype)                       # a at frame H-1 (any scale)
+            x_cut = mask(scan2_apply_transposed(gbound[k], *p2, dtype))      # x at frame H-1 (any scale)
+            rerun(t0, Bk[:H], fbound[k], k == 0, x_cut)
+            rerun(t0 + H, Bk[H:], a_cut, False, gbound[k])
+        else:
+            rerun(t0, Bk, fbound[k], k == 0, gbound[k])
     g = ahat.astype(np.float64) * bhat.astype(np.float64)
     with np.errstate(invalid='ignore', divide='ignore'):
         gamma = g / g.sum(axis=1, keepdims=True)

@@ -101,3 +101,22 @@ def test_two_level_boundary_walk_model(dtype, tol, group):
         np.testing.assert_allclose(g, ref, rtol=0, atol=tol)
         np.testing.assert_allclose(tll, tll_ref, rtol=1e-6)
         np.testing.assert_allclose(ent, ent_ref, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize('dtype,tol', [(np.float64, 1e-12), (np.float32, 5e-6)])
+def test_half_chunk_operators_model(dtype, tol):
+    """The fused kernels of round 2: operators of the two halves of every chunk, the chunk operator composed from
+    them for the boundary walk, the vectors at the cut from one product each -- same gamma, log-likelihood and prior
+    statistic as the plain recursion, for full chunks, a tail shorter and a tail longer than half a chunk, a zero
+    operator column in the first chunk, with and without the two-level walk."""
+    for T in (1500, 1500 + 20, 1500 + 70, 65, 64):
+        lls, pi = make_lls(T, 9, seed=5, scale=5.0)
+        lls[0, 2] = -1e4
+        for lp in (0.9, 0.0):
+            ref, tll_ref, ent_ref = orc.fb_linear(lls, pi, lp)
+            for group in (1, 3):
+                g, tll, ent = cs.forward_backward_chunked(lls, pi, lp, chunk=128, dtype=dtype, pad_to=16,
+                                                          super_group=group, split_halves=True)
+                np.testing.assert_allclose(g, ref, rtol=0, atol=tol)
+                np.testing.assert_allclose(tll, tll_ref, rtol=1e-6)
+                np.testing.assert_allclose(ent, ent_ref, rtol=1e-4, atol=1e-6)
