@@ -1,5 +1,4 @@
-python -m pytest tests/test_driver.py tests/test_gpu_ahc.py tests/test_drop_in_launcher.py -q -x -m gpu 2>&1 | tail -2
-python tools/bench_driver.py --recordings 64 --xvectors 1025 2>&1 | tail -1
-python tools/bench_driver.py --recordings 16 --xvectors 4000 --cpu-recordings 0 2>&1 | tail -1
-python tools/bench_driver.py --recordings 4 --xvectors 10000 --cpu-recordings 0 2>&1 | tail -1
-python tools/bench_driver.py --recordings 2 --xvectors 20000 --cpu-recordings 0 2>&1 | tail -1
+for k in 2 3 4 5 6; do
+python bench.py --streams $k --no-f64 --no-single --cpu-iters 0 2>&1 | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('streams', d['config']['streams_per_gpu'], d['value'], d['ms_per_step'], d['timed_region']['ms_per_step_min'], d['timed_region']['ms_per_step_max'])"
+done
