@@ -74,11 +74,14 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)si
             const int kw = min(kAlphaSlice, Dp - k0);          // multiple of 32
             if (k0 > 0) __syncthreads();
             {
-                const int vpr = kw / 4;                        // 16-byte vectors per speaker row
-                for (int idx = tid; idx < SP * vpr; idx += 256) {
-                    const int row = idx / vpr, c4 = idx - row * vpr;
-                    *reinterpret_cast<R4*>(al + row * AST + 4 * c4) =
-                        *reinterpret_cast<const R4*>(alpha + (long long)row * Dp + k0 + 4 * c4);
+                // eight threads per speaker row, 32 rows per pass (kw is a multiple of 32: no division by a run-time
+                // vector count in the index arithmetic)
+                const int c8 = tid & 7;
+#pragma unroll
+                for (int row = tid >> 3; row < SP; row += 32) {
+                    for (int c4 = c8; 4 * c4 < kw; c4 += 8)
+                        *reinterpret_cast<R4*>(al + row * AST + 4 * c4) =
+                            *reinterpret_cast<const R4*>(alpha + (long long)row * Dp + k0 + 4 * c4);
                 }
             }
             const int nq = kw / 16;
@@ -121,31 +124,39 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)si
         R biasv[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) biasv[n] = bt.bias[(long long)rec * SP + 16 * n + i];
+        // (a full chunk -- all but the last one of a recording -- stores without per-row conditions: each of them is a
+        //  branch around the store)
+        auto epilogue = [&](auto full_tag) {
+            constexpr bool kFull = decltype(full_tag)::value;
+            R* __restrict__ bout = bt.bmat + (rd.row0 + t0) * SP + i;
+            R* __restrict__ mout = bt.mrow + rd.row0 + t0;
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
+            for (int m = 0; m < 2; ++m) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int fl = 32 * wave + 16 * m + M::row(lane, r);     // frame within the chunk
-                R v[NT];
-                R mx = neg_inf<R>();
+                for (int r = 0; r < 4; ++r) {
+                    const int fl = 32 * wave + 16 * m + M::row(lane, r);     // frame within the chunk
+                    R v[NT];
+                    R mx = neg_inf<R>();
 #pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    const int s = 16 * n + i;
-                    v[n] = (s < rd.S) ? Fa * (acc[m][n][r] + biasv[n]) : neg_inf<R>();
-                    mx = vmax(mx, v[n]);
+                    for (int n = 0; n < NT; ++n) {
+                        const int s = 16 * n + i;
+                        v[n] = (s < rd.S) ? Fa * (acc[m][n][r] + biasv[n]) : neg_inf<R>();
+                        mx = vmax(mx, v[n]);
+                    }
+                    mx = allreduce_max<16>(mx);
+                    const bool ok = kFull || fl < len;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const R b = exp_r(v[n] - mx);
+                        btile[fl * SP + 16 * n + i] = b;
+                        if (ok) bout[fl * SP + 16 * n] = b;
+                    }
+                    if (ok && i == 0) mout[fl] = mx;
                 }
-                mx = allreduce_max<16>(mx);
-                const bool ok = fl < len;
-                const long long cell = (rd.row0 + t0 + fl) * SP;
-#pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    const R b = exp_r(v[n] - mx);
-                    btile[fl * SP + 16 * n + i] = b;
-                    if (ok) bt.bmat[cell + 16 * n + i] = b;
-                }
-                if (ok && i == 0) bt.mrow[rd.row0 + t0 + fl] = mx;
             }
-        }
+        };
+        if (len == kTileFrames) epilogue(std::true_type{});
+        else epilogue(std::false_type{});
     }
     VBX_STAMP();
     __syncthreads();

@@ -43,6 +43,7 @@
 // LDS: 2 regions of kTileFrames x SP + ~3 KB: 35 KB at SP = 32 (f32) -> four workgroups per CU.
 // Instrumentation build: -DVBX_PHASE_CLOCKS (per-workgroup phase stamps, tools/phase_timeline.py).
 #pragma once
+#include <type_traits>
 #include "vbx_scan.hpp"
 
 namespace vbx {
@@ -179,7 +180,11 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
 #pragma unroll
             for (int r = 0; r < NREG; ++r) a[r] = scale2(a[r], -e);
         };
-        auto f_store = [&](int f) { store_pack<NREG>((f < m ? r1 : bl) + f * SP + so, a); sfl[f] = sig; };
+        // (a chain stores into one region per phase -- below the crossing a goes to r1 and x over b, from it on the other
+        //  way round -- so the region is a pointer set once per phase, not a select per frame)
+        R* fdst = r1;
+        R* xdst = r1;
+        auto f_store = [&](int f) { store_pack<NREG>(fdst + f * SP + so, a); sfl[f] = sig; };
         auto f_step = [&](const R (&b)[NREG], int f) {
 #pragma unroll
             for (int r = 0; r < NREG; ++r) a[r] = b[r] * (lp * a[r] + c[r] * sig);
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
         // backward state: x = x_{fb} (unnormalised), produced by consuming rows > fb
         R x[NREG], q = 1;
         int fb = hi - 1;
-        auto b_store = [&](int f) { store_pack<NREG>((f < m ? bl : r1) + f * SP + so, x); qfl[f] = q; };
+        auto b_store = [&](int f) { store_pack<NREG>(xdst + f * SP + so, x); qfl[f] = q; };
         auto b_step = [&](const R (&b)[NREG], bool store) {      // consumes row fb, produces x_{fb-1}
             R u[NREG];
 #pragma unroll
@@ -279,9 +284,11 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
             sig = allreduce_sum<16>(sig);
             sig_in = sig;
             if (chunk0 && half == 0) {
-                f_store(0);                                      // (row 0 of bl if len == 1: b_0 is not needed again)
+                fdst = 0 < m ? r1 : bl;                          // (row 0 of bl if len == 1: b_0 is not needed again)
+                f_store(0);
                 ff = 1;
             }
+            fdst = r1;
             f_run(max(m, ff));                                   // rows < m -> r1
         } else if (is_bwd) {
             if (half == 1 || !split) {
@@ -346,6 +353,7 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
         __syncthreads();                                         // crossing: rows >= m of each half are consumed by its
                                                                  // backward wave, rows < m by its forward wave
         if (is_fwd) {
+            fdst = bl;
             f_run(hi);                                           // rows >= m -> bl (over b_f, after reading it)
             if (lane == 0) {
                 tl_sig[half][0] = sig;
@@ -362,6 +370,7 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
             for (int k = 0; k < 3; ++k)
                 if (k < tail) load_pack<NREG>(lead[k], bl + (fb - k) * SP + so);
             if (n - tail >= 4) load_rows(cu, fb - tail, -1);
+            xdst = bl;
             b_store(fb);                                         // x_{m-1} -> bl[m-1]
 #pragma unroll
             for (int k = 0; k < 3; ++k)
@@ -404,35 +413,57 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
             R gam[NIT][NREG], ent[NREG];
 #pragma unroll
             for (int r = 0; r < NREG; ++r) ent[r] = 0;
+            // kFast: a full tile re-run as two halves (all but the last tile of a recording).  Which region holds a_f / x_f
+            // is then a compile-time property of the unrolled iteration (bit 5 of f = 16 it + 4 wave + g4), every frame
+            // exists, and the address / select arithmetic of the general form -- half of its instructions -- goes away.
+            const int f16 = 4 * wave + g4;
+            auto pass1 = [&](auto fast_tag) {
+                constexpr bool kFast = decltype(fast_tag)::value;
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int f = 16 * it + 4 * wave + g4;
-                const bool ok = f < len;
-                const int fr = ok ? f : 0;
-                const R isig = fast_rcp(sfl[fr]), iq = fast_rcp(qfl[fr]);   // (applied one after the other: their product may overflow)
-                const R sp = fr > 0 ? sfl[fr - 1] : tl_sig[0][1];
-                R av[NREG], xv[NREG], ap[NREG];
-                const bool lowf = low_part(fr);
-                load_pack<NREG>(av, (lowf ? r1 : bl) + fr * SP + so);
-                load_pack<NREG>(xv, (lowf ? bl : r1) + fr * SP + so);
-                if (!REPLAY) load_pack<NREG>(ap, (fr == 0 ? aprev0 : (low_part(fr - 1) ? r1 : bl) + (fr - 1) * SP) + so);
-#pragma unroll
-                for (int r = 0; r < NREG; ++r) gam[it][r] = (av[r] * isig) * (xv[r] * iq);
-                R sum = gam[it][0];
-#pragma unroll
-                for (int r = 1; r < NREG; ++r) sum += gam[it][r];
-                sum = allreduce_sum<16>(sum);
-                const R inv = ok ? fast_rcp(sum) : (R)0;
-                const bool stat = ok && t0 + f >= 1;               // frame 0 of the recording has no "entered" term
-#pragma unroll
-                for (int r = 0; r < NREG; ++r) {
-                    gam[it][r] *= inv;
+                for (int it = 0; it < NIT; ++it) {
+                    const int f = 16 * it + f16;
+                    const bool ok = kFast || f < len;
+                    const int fr = ok ? f : 0;
+                    const R isig = fast_rcp(sfl[fr]), iq = fast_rcp(qfl[fr]);   // (applied one after the other: their product may overflow)
+                    R sp;
+                    if (kFast && it > 0) sp = sfl[fr - 1];
+                    else sp = fr > 0 ? sfl[fr - 1] : tl_sig[0][1];
+                    R av[NREG], xv[NREG], ap[NREG];
+                    bool lowf, lowp;
+                    if constexpr (kFast) {
+                        lowf = ((16 * it) & (kTileFrames / 4)) == 0;
+                        lowp = f16 > 0 ? lowf : ((16 * it - 16) & (kTileFrames / 4)) == 0;
+                    } else {
+                        lowf = low_part(fr);
+                        lowp = low_part(fr - 1);
+                    }
+                    load_pack<NREG>(av, (lowf ? r1 : bl) + fr * SP + so);
+                    load_pack<NREG>(xv, (lowf ? bl : r1) + fr * SP + so);
                     if (!REPLAY) {
-                        const R term = gam[it][r] * sp * fast_rcp(lp * ap[r] + c[r] * sp);
-                        ent[r] += stat ? term : (R)0;              // (select, not multiply: ap is undefined for frame 0)
+                        const R* app = (lowp ? r1 : bl) + (fr - 1) * SP;
+                        if (!kFast || it == 0) app = fr == 0 ? aprev0 : app;
+                        load_pack<NREG>(ap, app + so);
+                    }
+#pragma unroll
+                    for (int r = 0; r < NREG; ++r) gam[it][r] = (av[r] * isig) * (xv[r] * iq);
+                    R sum = gam[it][0];
+#pragma unroll
+                    for (int r = 1; r < NREG; ++r) sum += gam[it][r];
+                    sum = allreduce_sum<16>(sum);
+                    const R inv = ok ? fast_rcp(sum) : (R)0;
+                    const bool stat = ok && t0 + f >= 1;           // frame 0 of the recording has no "entered" term
+#pragma unroll
+                    for (int r = 0; r < NREG; ++r) {
+                        gam[it][r] *= inv;
+                        if (!REPLAY) {
+                            const R term = gam[it][r] * sp * fast_rcp(lp * ap[r] + c[r] * sp);
+                            ent[r] += stat ? term : (R)0;          // (select, not multiply: ap is undefined for frame 0)
+                        }
                     }
                 }
-            }
+            };
+            if (split && len == kTileFrames) pass1(std::true_type{});
+            else pass1(std::false_type{});
             if (REPLAY) {
                 // the responsibilities themselves: [T][SP] in HBM (VBx.py:99,126)
                 R* __restrict__ G = bt.gamma + trow * SP;

@@ -3,6 +3,7 @@
 // Nothing here is portable HIP on purpose: 64-lane wavefronts, DPP row operations and the
 // f32/f64 16x16x4 MFMA fragment layouts of gfx950 are hard-wired.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -146,7 +147,10 @@ __device__ __forceinline__ double read_lane(double v, int lane) {
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-template <typename R> __device__ __forceinline__ R vmax(R a, R b) { return a > b ? a : b; }
+// (one v_max_* each -- a compare + select would also keep the DPP move of a butterfly stage from folding into it)
+__device__ __forceinline__ float vmax(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double vmax(double a, double b) { return __builtin_fmax(a, b); }
+__device__ __forceinline__ int vmax(int a, int b) { return a > b ? a : b; }
 
 // Butterfly all-reduce over aligned groups of W lanes (W = 16, 32 or 64): every lane of a
 // group ends up with the group's result (identical bits in every lane: each stage combines a
@@ -171,7 +175,23 @@ template <int W, typename R> __device__ __forceinline__ R allreduce_sum(R v) {
     return v;
 }
 
+template <int W, typename R> __device__ __forceinline__ R allreduce_max_impl(R v);
+
+// f32: the butterfly runs on an order-preserving integer image of the value (sign-magnitude -> two's complement: one
+// v_max_i32_dpp per stage; on floats every stage is a DPP move + a canonicalising max of the moved operand + the max)
 template <int W, typename R> __device__ __forceinline__ R allreduce_max(R v) {
+    if constexpr (std::is_same<R, float>::value) {
+        int k = __builtin_bit_cast(int, v);
+        k ^= (k >> 31) & 0x7fffffff;
+        k = allreduce_max_impl<W, int>(k);
+        k ^= (k >> 31) & 0x7fffffff;
+        return __builtin_bit_cast(float, k);
+    } else {
+        return allreduce_max_impl<W, R>(v);
+    }
+}
+
+template <int W, typename R> __device__ __forceinline__ R allreduce_max_impl(R v) {
     static_assert(W == 16 || W == 32 || W == 64, "group width");
 #ifdef VBX_NO_DPP
     v = vmax(v, __shfl_xor(v, 1, 64));
