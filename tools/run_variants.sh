@@ -1,6 +1,6 @@
 python -m pytest tests -q -x -m gpu 2>&1 | tail -3
-python tools/kbench.py --tag fast --iters 100 2>&1 | tail -1
-python tools/kbench.py --tag fast-b1 --batch 1 --iters 100 2>&1 | tail -1
-python tools/kbench.py --tag fast-f64 --precision fp64 --iters 50 2>&1 | tail -1
+python tools/kbench.py --tag sc --iters 100 2>&1 | tail -1
+python tools/kbench.py --tag sc-b1 --batch 1 --iters 100 2>&1 | tail -1
+python tools/kbench.py --tag sc-f64 --precision fp64 --iters 50 2>&1 | tail -1
 python bench.py --no-f64 --no-single --cpu-iters 0 2>&1 | tail -1 | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('bench', d['value'], d['ms_per_step'], d['kernels_avg_us'], d['roofline']['frac'])"

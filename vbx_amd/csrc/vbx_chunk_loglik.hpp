@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)si
     if (bt.state[rec].done) return;
     const RecDesc rd = bt.recs[rec];
     const int Dp = bt.Dp;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 15, g = lane >> 4;
+    // (the wave index as a scalar: everything derived from it -- frame ranges, loop bounds, roles -- stays in SGPRs)
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15, g = lane >> 4;
     const int t0 = bt.tile_t0[tile];
     const int len = min(kTileFrames, rd.T - t0);
 
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)si
         __shared__ int eF[SP], eW[SP];
         const bool split = bt.oph != nullptr;              // (uniform) off: one operator over the whole tile, as scan1 builds it
         const bool two = split && len > H;                 // (uniform) the tile has a second half
-        const int my_half = kSideBySide ? tid / NOPT : 0;
+        const int my_half = !kSideBySide ? 0 : (NOPT % 64 == 0) ? wave / (NOPT / 64) : tid / NOPT;   // (scalar: loop bounds)
         const int otid = kSideBySide ? tid % NOPT : tid;
         const int col = otid / PH, part = otid % PH, j0 = part * NR;
         const bool builder = kSideBySide ? tid < 2 * NOPT : tid < NOPT;

@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
     const int tile = blockIdx.x;
     if (!REPLAY && bt.tile_done[tile]) return;
     VBX_CLOCKS_DECL();
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // (the wave index as a scalar: roles, frame ranges and loop bounds of the re-run stay in SGPRs)
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int i16 = lane & 15, g4 = lane >> 4;
     const int so = i16 * NREG;                         // first state of this lane
     const int Dp = bt.Dp;
