@@ -154,6 +154,8 @@ struct vbx_batch {
     // chunked scan
     void *d_op = nullptr, *d_fbound = nullptr, *d_gbound = nullptr;
     int* d_opexp = nullptr;
+    void* d_cop = nullptr;                        // c of the operator recursion per recording (mstep_fin -> chunk_loglik)
+    vbx::LpPow* d_lppow = nullptr;                // lp^n tables of the recordings (host-computed)
     void* d_oph = nullptr;                        // half-tile operators of the fused path (chunk_loglik -> chunk_post)
     int* d_ophexp = nullptr;
     double* d_tllpart = nullptr;
@@ -190,6 +192,7 @@ struct vbx_batch {
         v.npart = (R*)d_npart; v.epart = d_epart; v.Li = d_Li; v.epsilon = epsilon;
         v.ip = d_ip ? d_ip : d_pi; v.fw_scale = (R*)d_fw_scale; v.bw_scale = (R*)d_bw_scale;
         v.oph = fused_now && half_ops_now ? (R*)d_oph : nullptr; v.ophexp = d_ophexp;
+        v.cop = fused_now ? (R*)d_cop : nullptr; v.lppow = d_lppow;
         v.op = (R*)d_op; v.opexp = d_opexp; v.fbound = (R*)d_fbound; v.gbound = (R*)d_gbound;
         v.tllpart = use_chunked ? d_tllpart : nullptr; v.sfw = (R*)d_sfw; v.dump = (R*)d_dump;
         v.sop = (R*)d_sop; v.sopexp = d_sopexp; v.sup_rec = d_sup_rec; v.sup_idx = d_sup_idx;
@@ -493,7 +496,10 @@ int choose_fb_algo(vbx_batch* b, bool step_api_logs) {
         const size_t nt = (size_t)b->ntiles_total, sp = (size_t)b->Sp;
         int rc = dmalloc_bytes(b->ctx, &b->d_oph, 2 * nt * sp * sp * b->rsize);
         if (rc == VBX_OK) rc = dmalloc(b->ctx, &b->d_ophexp, 2 * nt * sp);
+        if (rc == VBX_OK) rc = dmalloc_bytes(b->ctx, &b->d_cop, (size_t)b->n_rec * sp * b->rsize);
+        if (rc == VBX_OK) rc = dmalloc(b->ctx, &b->d_lppow, (size_t)b->n_rec * (kTileFrames + 1));
         if (rc != VBX_OK) return rc;
+        b->recs_dirty = true;                    // (the lp^n tables go up with the recording descriptors)
     }
     if (!fused1 && !b->d_ahat) {
         const size_t cells = (size_t)b->sum_T * b->Sp;
@@ -557,6 +563,18 @@ int upload_recs(vbx_batch* b) {
     if (!b->recs_dirty) return VBX_OK;
     HIPCHK(b->ctx, hipMemcpyAsync(b->d_recs, b->recs.data(), sizeof(RecDesc) * b->n_rec, hipMemcpyHostToDevice,
                                   b->ctx->stream));
+    std::vector<vbx::LpPow> pw;
+    if (b->d_lppow) {        // lp^n = mant * 2^fl for n = 0 .. kTileFrames (vbx_operator.hpp: the scaled recursion's factor)
+        pw.resize((size_t)b->n_rec * (kTileFrames + 1));
+        for (int i = 0; i < b->n_rec; ++i) {
+            const double lp = b->recs[i].lp, l2lp = lp > 0.0 ? std::log2(lp) : 0.0;
+            for (int n = 0; n <= kTileFrames; ++n) {
+                const double l2 = (double)n * l2lp, fl = std::floor(l2);
+                pw[(size_t)i * (kTileFrames + 1) + n] = vbx::LpPow{std::exp2(l2 - fl), (int)fl, 0};
+            }
+        }
+        HIPCHK(b->ctx, hipMemcpyAsync(b->d_lppow, pw.data(), sizeof(vbx::LpPow) * pw.size(), hipMemcpyHostToDevice, b->ctx->stream));
+    }
     HIPCHK(b->ctx, hipStreamSynchronize(b->ctx->stream));
     b->recs_dirty = false;
     return VBX_OK;
@@ -651,7 +669,7 @@ static int leaf_destroy(vbx_batch* b) {
                     b->d_bias, b->d_mpart, b->d_npart, b->d_lraw, b->d_emodel, b->d_pi, b->d_epart, b->d_Li,
                     b->d_xstage, b->d_ip, b->d_fw_scale, b->d_bw_scale, b->d_op, b->d_fbound, b->d_gbound,
                     b->d_opexp, b->d_tllpart, b->d_sfw, b->d_dump, b->d_sop, b->d_sopexp, b->d_sup_rec, b->d_sup_idx,
-                    b->d_gamma0, b->d_pi_prev, b->d_oph, b->d_ophexp};
+                    b->d_gamma0, b->d_pi_prev, b->d_oph, b->d_ophexp, b->d_cop, b->d_lppow};
     (void)hipStreamSynchronize(b->ctx->stream);               // nothing of this batch may still be running when its
     for (void* p : ptrs) ctx_free(b->ctx, p);                 // blocks go back to the spare list
     if (b->ev_start) (void)hipEventDestroy(b->ev_start);

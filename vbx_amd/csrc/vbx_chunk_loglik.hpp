@@ -185,10 +185,11 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)si
         const bool builder = kSideBySide ? tid < 2 * NOPT : tid < NOPT;
         R x[2][NR];                                        // [0]: my operator (side by side) or P1; [1]: P2 (SP = 64)
         int expo[2] = {kNoMass, kNoMass};
-        const double* pi_rec = bt.pi + (long long)rec * SP;
+        const R* c_rec = bt.cop + (long long)rec * SP;
+        const LpPow* lppow = bt.lppow + (long long)rec * (kTileFrames + 1);
         auto build = [&](int half, R (&xo)[NR], int& eo) {
             const int lo = half * H, hi = (half == 0 && split) ? min(len, H) : len;
-            operator_column<R, SP, PH>(btile, lo, hi, t0 + lo == 0, col, part, rd.lp, pi_rec, rd.S, xo, eo);
+            operator_column<R, SP, PH>(btile, lo, hi, t0 + lo == 0, col, part, rd.lp, c_rec, lppow, xo, eo);
             if (bt.oph) {
                 R* __restrict__ dst = bt.oph + (((long long)tile * 2 + half) * SP + col) * SP + j0;
 #pragma unroll

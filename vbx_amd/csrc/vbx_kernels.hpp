@@ -37,6 +37,8 @@ struct RecState {
     int pad_;
 };
 
+struct LpPow { double mant; int fl; int pad_; };   // lp^n = mant * 2^fl, mant in [1, 2)  (host table, per recording and n)
+
 template <typename R> struct BatchView {
     int n_rec, Sp, Dp, D, max_iters;
     int ntiles_total;
@@ -75,6 +77,9 @@ template <typename R> struct BatchView {
     R* oph;                // [ntiles_total][2][Sp][Sp] or null: the operators of the two halves of a tile (fused path:
                            //                     chunk_loglik -> chunk_post, which re-runs the halves side by side)
     int* ophexp;           // [ntiles_total][2][Sp]
+    R* cop;                // [n_rec][Sp]  the operator recursion's c: ((1-lp) pi + 1e-8) / lp (plain for lp < 2^-20), written
+                           //              by mstep_fin from the priors every iteration (f64 arithmetic, rounded once)
+    const LpPow* lppow;    // [n_rec][kTileFrames + 1]  lp^n as mantissa and exponent (host: log2 / exp2 in f64)
     R* fbound;             // [ntiles_total][Sp]  forward vector entering the chunk (ahat[t0-1], any scale)
     R* gbound;             // [ntiles_total][Sp]  backward vector at the chunk's last frame (any scale)
     double* tllpart;       // [ntiles_total] or null: sum over the chunk of log s_t + m_t
@@ -222,6 +227,10 @@ __global__ __launch_bounds__(256) void mstep_fin_kernel(BatchView<R> bt) {
     const RecDesc rd = bt.recs[rec];
     const int Sp = bt.Sp, Dp = bt.Dp;
     const bool given = (st.n_iters == 0 && rd.has_model);
+    if (threadIdx.x == 0 && bt.cop) {      // the c of the operator recursion (vbx_operator.hpp) for this speaker
+        const double cj = s < rd.S ? (1.0 - rd.lp) * bt.pi[(long long)rec * Sp + s] + 1e-8 : 0.0;
+        bt.cop[(long long)rec * Sp + s] = (R)(rd.lp >= 0x1p-20 ? cj / rd.lp : cj);
+    }
     const double fafb = rd.Fa / rd.Fb;
     const int u0 = rd.tile0, nu = rd.ntiles;
     double N = 0.0;

@@ -17,11 +17,14 @@
 namespace vbx {
 
 // btile: b of the tile in LDS, [frames][SP].  first_plain: frame lo is frame 0 of the recording (x <- b_0 x, VBx.py:163:
-// no transition).  pi_rec: the recording's priors [SP] (f64).  -> x[NR] (column sums in [0.5, 1)), expo (the column is
-// x * 2^expo; -(1 << 24) for an all-zero column, which must never win an exponent maximum).
+// no transition).  c_rec: the recursion's c of the recording, [SP] (c / lp in the scaled form: BatchView::cop, written by
+// mstep_fin); lppow: lp^n as (mantissa, exponent) for n = 0 .. kTileFrames (BatchView::lppow, host table) -- a dozen f64
+// divisions, a log2 and an exp2 per wave and operator used to be a fifth of chunk_loglik's vector instructions.
+// -> x[NR] (column sums in [0.5, 1)), expo (the column is x * 2^expo; -(1 << 24) for an all-zero column, which must
+// never win an exponent maximum).
 template <typename R, int SP, int PH>
 __device__ __forceinline__ void operator_column(const R* btile, int lo, int hi, bool first_plain, int col, int part,
-                                                double lp_d, const double* __restrict__ pi_rec, int n_spk,
+                                                double lp_d, const R* __restrict__ c_rec, const LpPow* __restrict__ lppow,
                                                 R (&x)[SP / PH], int& expo) {
     using R2 = typename Vec<R>::v2;
     using R4 = typename Vec<R>::v4;
@@ -32,11 +35,12 @@ __device__ __forceinline__ void operator_column(const R* btile, int lo, int hi, 
     const bool scaled = lp_d >= 0x1p-20;
     R c[NR];
 #pragma unroll
-    for (int r = 0; r < NR; ++r) {
-        x[r] = (j0 + r == col) ? (R)1 : (R)0;
-        const double cj = (1.0 - lp_d) * pi_rec[j0 + r] + 1e-8;
-        c[r] = (j0 + r < n_spk) ? (R)(scaled ? cj / lp_d : cj) : (R)0;
+    for (int q = 0; q < NR / 4; ++q) {
+        const R4 c4 = *reinterpret_cast<const R4*>(c_rec + j0 + 4 * q);
+        c[4 * q] = c4.x; c[4 * q + 1] = c4.y; c[4 * q + 2] = c4.z; c[4 * q + 3] = c4.w;
     }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) x[r] = (j0 + r == col) ? (R)1 : (R)0;
     expo = 0;
     int step = lo;
     if (first_plain) {
@@ -103,9 +107,9 @@ __device__ __forceinline__ void operator_column(const R* btile, int lo, int hi, 
     };
     if (scaled) {
         recursion(std::true_type{});
-        const double l2 = (double)transitions * log2(lp_d), fl = floor(l2);
-        const R mant = (R)exp2(l2 - fl);                     // lp^transitions = mant * 2^fl, mant in [1, 2)
-        expo += (int)fl;
+        const LpPow pw = lppow[transitions];                 // lp^transitions = mant * 2^fl, mant in [1, 2)
+        const R mant = (R)pw.mant;
+        expo += pw.fl;
 #pragma unroll
         for (int r = 0; r < NR; ++r) x[r] *= mant;
     } else {
