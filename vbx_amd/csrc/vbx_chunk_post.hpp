@@ -46,6 +46,7 @@
 #include <type_traits>
 #include "vbx_scan.hpp"
 
+
 namespace vbx {
 
 #ifdef VBX_PHASE_CLOCKS
@@ -486,7 +487,12 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
             if (tid < len) mpartial = (double)bt.mrow[trow + tid];
             if (tid == 128 || (tid == 129 && split)) {         // one term per forward chain
                 const int h = tid - 128;
-                mpartial += log((double)tl_sig[h][0]) - log((double)tl_sig[h][1]) + (double)tl_expo[h] * 0.69314718055994530942;
+                // (f32: the sums carry 24 bits, v_log_f32 gives the difference to ~1e-7 absolute -- 1e-12 of an ELBO)
+                if (sizeof(R) == 4)
+                    mpartial += (double)(__logf((float)tl_sig[h][0]) - __logf((float)tl_sig[h][1]));
+                else
+                    mpartial += log((double)tl_sig[h][0]) - log((double)tl_sig[h][1]);
+                mpartial += (double)tl_expo[h] * 0.69314718055994530942;
             }
             mpartial = block_sum(mpartial, red);               // (its barriers also end pass 1)
             if (tid < SP) {
@@ -526,7 +532,7 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
                     load_pack<NT>(av, bl + f * SP + NT * i16);
 #pragma unroll
                     for (int mu = 0; mu < NT; ++mu) {
-                        nsum[mu] += av[mu];
+                        if (slab == 0) nsum[mu] += av[mu];      // (sum of gamma: stored by slab 0 only)
                         acc[mu][0] = M::mma(av[mu], bfr[u].x, acc[mu][0]);
                         acc[mu][1] = M::mma(av[mu], bfr[u].y, acc[mu][1]);
                     }
