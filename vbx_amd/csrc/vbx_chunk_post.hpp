@@ -10,7 +10,8 @@
 //            product each with the half-tile operators chunk_loglik has left in `oph`:
 //                a_(H-1) = P1 a_in        x_(H-1) = P2^T x_(len-1)
 //            (64 dependent steps per chain instead of 128; a tile of at most H frames, or a batch without `oph`, is one
-//            half walked by waves 0 and 1).  The two chains of a half meet in its middle m: each stores only what the
+//            half walked by waves 0 and 1; a full tile that is not the first of its recording packs the two forward
+//            chains into wave 0 and the two backward chains into wave 1, rows 0-1 / 2-3 of the wave: PACKED below).  The two chains of a half meet in its middle m: each stores only what the
 //            OTHER has not produced yet in region `r1`, and everything after the crossing overwrites rows of b that
 //            both have consumed:
 //                rows [lo, m) : a_f -> r1[f]  (forward, before the barrier)    x_f -> bl[f]  (backward, after it)
@@ -46,6 +47,10 @@
 #include <type_traits>
 #include "vbx_scan.hpp"
 
+
+#ifndef VBX_POST_PACKED
+#define VBX_POST_PACKED 1
+#endif
 
 namespace vbx {
 
@@ -107,6 +112,16 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
         const int m0 = split ? H / 2 : len / 2, m1 = H + (len - H) / 2;      // where the chains of a half cross
         const int m = half ? m1 : m0;
         auto low_part = [&](int f) { return split && f >= H ? f < m1 : f < m0; };   // a_f in r1 and x_f in bl?
+        // PACKED (a full tile that is not the first of its recording, re-run as halves): the two forward chains share
+        // wave 0 and the two backward chains wave 1 -- rows 0-1 of the wave walk the first half, rows 2-3 the second,
+        // same instruction stream, LDS rows offset by H frames per lane -- while waves 2 and 3 only compute the vectors at
+        // the cut.  Half as many chain waves compete for a SIMD and the re-run issues half the vector instructions.
+        const bool chunk0 = (t0 == 0);
+        const bool packed = VBX_POST_PACKED && split && len == kTileFrames && !chunk0;     // (uniform)
+        const int hl = packed ? (g4 >> 1) : 0;             // the half this lane's row walks in a packed wave
+        const int hoff = hl * H, soh = so + hoff * SP;     // ... as a frame offset / an offset into a lattice region
+        const int clo = packed ? 0 : lo, chi = packed ? H : hi, cm = packed ? H / 2 : m;   // chain range and crossing
+        const bool run_fwd = packed ? wave == 0 : is_fwd, run_bwd = packed ? wave == 1 : is_bwd;
         const double lp_d = bt.recs[rec].lp;
         const int n_spk = bt.recs[rec].S;
         const R lp = (R)lp_d;
@@ -154,7 +169,6 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
             const double pj = (REPLAY ? bt.pi_prev : bt.pi)[(long long)rec * SP + tid];
             c_l[tid] = (tid < n_spk) ? (R)((1.0 - lp_d) * pj + 1e-8) : (R)0;
         }
-        const bool chunk0 = (t0 == 0);
         __syncthreads();
         VBX_STAMP();
 
@@ -170,11 +184,11 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
         for (int r = 0; r < NREG; ++r) c[r] = c_l[so + r];
         auto load_rows = [&](R (&dst)[4][NREG], int f, int dir) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) load_pack<NREG>(dst[k], bl + (f + dir * k) * SP + so);
+            for (int k = 0; k < 4; ++k) load_pack<NREG>(dst[k], bl + (f + dir * k) * SP + soh);
         };
         // forward state
         R a[NREG], sig = 1, sig_in = 1;
-        int expo = 0, ff = lo;
+        int expo = 0, ff = clo;
         auto f_renorm = [&]() {
             const int e = rescale_exponent(sig);
             expo += e;
@@ -186,7 +200,7 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
         //  way round -- so the region is a pointer set once per phase, not a select per frame)
         R* fdst = r1;
         R* xdst = r1;
-        auto f_store = [&](int f) { store_pack<NREG>(fdst + f * SP + so, a); sfl[f] = sig; };
+        auto f_store = [&](int f) { store_pack<NREG>(fdst + f * SP + soh, a); sfl[f + hoff] = sig; };
         auto f_step = [&](const R (&b)[NREG], int f) {
 #pragma unroll
             for (int r = 0; r < NREG; ++r) a[r] = b[r] * (lp * a[r] + c[r] * sig);
@@ -212,14 +226,14 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
             f_renorm();
             for (; ff < end; ++ff) {
                 R b[NREG];
-                load_pack<NREG>(b, bl + ff * SP + so);
+                load_pack<NREG>(b, bl + ff * SP + soh);
                 f_step(b, ff);
             }
         };
         // backward state: x = x_{fb} (unnormalised), produced by consuming rows > fb
         R x[NREG], q = 1;
-        int fb = hi - 1;
-        auto b_store = [&](int f) { store_pack<NREG>(xdst + f * SP + so, x); qfl[f] = q; };
+        int fb = chi - 1;
+        auto b_store = [&](int f) { store_pack<NREG>(xdst + f * SP + soh, x); qfl[f + hoff] = q; };
         auto b_step = [&](const R (&b)[NREG], bool store) {      // consumes row fb, produces x_{fb-1}
             R u[NREG];
 #pragma unroll
@@ -280,18 +294,10 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
                     if (so + r >= n_spk) a[r] = 0;               // padded speakers carry no mass
                 }
             }
-            sig = a[0];
-#pragma unroll
-            for (int r = 1; r < NREG; ++r) sig += a[r];
-            sig = allreduce_sum<16>(sig);
-            sig_in = sig;
-            if (chunk0 && half == 0) {
-                fdst = 0 < m ? r1 : bl;                          // (row 0 of bl if len == 1: b_0 is not needed again)
-                f_store(0);
-                ff = 1;
+            if (packed && wave == 2) {                           // the vector at the cut goes to wave 0 through LDS
+                __builtin_amdgcn_wave_barrier();                 // (every lane has read the weights in mv_w[0])
+                if (g4 == 0) store_pack<NREG>(mv_w[0] + so, a);
             }
-            fdst = r1;
-            f_run(max(m, ff));                                   // rows < m -> r1
         } else if (is_bwd) {
             if (half == 1 || !split) {
 #pragma unroll
@@ -319,6 +325,30 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
                 for (int r = 0; r < NREG; ++r)
                     x[r] = (tj[r] > -(1 << 27) && so + r < n_spk) ? scale2(x[r], ope[r] - top) : (R)0;
             }
+            if (packed && wave == 3) {                           // the vector at the cut goes to wave 1 through LDS
+                __builtin_amdgcn_wave_barrier();
+                if (g4 == 0) store_pack<NREG>(mv_w[1] + so, x);
+            }
+        }
+        if (packed) {
+            __syncthreads();
+            if (wave == 0 && hl == 1) load_pack<NREG>(a, mv_w[0] + so);      // rows 2-3: the second half starts from a_(H-1)
+            if (wave == 1 && hl == 0) load_pack<NREG>(x, mv_w[1] + so);      // rows 0-1: the first half starts from x_(H-1)
+        }
+        if (run_fwd) {
+            sig = a[0];
+#pragma unroll
+            for (int r = 1; r < NREG; ++r) sig += a[r];
+            sig = allreduce_sum<16>(sig);
+            sig_in = sig;
+            if (chunk0 && half == 0) {
+                fdst = 0 < cm ? r1 : bl;                         // (row 0 of bl if len == 1: b_0 is not needed again)
+                f_store(0);
+                ff = 1;
+            }
+            fdst = r1;
+            f_run(max(cm, ff));                                  // rows < m -> r1
+        } else if (run_bwd) {
             R part = 0;
 #pragma unroll
             for (int r = 0; r < NREG; ++r) part += x[r];
@@ -327,18 +357,18 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
 #pragma unroll
             for (int r = 0; r < NREG; ++r) x[r] = scale2(x[r], -e);
             q = scale2(part, -e) * (R)(1.0 / SP);                // a positive scale of the row, like q of the steps
-            b_store(hi - 1);                                     // -> r1 (hi-1 >= m always)
+            b_store(chi - 1);                                    // -> r1 (hi-1 >= m always)
             // consume rows hi-1 .. max(m, lo+1); the outputs with index >= m go to r1, the last one (x_{m-1})
             // stays in registers until the barrier: its slot in bl still holds b_{m-1}, which the forward wave
             // may not have consumed yet
-            const int stop = max(m, lo + 1);
+            const int stop = max(cm, clo + 1);
             R cu[4][NREG], nx[4][NREG];
             if (fb - 3 >= stop) load_rows(cu, fb, -1);
             while (fb - 3 >= stop) {                             // a block of four rows fb .. fb-3, all >= stop
                 const bool last_block = fb - 4 < stop;           // its last output is x_{stop-1}
                 if (fb - 7 >= stop) load_rows(nx, fb - 4, -1);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) b_step(cu[k], !(last_block && k == 3) || stop - 1 >= m);
+                for (int k = 0; k < 4; ++k) b_step(cu[k], !(last_block && k == 3) || stop - 1 >= cm);
                 b_renorm();
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
@@ -347,30 +377,31 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
             }
             while (fb >= stop) {
                 R b[NREG];
-                load_pack<NREG>(b, bl + fb * SP + so);
-                b_step(b, fb - 1 >= m);
+                load_pack<NREG>(b, bl + fb * SP + soh);
+                b_step(b, fb - 1 >= cm);
             }
         }
         VBX_STAMP();
         __syncthreads();                                         // crossing: rows >= m of each half are consumed by its
                                                                  // backward wave, rows < m by its forward wave
-        if (is_fwd) {
+        if (run_fwd) {
             fdst = bl;
-            f_run(hi);                                           // rows >= m -> bl (over b_f, after reading it)
-            if (lane == 0) {
-                tl_sig[half][0] = sig;
-                tl_sig[half][1] = (chunk0 && half == 0) ? (R)1 : sig_in;
-                tl_expo[half] = expo;
+            f_run(chi);                                          // rows >= m -> bl (over b_f, after reading it)
+            const int th = packed ? hl : half;                   // (one lane per chain: lane 0, and lane 32 of a packed wave)
+            if (i16 == 0 && (packed ? (g4 & 1) == 0 : g4 == 0)) {
+                tl_sig[th][0] = sig;
+                tl_sig[th][1] = (chunk0 && half == 0) ? (R)1 : sig_in;
+                tl_expo[th] = expo;
             }
-        } else if (is_bwd && m > lo) {
+        } else if (run_bwd && cm > clo) {
             // x = x_{m-1} is in registers, rows m-1 .. lo+1 remain.  Every output x_{f-1} lands on b_{f-1}, the row
             // the NEXT step consumes, so rows are always in registers before their slot is written: up to three
             // leading single rows and the first block of four are fetched before the first store.
-            const int n = fb - lo, tail = n & 3;                 // fb == m - 1
+            const int n = fb - clo, tail = n & 3;                // fb == m - 1
             R lead[3][NREG], cu[4][NREG], nx[4][NREG];
 #pragma unroll
             for (int k = 0; k < 3; ++k)
-                if (k < tail) load_pack<NREG>(lead[k], bl + (fb - k) * SP + so);
+                if (k < tail) load_pack<NREG>(lead[k], bl + (fb - k) * SP + soh);
             if (n - tail >= 4) load_rows(cu, fb - tail, -1);
             xdst = bl;
             b_store(fb);                                         // x_{m-1} -> bl[m-1]
@@ -378,8 +409,8 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
             for (int k = 0; k < 3; ++k)
                 if (k < tail) b_step(lead[k], true);
             if (tail) b_renorm();
-            while (fb - lo >= 4) {                               // blocks of four rows fb .. fb-3 (fb - lo is a multiple of 4 here)
-                if (fb - lo - 4 >= 4) load_rows(nx, fb - 4, -1);
+            while (fb - clo >= 4) {                               // blocks of four rows fb .. fb-3 (fb - lo is a multiple of 4 here)
+                if (fb - clo - 4 >= 4) load_rows(nx, fb - 4, -1);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) b_step(cu[k], true);
                 b_renorm();
