@@ -1,6 +1,6 @@
-python bench.py 2>&1 | tail -1 > gpurun_out/r02_bench_final.json
-python bench.py --gpus 1 --steps 20 --warmup 5 2>&1 | tail -1 > gpurun_out/r02_bench_final_driver_args.json
-bash tools/profile_bench.sh r02h_s1 --streams 1 > gpurun_out/prof_r02h_s1.log 2>&1
-python tools/pmc_traffic.py gpurun_out/prof_r02h_s1/fetch/fetch_results.db gpurun_out/prof_r02h_s1/write/write_results.db gpurun_out/prof_r02h_s1/pmc_traffic.json batch=64 T=10000 S=30 D=128 precision=fp32 >> gpurun_out/prof_r02h_s1.log 2>&1
-rm -rf gpurun_out/prof_r02h_s1/trace gpurun_out/prof_r02h_s1/fetch gpurun_out/prof_r02h_s1/write gpurun_out/prof_r02h_s1/sq gpurun_out/prof_r02h_s1/bench
-python tools/bench_call.py 2>&1 | tail -3
+# Scratch script of the last measurement run on the GPU box (gpurun -- 'bash tools/run_variants.sh > gpurun_out/x.log').
+# Typical use: build A/B libraries with tools/build_variants.sh tagA:"-DX=1" tagB:"-DX=0", then alternate them in ONE run
+# (boxes of the pool differ by ~4 %, runs on the same box by < 1 %):
+for v in tagA tagB tagA tagB; do
+VBX_AMD_LIB=vbx_amd/csrc/libvbx_hip_$v.so python tools/kbench.py --tag $v --iters 150 2>&1 | tail -1
+done
