@@ -11,9 +11,9 @@
 //                a_(H-1) = P1 a_in        x_(H-1) = P2^T x_(len-1)
 //            (64 dependent steps per chain instead of 128; a tile of at most H frames, or a batch without `oph`, is one
 //            half walked by waves 0 and 1; a full tile that is not the first of its recording packs the two forward
-//            chains into wave 0 and the two backward chains into wave 1, rows 0-1 / 2-3 of the wave: PACKED below).  The two chains of a half meet in its middle m: each stores only what the
-//            OTHER has not produced yet in region `r1`, and everything after the crossing overwrites rows of b that
-//            both have consumed:
+//            chains into wave 0 and the two backward chains into wave 1, rows 0-1 / 2-3 of the wave: PACKED below).
+//            The two chains of a half meet in its middle m: each stores only what the OTHER has not produced yet in
+//            region `r1`, and everything after the crossing overwrites rows of b that both have consumed:
 //                rows [lo, m) : a_f -> r1[f]  (forward, before the barrier)    x_f -> bl[f]  (backward, after it)
 //                rows [m, hi) : x_f -> r1[f]  (backward, before the barrier)   a_f -> bl[f]  (forward, after it)
 //   post     gamma ~ a x, "entered" statistic, log-likelihood share; gamma -> bl (A operand of the accumulation)
@@ -26,12 +26,13 @@
 // has stopped).  Measured on 64 recordings of T = 10 000, S = 30: 174 -> 165 us per launch, 77 MB less written.
 //
 // Tried and dropped (round 2): one workgroup walking a RUN of several tiles with the accumulators kept in registers
-// across them (one partial per run instead of per tile) and b of the next tile prefetched into `hl` during the
+// across them (one partial per run instead of per tile) and b of the next tile prefetched into `r1` during the
 // accumulation.  As a loop the compiler keeps per-lane addresses of the whole body live across it (100-130 spilled
 // registers at the 128-register budget of four workgroups per CU; laundering the lane index per tile and unrolling
 // the loop completely brings that to ~25); measured 182 us (two tiles per run), 226 us (three), 277-333 us (five:
 // one balanced round of persistent workgroups also puts the phases of the whole chip in lock-step) against 165 us.
 //
+// (What worked in the end is the half-tile scheme above: two operators per tile from chunk_loglik, 8 KB per tile.)
 // Also tried and dropped (round 2): the tile cut into four SUB-CHUNKS of 32 frames that re-run side by side in the four
 // 16-lane rows of the two re-run waves (32 dependent steps instead of 128; elimination runs of the re-run cut to 64 /
 // 32 / 4 frames: 134 / 119 / 107 us).  The vectors at the three inner edges need the sub-chunks' S x S transfer
@@ -47,7 +48,7 @@
 #include <type_traits>
 #include "vbx_scan.hpp"
 
-
+// 0: the four chains of a split tile on four waves (A/B builds)
 #ifndef VBX_POST_PACKED
 #define VBX_POST_PACKED 1
 #endif
