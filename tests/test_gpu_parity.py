@@ -813,3 +813,24 @@ def test_stream_groups_give_the_results_of_a_plain_batch(ctx, precision, tol, mo
     with pytest.raises(_capi.VbxError):
         plain.set_option(_capi.OPT_STREAMS, 2)
     plain.close()
+
+
+def test_a_batch_slot_set_again_with_another_loop_probability(ctx):
+    """The per-recording tables the operator build reads (lp^n, the recursion's c) follow a recording that is set again
+    with another loopProb in the same batch slot."""
+    from vbx_amd import _capi
+    from vbx_amd.synth import make_recording
+    T, S = 700, 9
+    X, Phi, _ = make_recording(T, S, seed=77, kappa=0.05)
+    g0 = np.random.default_rng(78).gamma(1.0, size=(T, S))
+    g0 /= g0.sum(1, keepdims=True)
+    batch = _capi.Batch(ctx, [T], [S], 128, precision='fp64', max_iters=8)
+    batch.set_option(_capi.OPT_FB_ALGO, _capi.FB_CHUNKED)
+    for lp in (0.9, 0.35, 0.999):
+        batch.set_recording(0, X, Phi, np.ones(S) / S, g0, lp, 0.3, 17.0)
+        batch.run(3, -np.inf)
+        a = batch.result(0, want_model=False)
+        gr, pr, Lr = _orc().VBx(X, Phi, loopProb=lp, Fa=0.3, Fb=17.0, pi=S, gamma=g0, maxIters=3, epsilon=-1e300)
+        assert np.abs(a['gamma'] - gr).max() <= 2e-8, (lp, np.abs(a['gamma'] - gr).max())
+        assert rel_err(a['Li'], [r[0] for r in Lr]) <= 1e-10, lp
+    batch.close()
