@@ -355,9 +355,10 @@ def test_device_linkage_is_the_host_linkage_bit_for_bit(kind):
     rng = np.random.default_rng(11)
     xs = []
     if kind == 'cosine':
-        xs = [rng.standard_normal((n, 16)) for n in (2, 3, 5, 64, 257, 1000, 2500)]
+        # (from 8192 clusters the chain runs in stages with the live rows / columns compacted in between)
+        xs = [rng.standard_normal((n, 16)) for n in (2, 3, 5, 64, 257, 1000, 2500, 8192, 9001)]
     elif kind == 'ties':
-        for n in (7, 40, 300, 1200):
+        for n in (7, 40, 300, 1200, 8300):
             base = rng.integers(-1, 2, size=(6, 8)).astype(float) + 0.5           # six distinct directions: duplicates galore
             xs.append(base[rng.integers(0, 6, n)])
     else:

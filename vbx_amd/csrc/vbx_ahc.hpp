@@ -215,21 +215,41 @@ __device__ __forceinline__ double average_update(double fa, double da, double fb
     return sum / fs;
 }
 
+// Staged (round 2): the chain is walked in stages of n/4 merges; between two stages the live rows and columns are
+// copied into a matrix of the new dimension by a grid of workgroups (linkage_compact_* below), so a row scan reads
+// what is alive and little else -- beyond its four dependent round trips a merge costs one CU's bandwidth on the ~110
+// bytes per entry it touches, which shows once the matrix no longer fits the 256 MB Infinity Cache (T > ~5600).  Indices
+// inside a stage are positions in the compacted matrix (`orig` maps them back when the stage ends; compaction keeps the
+// order, so SciPy's tie rules -- previous chain element, then the lowest index -- pick the same clusters); the chain
+// itself, the cluster sizes and (chain_length, first_live) live in global memory across stages.
+// Tried on top and dropped: the top of the chain mirrored in LDS with sizes and distances (a pop without global loads,
+// sizes carried through the arg-min reduction) -- 1 us per merge SLOWER (14.0 -> 15.0 us at T = 3000): the extra
+// shuffle stage of every scan costs more than the three loads of a merge, which overlap with the row update.
 __global__ __launch_bounds__(1024) void nn_chain_kernel(double* __restrict__ D, int n, int* __restrict__ size,
-                                                         int* __restrict__ chain, ChainMergeDev* __restrict__ merges) {
+                                                         int* __restrict__ chain, const int* __restrict__ orig,
+                                                         int* __restrict__ state, ChainMergeDev* __restrict__ merges,
+                                                         int k_begin, int k_end) {
     __shared__ double wmin[16];
     __shared__ int widx[16];
     __shared__ int s_x, s_pred, s_merge, s_a, s_b, s_na, s_nb;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double inf = (double)INFINITY;
-    for (int i = tid; i < n; i += 1024) size[i] = 1;
     // thread 0 keeps the chain: its length, the two top elements and their distance stay in registers (a push knows
     // them: d(y, x) = d(x, y), the matrix is kept symmetric), the rest lives in `chain`; after a merge the new top pair
     // is read back -- a chain step itself costs the row fetch and two barriers, no other dependent memory access
     int chain_length = 0, first_live = 0, top = 0, pred = -1;
     double top_pred_dist = inf;
+    if (tid == 0) {                                      // where the previous stage (or the initialisation) left the chain
+        chain_length = state[0];
+        first_live = state[1];
+        if (chain_length >= 1) {
+            top = chain[chain_length - 1];
+            pred = chain_length > 1 ? chain[chain_length - 2] : -1;
+            top_pred_dist = pred >= 0 ? D[(long long)top * n + pred] : inf;
+        }
+    }
     __syncthreads();
-    for (int k = 0; k < n - 1; ++k) {
+    for (int k = k_begin; k < k_end; ++k) {
         if (tid == 0) {
             if (chain_length == 0) {
                 while (size[first_live] == 0) ++first_live;  // the lowest live index starts a chain
@@ -286,7 +306,7 @@ __global__ __launch_bounds__(1024) void nn_chain_kernel(double* __restrict__ D, 
                     chain_length -= 2;
                     const int a = x < y ? x : y, b = x < y ? y : x;
                     s_a = a; s_b = b; s_na = size[a]; s_nb = size[b];
-                    merges[k] = ChainMergeDev{a, b, cur};
+                    merges[k] = ChainMergeDev{a, b, cur};            // (positions: translated when the stage ends)
                     s_merge = 1;
                 } else {
                     chain[chain_length++] = y;
@@ -339,6 +359,67 @@ __global__ __launch_bounds__(1024) void nn_chain_kernel(double* __restrict__ D, 
             }
         }
     }
+    __syncthreads();
+    for (int k = k_begin + tid; k < k_end; k += 1024) {  // positions in this stage's matrix -> the clusters they stand for
+        ChainMergeDev mg = merges[k];
+        mg.a = orig[mg.a];
+        mg.b = orig[mg.b];
+        merges[k] = mg;
+    }
+    if (tid == 0) {
+        state[0] = chain_length;
+        state[1] = first_live;
+    }
+}
+
+// ---- between two stages: the live clusters move up, in order ----------------------------------------------------------
+// One workgroup: position of every live cluster among the live ones (block-wide prefix sum), the lists that follow the
+// clusters (size, original id) and the chain re-indexed; `old_of_new` tells the matrix copy where a row / column comes from.
+__global__ __launch_bounds__(1024) void linkage_compact_index_kernel(int n, const int* __restrict__ size, const int* __restrict__ orig,
+                                                                      int* __restrict__ chain, int* __restrict__ state,
+                                                                      int* __restrict__ size2, int* __restrict__ orig2,
+                                                                      int* __restrict__ old_of_new, int* __restrict__ newidx) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const int live = (i < n && size[i] > 0) ? 1 : 0;
+        int incl = live;                                     // inclusive prefix sum inside the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int before = carry;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        const int pos = before + incl - live;
+        if (i < n) newidx[i] = live ? pos : -1;
+        if (live) {
+            old_of_new[pos] = i;
+            size2[pos] = size[i];
+            orig2[pos] = orig[i];
+        }
+        __syncthreads();
+        if (tid == 1023) carry = before + incl;
+        __syncthreads();
+    }
+    const int len = state[0];
+    for (int j = tid; j < len; j += 1024) chain[j] = newidx[chain[j]];      // (chain elements are alive)
+    if (tid == 0) state[1] = 0;                                              // every position is alive again
+}
+
+// grid = new dimension (one row each): D2[r][c] = D1[old(r)][old(c)]
+__global__ __launch_bounds__(256) void linkage_compact_matrix_kernel(const double* __restrict__ D1, int n1, double* __restrict__ D2,
+                                                                      int n2, const int* __restrict__ old_of_new) {
+    const int r = blockIdx.x;
+    const double* __restrict__ src = D1 + (long long)old_of_new[r] * n1;
+    double* __restrict__ dst = D2 + (long long)r * n2;
+    for (int c = threadIdx.x; c < n2; c += 256) dst[c] = src[old_of_new[c]];
 }
 
 }  // namespace vbx

@@ -2067,22 +2067,70 @@ int vbx_scores_linkage_average(vbx_scores* sc, int64_t T, double* Z) {
     if (T == 1) return VBX_OK;
     vbx_ctx* ctx = sc->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    int *d_size = nullptr, *d_chain = nullptr;
+    // stages of n/4 merges with a compaction of the live rows and columns in between (vbx_ahc.hpp); below kStageMin
+    // clusters the rest runs in one stage (there a merge costs its four round trips, not the bytes of a row)
+    static const long long kStageMin = [] { const char* e = getenv("VBX_AMD_LINKAGE_STAGE_MIN"); const long long v = e ? atoll(e) : 0; return v >= 64 ? v : 4096LL; }();
+    static const bool staged = [] { const char* e = getenv("VBX_AMD_LINKAGE_STAGES"); return !(e && e[0] == '0'); }();
+    int *d_size = nullptr, *d_size2 = nullptr, *d_chain = nullptr, *d_orig = nullptr, *d_orig2 = nullptr, *d_old = nullptr,
+        *d_newidx = nullptr, *d_state = nullptr;
+    double* d_alt = nullptr;
     vbx::ChainMergeDev* d_merges = nullptr;
+    const bool stages = staged && T >= 2 * kStageMin;
+    const long long n_alt = stages ? T - T / 4 : 0;
     int rc = dmalloc(ctx, &d_size, (size_t)T);
     if (rc == VBX_OK) rc = dmalloc(ctx, &d_chain, (size_t)T);
+    if (rc == VBX_OK) rc = dmalloc(ctx, &d_orig, (size_t)T);
+    if (rc == VBX_OK) rc = dmalloc(ctx, &d_state, (size_t)4);
     if (rc == VBX_OK) rc = dmalloc(ctx, &d_merges, (size_t)(T - 1));
+    if (rc == VBX_OK && stages) {
+        rc = dmalloc(ctx, &d_size2, (size_t)T);
+        if (rc == VBX_OK) rc = dmalloc(ctx, &d_orig2, (size_t)T);
+        if (rc == VBX_OK) rc = dmalloc(ctx, &d_old, (size_t)T);
+        if (rc == VBX_OK) rc = dmalloc(ctx, &d_newidx, (size_t)T);
+        if (rc == VBX_OK) rc = dmalloc(ctx, &d_alt, (size_t)(n_alt * n_alt));
+    }
     std::vector<vbx::ChainMerge> merges((size_t)(T - 1));
     static_assert(sizeof(vbx::ChainMerge) == sizeof(vbx::ChainMergeDev), "merge record layout");
     hipError_t e = hipSuccess;
     if (rc == VBX_OK) {
         hipStream_t st = ctx->stream;
-        hipLaunchKernelGGL(vbx::linkage_prepare_kernel, dim3((unsigned)T), dim3(256), 0, st, sc->d_s, (long long)T);
-        hipLaunchKernelGGL(vbx::nn_chain_kernel, dim3(1), dim3(1024), 0, st, sc->d_s, (int)T, d_size, d_chain, d_merges);
-        e = hipGetLastError();
+        std::vector<int> ones((size_t)T, 1), iota((size_t)T);
+        for (long long i = 0; i < T; ++i) iota[(size_t)i] = (int)i;
+        const int zero4[4] = {0, 0, 0, 0};
+        e = hipMemcpyAsync(d_size, ones.data(), sizeof(int) * (size_t)T, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_orig, iota.data(), sizeof(int) * (size_t)T, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_state, zero4, sizeof(zero4), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);                 // (the host vectors go out of scope below)
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(vbx::linkage_prepare_kernel, dim3((unsigned)T), dim3(256), 0, st, sc->d_s, (long long)T);
+            double *cur = sc->d_s, *alt = d_alt;
+            int *size_c = d_size, *size_a = d_size2, *orig_c = d_orig, *orig_a = d_orig2;
+            long long n_cur = T, done = 0;
+            while (done < T - 1) {
+                const long long remaining = T - 1 - done;
+                const long long m = (stages && n_cur >= 2 * kStageMin) ? std::min(remaining, n_cur / 4) : remaining;
+                hipLaunchKernelGGL(vbx::nn_chain_kernel, dim3(1), dim3(1024), 0, st, cur, (int)n_cur, size_c, d_chain, orig_c,
+                                   d_state, d_merges, (int)done, (int)(done + m));
+                done += m;
+                if (done < T - 1) {                                        // the live clusters move up, in order
+                    const long long n_new = n_cur - m;
+                    hipLaunchKernelGGL(vbx::linkage_compact_index_kernel, dim3(1), dim3(1024), 0, st, (int)n_cur, size_c, orig_c,
+                                       d_chain, d_state, size_a, orig_a, d_old, d_newidx);
+                    hipLaunchKernelGGL(vbx::linkage_compact_matrix_kernel, dim3((unsigned)n_new), dim3(256), 0, st, cur, (int)n_cur,
+                                       alt, (int)n_new, d_old);
+                    std::swap(cur, alt);
+                    std::swap(size_c, size_a);
+                    std::swap(orig_c, orig_a);
+                    n_cur = n_new;
+                }
+            }
+            e = hipGetLastError();
+        }
         if (e == hipSuccess) e = hipMemcpyAsync(merges.data(), d_merges, sizeof(vbx::ChainMerge) * merges.size(), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
     }
+    for (void* p : {(void*)d_size2, (void*)d_orig, (void*)d_orig2, (void*)d_old, (void*)d_newidx, (void*)d_state, (void*)d_alt})
+        ctx_free(ctx, p);
     ctx_free(ctx, d_size);
     ctx_free(ctx, d_chain);
     ctx_free(ctx, d_merges);
