@@ -54,3 +54,25 @@ def test_kernel_stats_and_pmc_tools(tmp_path):
     line = [ln for ln in txt.splitlines() if ln.startswith('chunk_post') and 'mfma_util' in ln][0]
     # 2 rows x 245 760 busy cycles = 491 520 SIMD-cycles over 1024 SIMDs x 200 us x 2400 cycles/us = 0.001
     assert 'mfma_busy_simd_cycles         491520' in line and 'mfma_util  0.0010' in line and 'active/wave_cycles  0.2500' in line
+
+
+def test_chunk_kernels_keep_their_register_and_lds_budget():
+    """The two chunk kernels of the bench shape live on their occupancy (four / eight workgroups per CU): no spilled
+    registers, LDS within the budget -- read from hipcc's resource remarks (tools/kernel_resources.py, no GPU needed)."""
+    import subprocess
+    import sys
+    if not os.path.exists('/opt/rocm/bin/hipcc'):
+        pytest.skip('hipcc not available')
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'kernel_resources.py'), 'chunk_'],
+                         capture_output=True, text=True, timeout=600).stdout
+    rows = {}
+    for line in out.splitlines()[1:]:
+        name, rest = line[:58].strip(), line[58:].split()
+        if len(rest) == 6:
+            rows[name] = dict(zip(('vgpr', 'agpr', 'spill', 'scratch', 'occ', 'lds'), map(int, rest)))
+    post, loglik = rows['chunk_post_kernel<float, 32, false>'], rows['chunk_loglik_kernel<float, 32>']
+    assert post['spill'] == 0 and post['scratch'] == 0 and post['occ'] >= 4 and post['lds'] <= 40 * 1024, post
+    assert loglik['spill'] == 0 and loglik['scratch'] == 0 and loglik['occ'] >= 8 and loglik['lds'] <= 20 * 1024, loglik
+    for name, r in rows.items():
+        if 'double' not in name and ', 16' not in name:
+            assert r['scratch'] == 0, (name, r)
