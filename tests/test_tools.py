@@ -6,6 +6,8 @@ import sqlite3
 import subprocess
 import sys
 
+import pytest
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAME = 'void vbx::chunk_post_kernel<float, 32, false>(vbx::BatchView<float>)'
 REPLAY = 'void vbx::chunk_post_kernel<float, 32, true>(vbx::BatchView<float>)'
