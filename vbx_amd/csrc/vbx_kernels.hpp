@@ -218,9 +218,9 @@ __global__ __launch_bounds__(64) void mstep_acc_kernel(BatchView<R> bt) {
 // Tile partials are combined in f64.  grid = (n_rec, Sp), block = 128.
 // =======================================================================================
 template <typename R>
-__global__ __launch_bounds__(256) void mstep_fin_kernel(BatchView<R> bt) {
+__global__ __launch_bounds__(1024) void mstep_fin_kernel(BatchView<R> bt) {      // block = 256, or 1024 for long recordings
     __shared__ double lds[16];
-    __shared__ double csum[256];
+    __shared__ double csum[1024];
     const int rec = blockIdx.x, s = blockIdx.y;
     const RecState st = bt.state[rec];
     if (st.done) return;
@@ -242,9 +242,10 @@ __global__ __launch_bounds__(256) void mstep_fin_kernel(BatchView<R> bt) {
     }
     const long long sd = ((long long)rec * Sp + s) * Dp;
     double bsum = 0.0, esum = 0.0;
-    // thread = (feature d, half of the tile range); loads are clamped instead of predicated so that
-    // sixteen of them are in flight per thread
-    const int half = threadIdx.x >> 7, dl = threadIdx.x & 127;
+    // thread = (feature d, slice of the tile range: 2 slices, 8 in a block of 1024 threads -- a recording of T = 200 000
+    // has 1563 partials per speaker, twenty dependent rounds of loads on two slices); loads are clamped instead of
+    // predicated so that all of a round are in flight per thread
+    const int nsl = blockDim.x >> 7, slice = threadIdx.x >> 7, dl = threadIdx.x & 127;
     for (int d0 = 0; d0 < Dp; d0 += 128) {
         const int d = d0 + dl;
         const bool dok = d < Dp;
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(256) void mstep_fin_kernel(BatchView<R> bt) {
             const int nt = nu, last = nt - 1;
             const R* __restrict__ mp = bt.mpart + ((long long)u0 * Sp + s) * Dp + (dok ? d : 0);
             const long long stride = (long long)Sp * Dp;
-            const int lo = half == 0 ? 0 : (nt + 1) / 2, hi = half == 0 ? (nt + 1) / 2 : nt;
+            const int per = (nt + nsl - 1) / nsl, lo = min(nt, slice * per), hi = min(nt, lo + per);
             constexpr int LB = sizeof(R) == 8 ? 20 : 40;       // loads in flight per thread: T = 10 000 in one round trip
             for (int tl = lo; tl < hi; tl += LB) {
                 R v[LB];
@@ -265,14 +266,14 @@ __global__ __launch_bounds__(256) void mstep_fin_kernel(BatchView<R> bt) {
         }
         csum[threadIdx.x] = C;
         __syncthreads();
-        if (half == 0 && dok) {
+        if (slice == 0 && dok) {
             const double phi = bt.phi[(long long)rec * Dp + d];
             double il, al;
             if (given) {
                 il = (double)bt.invL[sd + d];
                 al = (double)bt.alpha[sd + d];
             } else {
-                C += csum[threadIdx.x + 128];
+                for (int k = 1; k < nsl; ++k) C += csum[threadIdx.x + 128 * k];
                 il = 1.0 / (1.0 + fafb * N * phi);
                 al = fafb * il * C;
                 const R ilr = (R)il, alr = (R)al;      // the values every later kernel sees
@@ -619,9 +620,9 @@ __global__ __launch_bounds__(256) void post_kernel(BatchView<R> bt) {
 // and the convergence test (VBx.py:122-125).  grid = n_rec, block = 256 (thread = speaker).
 // =======================================================================================
 template <typename R>
-__global__ __launch_bounds__(256) void iter_fin_kernel(BatchView<R> bt) {
+__global__ __launch_bounds__(1024) void iter_fin_kernel(BatchView<R> bt) {       // block = 256, or 1024 for long recordings
     __shared__ double lds[16];
-    __shared__ double ent_sh[256];
+    __shared__ double ent_sh[1024];
     __shared__ int done_sh;
     const int rec = blockIdx.x;
     RecState st = bt.state[rec];
@@ -630,7 +631,7 @@ __global__ __launch_bounds__(256) void iter_fin_kernel(BatchView<R> bt) {
     const int Sp = bt.Sp, j = threadIdx.x;
     // "entered" statistic: thread (slot, state) sums tiles slot, slot+nslot, ... ; Sp divides 256
     const int u0 = rd.tile0, nu = rd.ntiles;
-    const int nslot = 256 / Sp, slot = threadIdx.x / Sp, sj = threadIdx.x % Sp;
+    const int nslot = blockDim.x / Sp, slot = threadIdx.x / Sp, sj = threadIdx.x % Sp;
     double part = 0.0;
     for (int tl = slot; tl < nu; tl += 16 * nslot) {
         double v[16];
@@ -643,7 +644,7 @@ __global__ __launch_bounds__(256) void iter_fin_kernel(BatchView<R> bt) {
     ent_sh[threadIdx.x] = part;
     double tpart = 0.0;
     if (bt.tllpart)
-        for (int tl = threadIdx.x; tl < nu; tl += 256) tpart += bt.tllpart[u0 + tl];
+        for (int tl = threadIdx.x; tl < nu; tl += blockDim.x) tpart += bt.tllpart[u0 + tl];
     __syncthreads();
     double pn = 0.0, em = 0.0, pj = 0.0;
     if (j < rd.S) {
@@ -677,7 +678,7 @@ __global__ __launch_bounds__(256) void iter_fin_kernel(BatchView<R> bt) {
     }
     __syncthreads();
     if (done_sh)
-        for (int tl = threadIdx.x; tl < rd.ntiles; tl += 256) bt.tile_done[rd.tile0 + tl] = 1;
+        for (int tl = threadIdx.x; tl < rd.ntiles; tl += blockDim.x) bt.tile_done[rd.tile0 + tl] = 1;
 }
 
 }  // namespace vbx
