@@ -25,7 +25,10 @@ Also on the same JSON line:
   roofline                  dominant kernel: algorithmic bytes / HIP-event time vs the 8 TB/s HBM peak
   roofline_whole_iteration  the five launches of an iteration together, against the survey's byte count (SURVEY 8d:
                             one kernel per stage) and against the fused design's compulsory bytes
-  f64                       the same batch on the fp64 path (what vbhmm.py gets: its inputs are float64)
+  f64                       the same batch on the fp64 path (what vbhmm.py gets: its inputs are float64), with its own roofline
+  configs                   BASELINE.json configs[1], [2], [4]: C2 (T=10k, S=10), C3 (T=50k, S=30), C5 (T=200k, S=50, loopProb
+                            0.9, the nine-point Fa/Fb sweep as one batch on a shared rho, and with private copies), fp32 and
+                            fp64: ms per iteration, dominant kernel, algorithmic bytes, fraction of the HBM peak
   single_recording          latency-bound rate of ONE recording (batch=1) on one GPU
   cpu_baseline              the NumPy/SciPy restatement of the reference (oracle/vbx_oracle.py, kind "port": the GPU
                             box has no /root/reference) on the host cores, bounded sample (rank 0, N=1 only)
@@ -62,18 +65,28 @@ ALGO_PASSES = {
 
 
 def pmc_traffic(kernel, workload):
-    """HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes (tools/pmc_traffic.py),
-    or None when no profile of exactly this workload is on file.  The newest matching file wins."""
+    """HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes (tools/pmc_traffic.py) ->
+    (bytes, file, document), or (None, reason, None).  A profile counts only if it was taken on exactly this workload AND
+    on the kernels this tree builds: the file carries the hash of the kernel sources it was measured on
+    (vbx_amd.build.iteration_source_hash), and a file whose hash differs is refused -- a stale figure is worse than none."""
     import glob
-    best = None
+    from vbx_amd.build import iteration_source_hash
+    now = iteration_source_hash()
+    best, stale = None, None
     for path in sorted(glob.glob(os.path.join(REPO, 'profiles', '*_pmc_traffic.json'))):
         try:
             doc = json.load(open(path))
         except (OSError, ValueError):
             continue
-        if doc.get('workload') == workload and kernel in doc.get('kernels', {}):
-            best = (doc['kernels'][kernel]['hbm_bytes_per_launch'], os.path.relpath(path, REPO), doc)
-    return best
+        if doc.get('workload') != workload or kernel not in doc.get('kernels', {}):
+            continue
+        if doc.get('iteration_source_sha16') != now:
+            stale = os.path.relpath(path, REPO)
+            continue
+        best = (doc['kernels'][kernel]['hbm_bytes_per_launch'], os.path.relpath(path, REPO), doc)
+    if best:
+        return best
+    return (None, f'refused: {stale} was measured on other kernel sources than {now}' if stale else 'no PMC profile of this workload on file', None)
 
 
 def algo_bytes(kernel, T, R, S, esize):
@@ -92,6 +105,30 @@ def make_batch(ctx, n_rec, T, S, D, precision, seed0, max_iters, streams=None):
         g = np.random.default_rng(10_000 + seed0 + b).gamma(1.0, size=(T, S))
         g /= g.sum(1, keepdims=True)
         batch.set_recording(b, X, Phi, np.ones(S) / S, g, 0.99, 0.3, 17.0)
+    return batch
+
+
+SWEEP_POINTS = [(fa, fb) for fa in (0.2, 0.3, 0.4) for fb in (6.0, 17.0, 64.0)]     # DIHARD2_run.sh:45-46, AMI_run.sh:47, CALLHOME_run.sh:45-46
+
+
+def make_sweep_batch(ctx, T, S, D, precision, max_iters, shared, loop_prob=0.9, seed=0):
+    """BASELINE configs[4]: ONE recording under the nine (Fa, Fb) points of the recipes' grids, every point from the same
+    random initialisation.  ``shared``: the points read one rho (vbx_batch_set_recording_shared); otherwise every point is
+    a recording of its own with a private copy of the same x-vectors (what round 2 ran)."""
+    from vbx_amd import _capi
+    from vbx_amd.synth import make_recording
+    n = len(SWEEP_POINTS)
+    batch = _capi.Batch(ctx, [T] * n, [S] * n, D, precision=precision, max_iters=max_iters)
+    if batch.streams != 1:
+        batch.set_option(_capi.OPT_STREAMS, 1)
+    X, Phi, _ = make_recording(T, S, D=D, seed=seed, kappa=0.05, dtype=np.float32)
+    g = np.random.default_rng(10_000 + seed).gamma(1.0, size=(T, S)).astype(np.float32)
+    g /= g.sum(1, keepdims=True)
+    for k, (fa, fb) in enumerate(SWEEP_POINTS):
+        if shared and k > 0:
+            batch.set_recording_shared(k, 0, np.ones(S) / S, g, loop_prob, fa, fb)
+        else:
+            batch.set_recording(k, X, Phi, np.ones(S) / S, g, loop_prob, fa, fb)
     return batch
 
 
@@ -151,6 +188,7 @@ def main():
     ap.add_argument('--cpu-iters', type=int, default=20, help='oracle iterations for cpu_baseline (0 = skip)')
     ap.add_argument('--no-single', action='store_true', help='skip the batch=1 latency measurement')
     ap.add_argument('--no-f64', action='store_true', help='skip the fp64 sub-record')
+    ap.add_argument('--no-configs', action='store_true', help='skip the C2 / C3 / C5 records (BASELINE.json configs[1,2,4])')
     ap.add_argument('--streams', type=int, default=None, help='HIP streams per batch (default: the library\'s choice)')
     ap.add_argument('--dry-run', action='store_true', help='stop after the ranks are established (no GPU needed)')
     args = ap.parse_args()
@@ -211,63 +249,137 @@ def main():
             if not int(go.item()):
                 return times
 
+    def kernel_probe(make, min_seconds, max_blocks):
+        """Kernel-level figures of a workload on ONE stream: with several streams per GPU (the library's default for a
+        big batch) launches of different streams share the CUs, and the duration of a launch says how it shared them, not
+        what the kernel achieves.  HIP events on the batch's own stream: 8 untimed iterations with events around every
+        launch (which kernels run at all?), then W + blocks of K iterations with events around the launches of the
+        HBM-side kernels only.  -> ({kernel: {avg_us, launches}}, dominant HBM-side kernel, ms per step, blocks)"""
+        probe = make(W + K * min(max_blocks, 64) + 32, 1)
+        probe.profile_kernels(None)
+        probe.run(8, -np.inf)
+        survey = probe.kernel_times()
+        per_kernel = {k: {'avg_us': 1e3 * ms / n, 'launches': n} for k, (ms, n) in survey.items() if n}
+        # (the survey runs on cold clocks; the HBM-side kernels of an iteration are close to each other, so all of them
+        #  are bracketed over the warm steps and the dominant one is chosen from those averages)
+        cands = [k for k in per_kernel if k in ALGO_PASSES and per_kernel[k]['launches'] >= 8]   # (not the one-off first accumulation)
+        probe.profile_kernels(cands)
+        probe.run(W, -np.inf)
+        acc = {k: [0.0, 0] for k in cands}
+        probe_ms, blocks, t_probe = 0.0, 0, time.perf_counter()
+        while blocks < max(1, min(max_blocks, (probe.max_iters - W - 16) // K)) and \
+                (blocks == 0 or time.perf_counter() - t_probe < min_seconds):
+            probe.run(K, -np.inf)                      # (like the timed region: blocks of exactly K steps, repeated to a
+            kt = probe.kernel_times()                  #  minimum duration -- one block of the driver's 20 steps is 6 ms)
+            for k in cands:
+                acc[k][0] += kt[k][0]
+                acc[k][1] += kt[k][1]
+            probe_ms += probe.last_run_ms()[0]
+            blocks += 1
+        for k in cands:
+            per_kernel[k] = {'avg_us': 1e3 * acc[k][0] / acc[k][1], 'launches': acc[k][1]}
+        dom = max(cands, key=lambda k: per_kernel[k]['avg_us'])
+        probe.close()
+        return per_kernel, dom, probe_ms / (K * blocks), blocks
+
+    def roofline_of(per_kernel, dom, n_rec, T, S, D, es, workload):
+        """``roofline`` of the dominant HBM-side kernel: algorithmic bytes of one launch / its HIP-event duration."""
+        dom_bytes = n_rec * algo_bytes(dom, T, D, S, es)
+        achieved = dom_bytes / (per_kernel[dom]['avg_us'] * 1e-6) / 1e9
+        traffic = pmc_traffic(dom, workload)
+        return {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic[0], 'traffic_source': traffic[1],
+                'algorithmic_bytes_per_launch': dom_bytes, 'avg_launch_us': per_kernel[dom]['avg_us']}, traffic
+
     # upper bound on the iterations a batch will be asked for (the ELBO history lives on the device)
     budget = W + K * (args.max_blocks + 2) + 16
 
-    # ---- kernel-level measurements on ONE stream: with several streams per GPU (the library's default for a batch of
-    # this size) launches of different streams share the CUs, and the duration of a launch says how it shared them,
-    # not what the kernel achieves.  Same recordings, HIP events on the batch's own stream:
-    #   - 8 untimed iterations with events around every launch: which kernel dominates?
-    #   - W + K iterations with events around the launches of the HBM-side kernels only; the K steps -> `roofline`.
-    probe = make_batch(ctx, args.batch, args.T, args.S, args.D, args.precision, seed0=rank * args.batch,
-                       max_iters=W + K * min(args.max_blocks, 64) + 32, streams=1)
-    probe.profile_kernels(None)
-    probe.run(8, -np.inf)
-    survey = probe.kernel_times()
-    per_kernel = {k: {'avg_us': 1e3 * ms / n, 'launches': n} for k, (ms, n) in survey.items() if n}
-    # (the survey runs on cold clocks; the HBM-side kernels of the iteration are close to each other, so all of them are
-    #  bracketed over the K warm steps and the dominant one is chosen from those averages)
-    cands = [k for k in per_kernel if k in ALGO_PASSES and per_kernel[k]['launches'] >= 8]   # (not the one-off first accumulation)
-    probe.profile_kernels(cands)
-    probe.run(W, -np.inf)
-    acc = {k: [0.0, 0] for k in cands}
-    probe_ms, probe_blocks, t_probe = 0.0, 0, time.perf_counter()
-    while probe_blocks < max(1, min(args.max_blocks, (probe.max_iters - W - 16) // K)) and \
-            (probe_blocks == 0 or time.perf_counter() - t_probe < args.min_seconds / 2):
-        probe.run(K, -np.inf)                      # (like the timed region: blocks of exactly K steps, repeated to a
-        kt = probe.kernel_times()                  #  minimum duration -- one block of the driver's 20 steps is 6 ms)
-        for k in cands:
-            acc[k][0] += kt[k][0]
-            acc[k][1] += kt[k][1]
-        probe_ms += probe.last_run_ms()[0]
-        probe_blocks += 1
-    for k in cands:
-        per_kernel[k] = {'avg_us': 1e3 * acc[k][0] / acc[k][1], 'launches': acc[k][1]}
-    dom = max(cands, key=lambda k: per_kernel[k]['avg_us'])
-    probe_ms_per_step = probe_ms / (K * probe_blocks)
-    probe.close()
+    def headline(precision, max_iters, streams):
+        return make_batch(ctx, args.batch, args.T, args.S, args.D, precision, seed0=rank * args.batch,
+                          max_iters=max_iters, streams=streams)
+
+    per_kernel, dom, probe_ms_per_step, probe_blocks = kernel_probe(lambda mi, st: headline(args.precision, mi, st),
+                                                                     args.min_seconds / 2, args.max_blocks)
 
     # ---- the timed region: the library's default configuration, no per-kernel events
-    batch = make_batch(ctx, args.batch, args.T, args.S, args.D, args.precision, seed0=rank * args.batch,
-                       max_iters=budget, streams=args.streams)
+    batch = headline(args.precision, budget, args.streams)
     streams = batch.streams
     batch.run(W, -np.inf)
     times = timed_blocks(batch, args.min_seconds, args.max_blocks)
-    dev_ms_last = batch.last_run_ms()[0]
     res0 = batch.result(0, want_model=False)
     batch.close()
     med = statistics.median(times)
 
+    # ---- the other configurations of BASELINE.json, each with its own kernel-level figure (rank 0 measures what fits one
+    # GPU by itself; the multi-GPU metric is the batch above).  value = recording-iterations/s like the headline.
+    def one_config(name, make, n_rec, T, S, precision, note, min_seconds):
+        es = 4 if precision == 'fp32' else 8
+        pk, dk, _, _ = kernel_probe(make, min_seconds / 2, 16)
+        b = make(W + K * 18 + 16, None)
+        b.run(W, -np.inf)
+        ts = []
+        while sum(ts) < min_seconds and len(ts) < 16:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            b.run(K, -np.inf)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        elbo = float(b.result(0, want_gamma=False, want_model=False)['Li'][-1])
+        nstreams = b.streams
+        b.close()
+        dt = statistics.median(ts)
+        workload = {'batch': n_rec, 'T': T, 'S': S, 'D': args.D, 'precision': precision}
+        if name.startswith('C5'):
+            workload['sweep'] = name.split('_')[-1]
+        roof, _ = roofline_of(pk, dk, n_rec, T, S, args.D, es, workload)
+        fused = n_rec * (8 * T * args.D + 8 * T * S) * es / 4
+        return {'workload': note, 'precision': precision, 'recordings': n_rec, 'T': T, 'S': S, 'streams': nstreams,
+                'ms_per_iteration': 1e3 * dt / K, 'value': n_rec * K / dt, 'unit': 'recording-EM-iterations/s',
+                'blocks_of_K_steps': len(ts), 'seconds': sum(ts),
+                'dominant_kernel': dk, 'avg_us': roof['avg_launch_us'], 'algorithmic_bytes': roof['algorithmic_bytes_per_launch'],
+                'frac': roof['frac'], 'achieved_GBs': roof['achieved'], 'traffic': roof['traffic'],
+                'traffic_source': roof['traffic_source'],
+                'iteration_compulsory_bytes': fused, 'iteration_frac_of_hbm_peak': fused / (dt / K) / 1e9 / HBM_PEAK_GBS,
+                'kernels_avg_us': {k: round(v['avg_us'], 2) for k, v in pk.items()}, 'elbo_last': elbo}
+
+    configs = {}
+    if rank == 0 and not args.no_configs:
+        def single(T, S, precision, lp):
+            def make(mi, st):
+                from vbx_amd.synth import make_recording
+                b = _capi.Batch(ctx, [T], [S], args.D, precision=precision, max_iters=mi)
+                X, Phi, _ = make_recording(T, S, D=args.D, seed=0, kappa=0.05, dtype=np.float32)
+                g = np.random.default_rng(10_000).gamma(1.0, size=(T, S)).astype(np.float32)
+                g /= g.sum(1, keepdims=True)
+                b.set_recording(0, X, Phi, np.ones(S) / S, g, lp, 0.3, 17.0)
+                return b
+            return make
+        short = args.min_seconds / 4
+        for prec in ('fp32', 'fp64'):
+            configs[f'C2_T10k_S10_{prec}'] = one_config('C2', single(10000, 10, prec, 0.99), 1, 10000, 10, prec,
+                                                         'configs[1]: one recording, T=10 000, S=10, Fa=0.3 Fb=17 loopProb=0.99', short)
+            configs[f'C3_T50k_S30_{prec}'] = one_config('C3', single(50000, 30, prec, 0.99), 1, 50000, 30, prec,
+                                                         'configs[2]: one recording, T=50 000, S=30 (two-level boundary walk)', short)
+            for mode in ('shared', 'private'):
+                if mode == 'private' and prec == 'fp64':
+                    continue
+                configs[f'C5_T200k_S50_sweep9_{prec}_{mode}'] = one_config(
+                    f'C5_{mode}', lambda mi, st, prec=prec, mode=mode: make_sweep_batch(ctx, 200000, 50, args.D, prec, mi, mode == 'shared'),
+                    len(SWEEP_POINTS), 200000, 50, prec,
+                    'configs[4]: T=200 000, S=50, loopProb=0.9, the nine (Fa, Fb) points of the recipes as ONE batch, '
+                    + ('one rho shared by all points (vbx_batch_set_recording_shared)' if mode == 'shared'
+                       else 'every point with a private copy of the x-vectors (round 2)'), short)
+
     f64 = None
     if not args.no_f64 and args.precision == 'fp32':
-        b64 = make_batch(ctx, args.batch, args.T, args.S, args.D, 'fp64', seed0=rank * args.batch, max_iters=budget,
-                         streams=args.streams)
+        pk64, dk64, ms64, _ = kernel_probe(lambda mi, st: headline('fp64', mi, st), args.min_seconds / 4, args.max_blocks)
+        b64 = headline('fp64', budget, args.streams)
         b64.run(W, -np.inf)
         t64 = timed_blocks(b64, args.min_seconds / 2, args.max_blocks)
         b64.close()
-        f64 = t64
+        f64 = (t64, pk64, dk64, ms64)
 
-    single = None
+    single_rec = None
     if not args.no_single and rank == 0:
         b1 = make_batch(ctx, 1, args.T, args.S, args.D, args.precision, seed0=0, max_iters=W + 4 * K)
         b1.run(W, -np.inf)
@@ -279,15 +391,16 @@ def main():
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - t0)
         dt = statistics.median(ts)
-        single = {'value': K / dt, 'unit': 'EM iterations/s', 'ms_per_iteration': 1e3 * dt / K, 'batch': 1}
+        single_rec = {'value': K / dt, 'unit': 'EM iterations/s', 'ms_per_iteration': 1e3 * dt / K, 'batch': 1}
         b1.close()
 
     if rank == 0:
         total_units = world * args.batch * K
-        dom_bytes = args.batch * algo_bytes(dom, args.T, args.D, args.S, esize)      # one launch of the one-stream pass
-        achieved = dom_bytes / (per_kernel[dom]['avg_us'] * 1e-6) / 1e9
         workload = {'batch': args.batch, 'T': args.T, 'S': args.S, 'D': args.D, 'precision': args.precision}
-        traffic = pmc_traffic(dom, workload)                                        # (profiled with --streams 1)
+        roof, traffic = roofline_of(per_kernel, dom, args.batch, args.T, args.S, args.D, esize, workload)   # (profiled with --streams 1)
+        roof['measured'] = (f'HIP events over {probe_blocks} block(s) of K steps (after W warm-up steps) of the same batch on ONE '
+                            f'stream (VBX_OPT_STREAMS=1, {probe_ms_per_step:.4f} ms per step): a kernel-level figure needs the '
+                            'kernel alone on the GPU')
         out = {
             'metric': 'VB EM iterations/sec (T=10k xvecs, R=128, S=30)',
             'value': total_units / med,
@@ -314,15 +427,7 @@ def main():
             'kernels_avg_us': {k: round(v['avg_us'], 2) for k, v in per_kernel.items()},
             'kernels_avg_us_note': 'one-stream pass: the HBM-side kernels (ALGO_PASSES) over the K steps, the others over 8 survey iterations; '
                                    '"post" = the gamma write-out, once per run',
-            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic[0] if traffic else None,
-                         'traffic_source': traffic[1] if traffic else None,
-                         'algorithmic_bytes_per_launch': dom_bytes,
-                         'avg_launch_us': per_kernel[dom]['avg_us'],
-                         'measured': f'HIP events over {probe_blocks} block(s) of K steps (after W warm-up steps) of the same batch on ONE stream (VBX_OPT_STREAMS=1, '
-                                     f'{probe_ms_per_step:.4f} ms per step): a kernel-level figure needs the kernel alone '
-                                     'on the GPU'},
+            'roofline': roof,
             'gamma_checks': {'row_sum_max_dev': float(np.abs(res0['gamma'].sum(1) - 1).max()),
                              'elbo_last': float(res0['Li'][-1])},
         }
@@ -338,23 +443,34 @@ def main():
                  'note': 'survey_8d = 8TR + 28TS (one kernel per stage, SURVEY 8d); fused_compulsory = 8TR + 8TS: rho read '
                          'twice (the log-likelihoods need the alpha that needs the full-T reduction), b written and read '
                          'once, gamma and the lattices never leave the chip'}
-        if traffic and 'iteration_hbm_bytes' in traffic[2]:
+        if traffic[2] and 'iteration_hbm_bytes' in traffic[2]:
             whole['pmc_bytes_per_step'] = traffic[2]['iteration_hbm_bytes']
             whole['pmc_over_fused_compulsory'] = traffic[2]['iteration_hbm_bytes'] / fused_bytes
         out['roofline_whole_iteration'] = whole
         if f64:
-            m64 = statistics.median(f64)
+            t64, pk64, dk64, ms64 = f64
+            m64 = statistics.median(t64)
+            w64 = dict(workload, precision='fp64')
+            roof64, _ = roofline_of(pk64, dk64, args.batch, args.T, args.S, args.D, 8, w64)
             out['f64'] = {'value': total_units / m64, 'unit': 'recording-EM-iterations/s', 'ms_per_step': 1e3 * m64 / K,
-                          'blocks_of_K_steps': len(f64),
+                          'blocks_of_K_steps': len(t64), 'roofline': roof64,
+                          'kernels_avg_us': {k: round(v['avg_us'], 2) for k, v in pk64.items()},
+                          'one_stream_ms_per_step': ms64,
                           'note': 'same batch on the fp64 path (f64 storage, v_mfma_f64_16x16x4_f64): what vbhmm.py '
                                   'gets, its inputs being float64; reproduces the reference\'s iteration counts'}
-        if single:
-            out['single_recording'] = single
+        if configs:
+            out['configs'] = configs
+            out['configs_note'] = ('the other configurations of BASELINE.json, each measured like the headline: ms per EM iteration '
+                                   'over blocks of K steps (median), value = recording-iterations/s, and the dominant HBM-side '
+                                   'kernel of a one-stream pass with its algorithmic bytes / HIP-event time vs the 8 TB/s peak; '
+                                   'C5 counts nine recording-iterations per sweep iteration')
+        if single_rec:
+            out['single_recording'] = single_rec
         if world == 1 and args.cpu_iters > 0:
             cb = cpu_baseline(args.T, args.S, args.D, args.cpu_iters, args.precision)
             out['cpu_baseline'] = cb
-            if single:
-                out['single_recording']['speedup_vs_cpu_baseline'] = single['value'] / cb['value']
+            if single_rec:
+                out['single_recording']['speedup_vs_cpu_baseline'] = single_rec['value'] / cb['value']
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

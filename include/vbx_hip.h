@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VBX_ABI_VERSION 3
+#define VBX_ABI_VERSION 4
 
 /* error codes */
 #define VBX_OK 0
@@ -121,6 +121,16 @@ int vbx_batch_set_recording(vbx_batch* batch, int b, const void* X, int x_dtype,
                             const double* pi0, const void* gamma0, int g_dtype,
                             const double* alpha0, const double* invL0, double loopProb, double Fa,
                             double Fb);
+
+/* Recording b on the x-vectors of recording src_b of the same batch (same T; src_b set before): a sweep of Fa / Fb /
+ * loopProb over one recording -- the hyper-parameter grids of DIHARD2_run.sh:42-47, AMI_run.sh:44-49,
+ * CALLHOME_run.sh:42-47 around one VBx.py:87-89 rho -- keeps ONE rho in HBM, and the per-chunk kernels run the chunks that
+ * read the same rows of it side by side on one XCD, so that HBM delivers them once per kernel instead of once per sweep
+ * point.  Everything else (pi0, gamma0, alpha0 / invL0, results) is per recording as in vbx_batch_set_recording.  Setting
+ * src_b again unsets the recordings that share with it.  In a batch that runs on several streams both recordings must be
+ * in the same sub-batch (create sweeps with VBX_OPT_STREAMS = 1). */
+int vbx_batch_set_recording_shared(vbx_batch* batch, int b, int src_b, const double* pi0, const void* gamma0, int g_dtype,
+                                   const double* alpha0, const double* invL0, double loopProb, double Fa, double Fb);
 
 /* Run up to max_iters VB iterations on every recording (VBx.py:91-125).  A recording
  * stops on its own when ii > 0 and ELBO - previous < epsilon (VBx.py:122-125); its state

@@ -31,40 +31,37 @@ def test_cos_similarity_and_calibration_match_the_reference(ahc_cases):
         stats = np.array([scr.sum(), (scr ** 2).sum(), scr.min(), scr.max(), np.trace(scr)])
         np.testing.assert_allclose(stats, c['scr_stats'], rtol=1e-12, err_msg=name)
         assert np.abs(scr - scr.T).max() <= 1e-15
-        thr, llr = twoGMMcalib_lin(scr.ravel())                     # the resident device copy is calibrated
+        thr, llr = twoGMMcalib_lin(scr.ravel())
         assert isinstance(thr, np.float64) and llr.shape == (scr.size,)
         np.testing.assert_allclose(thr, c['thr'], rtol=1e-10, err_msg=name)
         np.testing.assert_allclose(llr[c['scr_sample_idx']], c['llr_sample'], rtol=1e-9, atol=1e-9, err_msg=name)
         llr_stats = np.array([llr.sum(), (llr ** 2).sum(), llr.min(), llr.max()])
         np.testing.assert_allclose(llr_stats, c['llr_stats'], rtol=1e-9, err_msg=name)
-        thr5, _ = twoGMMcalib_lin(scr.ravel().copy(), niters=5)     # a copy: uploaded, not the resident matrix
+        thr5, _ = twoGMMcalib_lin(scr.ravel().copy(), niters=5)
         np.testing.assert_allclose(thr5, c['thr5'], rtol=1e-10, err_msg=name)
 
 
-def test_resident_matrix_is_dropped_when_the_host_copy_changes_or_dies():
-    import gc
+def test_score_matrix_is_an_ordinary_array_and_in_place_edits_reach_the_calibration():
+    """The reference returns a plain writable matrix (diarization_lib.py:213) and callers edit it in place; whatever
+    they hand to twoGMMcalib_lin afterwards is what gets calibrated."""
     from vbx_amd import diarization_lib as dl
     from oracle import ahc_oracle
     x = np.random.default_rng(0).standard_normal((200, 32))
     scr = dl.cos_similarity(x)
-    assert dl._find_resident(scr.ravel()) is not None
-    assert dl._find_resident(scr.ravel()[:100]) is None and dl._find_resident(scr.T) is None
-    with pytest.raises(ValueError):                                  # the device copy stands for this array: read-only
-        scr[0, 0] = 0.25
-    edited = scr.copy()                                              # an editable copy is a new array: uploaded
-    edited[0, 0] = 0.25
-    assert dl._find_resident(edited.ravel()) is None
-    thr, _ = dl.twoGMMcalib_lin(edited.ravel())
-    np.testing.assert_allclose(thr, ahc_oracle.twoGMMcalib_lin(edited.ravel())[0], rtol=1e-10)
-    scr.flags.writeable = True                                       # someone forces a write anyway: the spot check at
-    scr.ravel()[::7] = 0.5                                           # the next use finds it and drops the device copy
-    n = len(dl._resident)
-    assert dl._find_resident(scr.ravel()) is None and len(dl._resident) == n - 1
-    scr2 = dl.cos_similarity(x)
-    n = len(dl._resident)
-    del scr2
-    gc.collect()
-    assert len(dl._resident) == n - 1
+    assert scr.flags.writeable and scr.flags.owndata and scr.flags.c_contiguous
+    ref = ahc_oracle.cos_similarity(x)
+    np.fill_diagonal(scr, 0.25)                                      # in-place edits of every kind ...
+    np.fill_diagonal(ref, 0.25)
+    scr *= -1
+    ref *= -1
+    scr[scr > 0.3] = 0.3
+    ref[ref > 0.3] = 0.3
+    thr, llr = dl.twoGMMcalib_lin(scr.ravel())                       # ... are what the calibration sees
+    thr_o, llr_o = ahc_oracle.twoGMMcalib_lin(ref.ravel())
+    np.testing.assert_allclose(thr, thr_o, rtol=1e-9)
+    np.testing.assert_allclose(llr, llr_o, rtol=1e-8, atol=1e-8)
+    with pytest.raises(ValueError):
+        dl.twoGMMcalib_lin(scr)                                      # 2-D: the reference's s[:, np.newaxis] would fail too
 
 
 @pytest.mark.parametrize('T,D', [(1, 8), (63, 5), (65, 128), (1000, 257)])

@@ -157,3 +157,23 @@ def test_c5_very_long_recording_sweep_points(ctx, precision):
         res = batch.result(k)
         check(tag, precision, config_diffs(cfg, tag, res['gamma'], res['pi'], res['Li'], res['alpha'], res['invL']), 2, T=200000)
     batch.close()
+
+
+@pytest.mark.parametrize('precision', ['fp64', 'fp32'])
+def test_c5_sweep_on_one_shared_rho(ctx, precision):
+    """configs[4] as the library runs a sweep: ONE rho for all points (vbx_batch_set_recording_shared), tiles dealt to the
+    XCDs so that the chunks reading the same rows run side by side; the two points the reference computed."""
+    from vbx_amd import _capi
+    cfg = load_config('c5')
+    X, Phi, g0 = config_inputs(cfg, 'c5', g0_seed=4)
+    points = [(0.3, 17.0), (0.2, 6.0), (0.4, 64.0)]
+    batch = _capi.Batch(ctx, [X.shape[0]] * 3, [50] * 3, 128, precision=precision, max_iters=2)
+    batch.set_recording(0, X, Phi, np.ones(50) / 50, g0, 0.9, *points[0])
+    for k in (1, 2):
+        batch.set_recording_shared(k, 0, np.ones(50) / 50, g0, 0.9, *points[k])
+    batch.run(2, -np.inf)
+    for k, (fa, fb) in enumerate(points[:2]):
+        tag = f'c5/fa{fa}_fb{fb:g}/it2'
+        res = batch.result(k)
+        check(tag + '/shared', precision, config_diffs(cfg, tag, res['gamma'], res['pi'], res['Li'], res['alpha'], res['invL']), 2, T=200000)
+    batch.close()

@@ -477,6 +477,76 @@ def test_fa_fb_sweep_c5_shares_nothing_but_the_inputs(ctx):
         assert np.abs(gr - single_two_iters(ctx, X, Phi, g0, S, fa, fb)).max() <= 2e-7
 
 
+@pytest.mark.parametrize('precision', ['fp64', 'fp32'])
+def test_fa_fb_sweep_on_one_shared_rho_equals_independent_recordings(ctx, precision):
+    """vbx_batch_set_recording_shared: the nine points of the sweep read ONE rho (the first recording's) and the per-chunk
+    kernels walk the tiles in the XCD-aware order; every point must come out as it does with nine private copies -- the
+    arithmetic of a recording does not depend on where its rho lies or in which order the workgroups start.  Includes a
+    point with its own loopProb and speaker count, a source that is itself a sharer, and the error paths."""
+    from vbx_amd import _capi
+    from vbx_amd.synth import make_recording
+    T, S = 3000, 50
+    X, Phi, _ = make_recording(T, S, seed=9, kappa=0.05)
+    g0 = np.random.default_rng(10).gamma(1.0, size=(T, S))
+    g0 /= g0.sum(1, keepdims=True)
+    sweep = [(fa, fb, 0.9, S) for fa in (0.2, 0.3, 0.4) for fb in (6.0, 17.0, 64.0)]
+    sweep[5] = (0.3, 17.0, 0.6, 37)                     # another loop probability and fewer speakers on the same x-vectors
+    n = len(sweep)
+
+    def init(s):
+        g = g0[:, :s] / g0[:, :s].sum(1, keepdims=True)
+        return np.ones(s) / s, g
+
+    private = _capi.Batch(ctx, [T] * n, [p[3] for p in sweep], 128, precision=precision, max_iters=5)
+    for k, (fa, fb, lp, s) in enumerate(sweep):
+        private.set_recording(k, X, Phi, *init(s), lp, fa, fb)
+    private.run(5, -np.inf)
+    want = [private.result(k) for k in range(n)]
+    private.close()
+    shared = _capi.Batch(ctx, [T] * n, [p[3] for p in sweep], 128, precision=precision, max_iters=5)
+    with pytest.raises(_capi.VbxError):                 # the source has to be there first
+        shared.set_recording_shared(1, 0, *init(S), 0.9, 0.3, 17.0)
+    for k, (fa, fb, lp, s) in enumerate(sweep):
+        if k == 0:
+            shared.set_recording(0, X, Phi, *init(s), lp, fa, fb)
+        else:
+            shared.set_recording_shared(k, 0 if k < 7 else 3, *init(s), lp, fa, fb)     # (3 shares itself: same rho)
+    shared.run(5, -np.inf)
+    for k in range(n):
+        got = shared.result(k)
+        for key in ('gamma', 'pi', 'Li', 'alpha', 'invL'):
+            assert np.array_equal(got[key], want[k][key]), (k, key, np.abs(got[key] - want[k][key]).max())
+    # setting the source again unsets its sharers: the batch refuses to run until they are set again
+    shared.set_recording(0, X, Phi, *init(S), 0.9, 0.2, 6.0)
+    with pytest.raises(_capi.VbxError):
+        shared.run(1, -np.inf)
+    shared.close()
+    other = _capi.Batch(ctx, [T, T + 1], [S, S], 128, precision=precision, max_iters=2)
+    other.set_recording(0, X, Phi, *init(S), 0.9, 0.3, 17.0)
+    with pytest.raises((_capi.VbxError, AssertionError)):      # another length cannot share (wrapper and library both check)
+        other.set_recording_shared(1, 0, np.ones(S) / S, np.vstack([g0, g0[:1]]), 0.9, 0.3, 17.0)
+    other.close()
+
+
+def test_python_sweep_api_equals_one_call_per_point(synth_cases):
+    """vbx_amd.batch.VBx_sweep == [VBx(X, Phi, **point) ...]: same tuples, same global-RNG draws in list order."""
+    import vbx_amd
+    from vbx_amd.batch import VBx_sweep
+    from vbx_amd.synth import make_recording
+    X, Phi, _ = make_recording(1500, 9, seed=21, kappa=0.05)
+    points = [dict(Fa=0.2, Fb=6.0), dict(Fa=0.3, Fb=17.0, loopProb=0.99), dict(Fa=0.4, Fb=64.0, pi=6)]
+    np.random.seed(7)
+    got = VBx_sweep(X, Phi, points, maxIters=6, epsilon=1e-6, loopProb=0.9, pi=9, return_model=True)
+    np.random.seed(7)
+    for p, g in zip(points, got):
+        kw = dict(dict(loopProb=0.9, pi=9), **p)
+        want = vbx_amd.VBx(X, Phi, maxIters=6, epsilon=1e-6, return_model=True, **kw)
+        assert len(g) == 5 and len(g[2]) == len(want[2])
+        for a, b in zip(g, want):
+            np.testing.assert_allclose(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64), rtol=0, atol=1e-12)
+    assert VBx_sweep(X, Phi, [], maxIters=3) == []
+
+
 def single_two_iters(ctx, X, Phi, g0, S, fa, fb):
     from vbx_amd import _capi
     b = _capi.Batch(ctx, [X.shape[0]], [S], 128, precision='fp64', max_iters=2)

@@ -22,7 +22,7 @@ def test_library_builds_and_exports_the_declared_abi():
     path = build.build()
     assert os.path.exists(path)
     lib = _capi.load()
-    assert lib.vbx_abi_version() == 3
+    assert lib.vbx_abi_version() == 4
     syms = declared_symbols()
     assert set(syms) == set(_capi.ABI_SYMBOLS), set(syms) ^ set(_capi.ABI_SYMBOLS)
     exported = subprocess.run(['nm', '-D', '--defined-only', path], capture_output=True, text=True).stdout
@@ -117,10 +117,12 @@ def test_batch_api_rejects_arguments_it_would_ignore():
     from vbx_amd.batch import _normalise
     rec = dict(X=np.zeros((4, 3)), Phi=np.ones(3), pi=2, gamma=np.full((4, 2), 0.5))
     assert _normalise(rec, dict(Fa=0.3))['Fa'] == 0.3
-    with pytest.raises(TypeError, match='maxIters'):
-        _normalise(dict(rec, maxIters=3), {})
-    with pytest.raises(TypeError, match='looprob'):
+    with pytest.warns(UserWarning, match='maxIters'):             # a dict built for VBx(**kw): the per-batch arguments
+        assert _normalise(dict(rec, maxIters=3, return_model=True, ref=None), {})['Fb'] == 1.0     # are ignored, loudly
+    with pytest.raises(TypeError, match='looprob'):                 # a typo is an error, not silence
         _normalise(rec, dict(looprob=0.5))
+    with pytest.raises(TypeError, match='Fc'):
+        _normalise(dict(rec, Fc=1.0), {})
 
 
 def test_drop_in_module_exports_reference_names():

@@ -23,13 +23,19 @@ def main():
     ap.add_argument('--D', type=int, default=128)
     ap.add_argument('--precision', default='fp32')
     ap.add_argument('--iters', type=int, default=40)
+    ap.add_argument('--sweep', choices=['private', 'shared'], default=None,
+                    help='the nine-point Fa/Fb sweep over ONE recording (bench.make_sweep_batch) instead of --batch recordings')
     ap.add_argument('--tag', default=os.path.basename(os.environ.get('VBX_AMD_LIB', 'default')))
     args = ap.parse_args()
     from vbx_amd import _capi
     ctx = _capi.Context(0)
     n = args.iters
     out = {'tag': args.tag}
-    b = make_batch(ctx, args.batch, args.T, args.S, args.D, args.precision, 0, 3 * n + 8, streams=1)
+    if args.sweep:
+        from bench import make_sweep_batch
+        b = make_sweep_batch(ctx, args.T, args.S, args.D, args.precision, 3 * n + 8, args.sweep == 'shared')
+    else:
+        b = make_batch(ctx, args.batch, args.T, args.S, args.D, args.precision, 0, 3 * n + 8, streams=1)
     b.run(4, -np.inf)
     b.profile_kernels(None)
     b.run(n, -np.inf)
@@ -39,6 +45,9 @@ def main():
     out['one_stream_ms_per_iter'] = round(b.last_run_ms()[0] / n, 4)
     out['elbo_rec0'] = float(b.result(0, want_gamma=False, want_model=False)['Li'][-1])
     b.close()
+    if args.sweep:
+        print(json.dumps(out))
+        return
     b = make_batch(ctx, args.batch, args.T, args.S, args.D, args.precision, 0, 2 * n + 8)
     b.run(8, -np.inf)
     t0 = time.perf_counter()

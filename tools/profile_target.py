@@ -22,11 +22,19 @@ def main():
     ap.add_argument('--precision', default='fp32')
     ap.add_argument('--streams', type=int, default=None)
     ap.add_argument('--iters', type=int, default=12)
+    ap.add_argument('--sweep', choices=['private', 'shared'], default=None,
+                    help='the nine-point Fa/Fb sweep over ONE recording of --T x --S (bench.make_sweep_batch)')
     a = ap.parse_args()
     from vbx_amd import _capi
     ctx = _capi.Context(0)
-    b = make_batch(ctx, a.batch, a.T, a.S, a.D, a.precision, 0, a.iters + 4, streams=a.streams)
+    if a.sweep:
+        from bench import make_sweep_batch, SWEEP_POINTS
+        b = make_sweep_batch(ctx, a.T, a.S, a.D, a.precision, a.iters + 4, a.sweep == 'shared')
+        a.batch = len(SWEEP_POINTS)
+    else:
+        b = make_batch(ctx, a.batch, a.T, a.S, a.D, a.precision, 0, a.iters + 4, streams=a.streams)
     b.run(a.iters, -np.inf)
+    print('workload', f'batch={a.batch} T={a.T} S={a.S} D={a.D} precision={a.precision}' + (f' sweep={a.sweep}' if a.sweep else ''))
     print('iterations', a.iters, 'ms per iteration', b.last_run_ms()[0] / a.iters, 'streams', b.streams)
     b.close()
 

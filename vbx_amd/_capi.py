@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     'vbx_scores_two_gmm_calib',
     'vbx_scores_destroy',
     'vbx_xvectors_project', 'vbx_xvectors_get', 'vbx_xvectors_destroy', 'vbx_cos_similarity_resident',
-    'vbx_batch_set_recording_resident', 'vbx_batch_get_labels',
+    'vbx_batch_set_recording_resident', 'vbx_batch_get_labels', 'vbx_batch_set_recording_shared',
 ]
 
 
@@ -103,6 +103,7 @@ def load():
     lib.vbx_cos_similarity_resident.argtypes = [vp, vp, i64, i64, C.POINTER(vp)]
     lib.vbx_batch_set_recording_resident.argtypes = [vp, C.c_int, vp, i64, vp, dbl, vp, dbl, dbl, dbl]
     lib.vbx_batch_get_labels.argtypes = [vp, C.c_int, vp, vp]
+    lib.vbx_batch_set_recording_shared.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, dbl, dbl, dbl]
     for name in ABI_SYMBOLS:
         fn = getattr(lib, name)          # AttributeError here = the .so does not export the ABI
         if name in ('vbx_scores_count', 'vbx_ark_index'):
@@ -392,6 +393,19 @@ class Batch:
             self._h, int(b), _ptr(X), VBX_F32 if X.dtype == np.float32 else VBX_F64, _ptr(Phi), _ptr(pi0),
             _ptr(gamma0), VBX_F32 if gamma0.dtype == np.float32 else VBX_F64, _ptr(alpha0), _ptr(invL0),
             float(loopProb), float(Fa), float(Fb)), 'vbx_batch_set_recording')
+
+    def set_recording_shared(self, b, src, pi0, gamma0, loopProb, Fa, Fb, alpha0=None, invL0=None):
+        """Recording b on the x-vectors (rho, Phi) of recording ``src`` of this batch, set before: one point of an
+        Fa / Fb / loopProb sweep over one recording (vbx_batch_set_recording_shared)."""
+        gamma0 = np.ascontiguousarray(gamma0)
+        if gamma0.dtype != np.float32:
+            gamma0 = np.ascontiguousarray(gamma0, dtype=np.float64)
+        assert gamma0.shape == (self.T[b], self.S[b]) and self.T[b] == self.T[src]
+        pi0, alpha0, invL0 = _f64(pi0), _f64(alpha0), _f64(invL0)
+        assert pi0.shape == (self.S[b],)
+        self.ctx.check(self._lib.vbx_batch_set_recording_shared(
+            self._h, int(b), int(src), _ptr(pi0), _ptr(gamma0), VBX_F32 if gamma0.dtype == np.float32 else VBX_F64,
+            _ptr(alpha0), _ptr(invL0), float(loopProb), float(Fa), float(Fb)), 'vbx_batch_set_recording_shared')
 
     def set_recording_resident(self, b, xv: 'XVectors', row0, labels, init_smoothing, Phi, loopProb, Fa, Fb):
         """Recording b from resident rows of ``xv.fea`` and the AHC labels: initial responsibilities

@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import numpy as np
 
-__all__ = ['shard_recordings', 'VBx_batch', 'VBx_batch_distributed']
+__all__ = ['shard_recordings', 'VBx_batch', 'VBx_sweep', 'VBx_batch_distributed']
 
 
 def shard_recordings(costs, world_size: int):
@@ -29,16 +29,28 @@ def shard_recordings(costs, world_size: int):
     return assignment
 
 
+# VBx() keyword arguments that mean something per recording, and the ones that only exist per batch / per call: the
+# latter are accepted in a recording's dict (a dict built for VBx(**kw) can be passed as it is) and ignored with a warning
+# when they differ from what the batch runs with
+PER_RECORDING = ('loopProb', 'Fa', 'Fb', 'pi', 'gamma', 'alphaQInit', 'alpha', 'invL')
+PER_BATCH = ('maxIters', 'epsilon', 'return_model', 'ref', 'plot', 'precision', 'device')
+
+
 def _normalise(rec, defaults):
     """rec: dict with X, Phi and optional VBx() keyword arguments -> full argument dict."""
     kw = dict(loopProb=0.9, Fa=1.0, Fb=1.0, pi=10, gamma=None, alphaQInit=1.0, alpha=None, invL=None)
     for where in (defaults, rec):
-        bad = set(where) - set(kw) - {'X', 'Phi'}
-        if bad:            # maxIters / epsilon are per batch; anything else is a typo that would be ignored silently
-            raise TypeError(f'VBx_batch: unexpected per-recording argument(s) {sorted(bad)} (maxIters and epsilon '
-                            'apply to the whole batch)')
-    kw.update(defaults)
-    kw.update({k: v for k, v in rec.items() if k not in ('X', 'Phi')})
+        bad = set(where) - set(PER_RECORDING) - set(PER_BATCH) - {'X', 'Phi'}
+        if bad:            # a typo would otherwise be ignored silently
+            raise TypeError(f'VBx_batch: unexpected per-recording argument(s) {sorted(bad)}; accepted: '
+                            f'{", ".join(PER_RECORDING)} (and, ignored, the per-batch ones: {", ".join(PER_BATCH)})')
+        ignored = sorted(k for k in where if k in PER_BATCH and where[k] is not None and where[k] is not False)
+        if ignored and where is rec:
+            import warnings
+            warnings.warn(f'VBx_batch: {ignored} in a recording\'s arguments apply to the whole batch (pass them to '
+                          'VBx_batch itself); ignored here', stacklevel=3)
+    kw.update({k: v for k, v in defaults.items() if k in PER_RECORDING})
+    kw.update({k: v for k, v in rec.items() if k in PER_RECORDING})
     X = np.asarray(rec['X'])
     pi = kw['pi']
     if type(pi) is int:                                   # VBx.py:76-77
@@ -84,16 +96,63 @@ def VBx_batch(recordings, maxIters=10, epsilon=1e-4, precision=None, device=None
               **defaults):
     """``[VBx(**rec, maxIters=..., epsilon=...) for rec in recordings]`` on one GPU, in one batch.
 
-    Each recording is a dict with ``X`` and ``Phi`` plus any of VBx()'s keyword arguments;
-    ``defaults`` supplies shared hyper-parameters; ``maxIters`` and ``epsilon`` apply to the whole batch.  ``precision``
-    follows VBx(): fp64 kernels unless every X is float32 (or VBX_AMD_PRECISION / the argument says otherwise), so the
-    numerics and iteration counts are those of one VBx() call per recording.  Returns a list of ``(gamma, pi, Li[,
+    Each recording is a dict with ``X`` and ``Phi`` plus the per-recording keyword arguments of VBx(): ``loopProb``,
+    ``Fa``, ``Fb``, ``pi``, ``gamma``, ``alphaQInit``, ``alpha``, ``invL``; ``defaults`` supplies shared values of the
+    same.  ``maxIters``, ``epsilon``, ``return_model``, ``precision`` and ``device`` apply to the whole batch: given in a
+    recording's dict they are ignored with a warning (``ref`` / ``plot`` need the responsibilities on the host every
+    iteration and are a VBx() feature only); any other key is a TypeError.  ``precision`` follows VBx(): fp64 kernels
+    unless every X is float32 (or VBX_AMD_PRECISION / the argument says otherwise) -- NB before round 2 the default was
+    fp32 whatever the input type -- so the numerics and iteration counts are those of one VBx() call per recording.  Returns a list of ``(gamma, pi, Li[,
     alpha, invL])`` tuples in input order (same types as the reference returns, VBx.py:126)."""
     items = [_normalise(r, defaults) for r in recordings]
     if maxIters <= 0:
         return [(it['gamma'], it['pi'], []) + ((it['alpha'], it['invL']) if return_model else ())
                 for it in items]
     raw = run_shard_hip(items, int(maxIters), epsilon, precision=precision, device=device)
+    return [_as_tuple(r, return_model) for r in raw]
+
+
+def run_sweep_hip(X, Phi, items, maxIters, epsilon, precision=None, device=None):
+    """Normalised sweep points over ONE recording on the local GPU: one vbx_batch, one rho (the first point owns it, the
+    others share it: vbx_batch_set_recording_shared), one stream."""
+    from . import _capi
+    from .VBx import _pick_precision
+    ctx = _capi.default_context(device)
+    T, D = X.shape
+    batch = _capi.Batch(ctx, [T] * len(items), [len(it['pi']) for it in items], D, precision=_pick_precision(precision, X),
+                        max_iters=maxIters)
+    try:
+        if batch.streams != 1:
+            batch.set_option(_capi.OPT_STREAMS, 1)        # sharing works inside one device arena
+        for j, it in enumerate(items):
+            if j == 0:
+                batch.set_recording(0, X, Phi, it['pi'], it['gamma'], it['loopProb'], it['Fa'], it['Fb'],
+                                    alpha0=it['alpha'], invL0=it['invL'])
+            else:
+                batch.set_recording_shared(j, 0, it['pi'], it['gamma'], it['loopProb'], it['Fa'], it['Fb'],
+                                           alpha0=it['alpha'], invL0=it['invL'])
+        batch.run(maxIters, epsilon)
+        return [batch.result(j) for j in range(len(items))]
+    finally:
+        batch.close()
+
+
+def VBx_sweep(X, Phi, points, maxIters=10, epsilon=1e-4, precision=None, device=None, return_model=False, **defaults):
+    """``[VBx(X, Phi, **defaults, **p, maxIters=..., epsilon=...) for p in points]`` -- a hyper-parameter sweep over ONE
+    recording, the grids of the reference's recipes (DIHARD2_run.sh:42-47, AMI_run.sh:44-49, CALLHOME_run.sh:42-47:
+    Fa x Fb x loopP around one x-vector sequence) -- as one batch on one GPU with ONE rho = X * sqrt(Phi) (VBx.py:89) in
+    HBM: the per-chunk kernels run the chunks of all points that read the same rows of it side by side, so HBM delivers
+    the x-vectors once per kernel and not once per point.  ``points``: dicts of the per-recording keyword arguments of
+    VBx() (``Fa``, ``Fb``, ``loopProb``, ``pi``, ``gamma``, ``alphaQInit``, ``alpha``, ``invL``).  ``gamma=None`` draws the
+    initialisation from the global RNG per point, in list order, exactly as successive VBx() calls would.  Returns the
+    list of ``(gamma, pi, Li[, alpha, invL])`` tuples."""
+    X = np.asarray(X)
+    items = [_normalise(dict(p, X=X, Phi=Phi), defaults) for p in points]
+    if maxIters <= 0:
+        return [(it['gamma'], it['pi'], []) + ((it['alpha'], it['invL']) if return_model else ()) for it in items]
+    if not items:
+        return []
+    raw = run_sweep_hip(X, np.asarray(Phi), items, int(maxIters), epsilon, precision=precision, device=device)
     return [_as_tuple(r, return_model) for r in raw]
 
 

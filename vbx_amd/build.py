@@ -17,6 +17,21 @@ HEADERS = ['vbx_device.hpp', 'vbx_kernels.hpp', 'vbx_scan.hpp', 'vbx_scan_wide.h
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-Wno-pass-failed']
 
 
+# the sources that decide what the kernels of an EM iteration do and move: profiles/*_pmc_traffic.json carries their
+# hash, and bench.py only quotes a PMC figure whose hash matches the tree it runs from
+ITERATION_SOURCES = ['vbx_capi.hip', 'vbx_device.hpp', 'vbx_kernels.hpp', 'vbx_scan.hpp', 'vbx_operator.hpp',
+                     'vbx_chunk_loglik.hpp', 'vbx_chunk_post.hpp']
+
+
+def iteration_source_hash() -> str:
+    import hashlib
+    h = hashlib.sha256()
+    for f in ITERATION_SOURCES:
+        with open(os.path.join(CSRC, f), 'rb') as fh:
+            h.update(f.encode() + b'\0' + fh.read())
+    return h.hexdigest()[:16]
+
+
 def _hipcc() -> str:
     for cand in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
         if cand and os.path.exists(cand):

@@ -143,6 +143,12 @@ struct vbx_batch {
     RecDesc* d_recs = nullptr;
     RecState* d_state = nullptr;
     int *d_tile_rec = nullptr, *d_tile_t0 = nullptr, *d_tile_done = nullptr;
+    // recordings that share a rho (vbx_batch_set_recording_shared): who shares with whom, and the workgroup -> tile table
+    // that puts the chunks reading one rho tile side by side on one XCD
+    std::vector<int> share_src;                   // recording -> the recording whose rho it reads (itself: owns its rho)
+    int* d_tile_order = nullptr;
+    int nblocks_chunk = 0;                        // grid of the per-chunk kernels (ntiles_total, or the padded table)
+    bool order_dirty = false;
     int4* d_tile_desc = nullptr;
     double *d_phi = nullptr, *d_sqrt_phi = nullptr, *d_gtile = nullptr;
     void *d_rho = nullptr, *d_gamma = nullptr, *d_bmat = nullptr, *d_mrow = nullptr, *d_ahat = nullptr,
@@ -185,6 +191,7 @@ struct vbx_batch {
         v.n_rec = n_rec; v.Sp = Sp; v.Dp = Dp; v.D = D; v.max_iters = max_iters;
         v.ntiles_total = ntiles_total;
         v.recs = d_recs; v.state = d_state; v.tile_rec = d_tile_rec; v.tile_t0 = d_tile_t0; v.tile_desc = d_tile_desc; v.tile_done = d_tile_done;
+        v.tile_order = d_tile_order;
         v.phi = d_phi;
         v.rho = (R*)d_rho; v.gamma = (R*)d_gamma; v.bmat = (R*)d_bmat; v.mrow = (R*)d_mrow;
         v.ahat = (R*)d_ahat; v.bhat = (R*)d_bhat; v.alpha = (R*)d_alpha; v.invL = (R*)d_invL;
@@ -276,7 +283,7 @@ static int small_kernel_threads(const vbx_batch* b, int from_tiles) {
 // chunk_post over the tiles of the batch; REPLAY: the instance that only writes the responsibilities
 template <typename R, int SP, bool REPLAY> void launch_chunk_post(vbx_batch* b, const BatchView<R>& v) {
     if constexpr (ChunkPostCfg<R, SP>::kFits)
-        hipLaunchKernelGGL((chunk_post_kernel<R, SP, REPLAY>), dim3(b->ntiles_total), dim3(256), 0, b->ctx->stream, v);
+        hipLaunchKernelGGL((chunk_post_kernel<R, SP, REPLAY>), dim3(b->nblocks_chunk), dim3(256), 0, b->ctx->stream, v);
 }
 
 template <typename R, int SP> void launch_scan(vbx_batch* b, const BatchView<R>& v, bool fused_post, bool fused_loglik) {
@@ -285,7 +292,7 @@ template <typename R, int SP> void launch_scan(vbx_batch* b, const BatchView<R>&
     if constexpr (ChunkLoglikCfg<R, SP>::kFits) {
         if (fused_loglik) {      // log-likelihoods and the chunk operators in one pass over rho
             LaunchScope ls(b, VBX_K_CHUNK_LOGLIK);
-            hipLaunchKernelGGL((chunk_loglik_kernel<R, SP>), dim3(b->ntiles_total), dim3(256), 0, st, v);
+            hipLaunchKernelGGL((chunk_loglik_kernel<R, SP>), dim3(b->nblocks_chunk), dim3(256), 0, st, v);
             have_op = true;
         }
     }
@@ -570,7 +577,49 @@ int choose_fb_algo(vbx_batch* b, bool step_api_logs) {
     return VBX_OK;
 }
 
+// Workgroup -> tile table of the per-chunk kernels for a batch in which recordings share a rho (an Fa / Fb sweep over
+// one recording).  Block b of a grid runs on XCD b % 8 (observed on gfx950; a speed assumption only, nothing depends on
+// it for correctness) and each XCD has its own L2, so the tiles that read the same 128 rows of rho -- chunk c of every
+// recording of a sharing group -- get block ids with the same residue and consecutive quotients: they are dispatched
+// back to back to one XCD, the first one pulls the rho tile from HBM and the others find it in that L2.  Units (group,
+// chunk) are dealt to the XCD with the fewest blocks so far; positions left over at the end hold -1 (the block exits).
+int build_tile_order(vbx_batch* b) {
+    if (!b->order_dirty) return VBX_OK;
+    b->order_dirty = false;
+    ctx_free(b->ctx, b->d_tile_order);
+    b->d_tile_order = nullptr;
+    b->nblocks_chunk = b->ntiles_total;
+    bool any = false;
+    for (int i = 0; i < b->n_rec; ++i) any = any || b->share_src[i] != i;
+    if (!any) return VBX_OK;
+    std::vector<std::vector<int>> members(b->n_rec);
+    for (int i = 0; i < b->n_rec; ++i) members[b->share_src[i]].push_back(i);
+    constexpr int kXcds = 8;
+    std::vector<std::vector<int>> lists(kXcds);
+    for (int owner = 0; owner < b->n_rec; ++owner) {
+        if (members[owner].empty()) continue;
+        for (int c = 0; c < b->recs[owner].ntiles; ++c) {
+            int x = 0;
+            for (int y = 1; y < kXcds; ++y)
+                if (lists[y].size() < lists[x].size()) x = y;
+            for (int m : members[owner]) lists[x].push_back(b->recs[m].tile0 + c);
+        }
+    }
+    size_t len = 0;
+    for (auto& l : lists) len = std::max(len, l.size());
+    std::vector<int> order(kXcds * len, -1);
+    for (int x = 0; x < kXcds; ++x)
+        for (size_t k = 0; k < lists[x].size(); ++k) order[kXcds * k + x] = lists[x][k];
+    int rc = dmalloc(b->ctx, &b->d_tile_order, order.size());
+    if (rc != VBX_OK) return rc;
+    HIPCHK(b->ctx, hipMemcpyAsync(b->d_tile_order, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice, b->ctx->stream));
+    HIPCHK(b->ctx, hipStreamSynchronize(b->ctx->stream));
+    b->nblocks_chunk = (int)order.size();
+    return VBX_OK;
+}
+
 int upload_recs(vbx_batch* b) {
+    if (int rc = build_tile_order(b); rc != VBX_OK) return rc;
     if (!b->recs_dirty) return VBX_OK;
     HIPCHK(b->ctx, hipMemcpyAsync(b->d_recs, b->recs.data(), sizeof(RecDesc) * b->n_rec, hipMemcpyHostToDevice,
                                   b->ctx->stream));
@@ -680,7 +729,7 @@ static int leaf_destroy(vbx_batch* b) {
                     b->d_bias, b->d_mpart, b->d_npart, b->d_lraw, b->d_emodel, b->d_pi, b->d_epart, b->d_Li,
                     b->d_xstage, b->d_ip, b->d_fw_scale, b->d_bw_scale, b->d_op, b->d_fbound, b->d_gbound,
                     b->d_opexp, b->d_tllpart, b->d_sfw, b->d_dump, b->d_sop, b->d_sopexp, b->d_sup_rec, b->d_sup_idx,
-                    b->d_gamma0, b->d_pi_prev, b->d_oph, b->d_ophexp, b->d_cop, b->d_lppow};
+                    b->d_gamma0, b->d_pi_prev, b->d_oph, b->d_ophexp, b->d_cop, b->d_lppow, b->d_tile_order};
     (void)hipStreamSynchronize(b->ctx->stream);               // nothing of this batch may still be running when its
     for (void* p : ptrs) ctx_free(b->ctx, p);                 // blocks go back to the spare list
     if (b->ev_start) (void)hipEventDestroy(b->ev_start);
@@ -728,7 +777,7 @@ static int leaf_create(vbx_ctx* ctx, int n_rec, const int64_t* T, const int32_t*
     for (int i = 0; i < n_rec; ++i) {
         RecDesc& rd = b->recs[i];
         std::memset(&rd, 0, sizeof rd);
-        rd.row0 = row;
+        rd.row0 = rd.rho_row0 = row;
         rd.T = (int)T[i];
         rd.S = S[i];
         rd.tile0 = (int)tile_rec.size();
@@ -741,7 +790,9 @@ static int leaf_create(vbx_ctx* ctx, int n_rec, const int64_t* T, const int32_t*
         maxT = std::max<long long>(maxT, rd.T);
     }
     b->sum_T = row;
-    b->ntiles_total = (int)tile_rec.size();
+    b->ntiles_total = b->nblocks_chunk = (int)tile_rec.size();
+    b->share_src.resize(n_rec);
+    for (int i = 0; i < n_rec; ++i) b->share_src[i] = i;
     std::vector<int4> tile_desc;
     for (int t = 0; t < b->ntiles_total; ++t) {
         const RecDesc& rd = b->recs[tile_rec[t]];
@@ -855,20 +906,27 @@ int set_recording_impl(vbx_batch* b, int rec, const void* X, int x_dtype, const 
     const long long T = rd.T;
     // Phi, sqrt(Phi) (padded dims: 0)
     std::vector<double> phi(Dp, 0.0), sphi(Dp, 0.0);
-    for (int d = 0; d < D; ++d) {
+    for (int d = 0; X && d < D; ++d) {
         if (!(Phi[d] > 0.0)) FAIL(ctx, VBX_ERR_INVALID, "Phi[%d] must be positive", d);
         phi[d] = Phi[d];
         sphi[d] = std::sqrt(Phi[d]);
     }
-    HIPCHK(ctx, hipMemcpyAsync(b->d_phi + (size_t)rec * Dp, phi.data(), sizeof(double) * Dp, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(b->d_sqrt_phi, sphi.data(), sizeof(double) * Dp, hipMemcpyHostToDevice, ctx->stream));
-    // X -> staging -> rho, G
-    const size_t xbytes = (size_t)T * D * (x_dtype == VBX_F64 ? 8 : 4);
-    HIPCHK(ctx, hipMemcpyAsync(b->d_xstage, X, xbytes, hipMemcpyHostToDevice, ctx->stream));
-    if (x_dtype == VBX_F64) launch_prep<R, double>(b, rd); else launch_prep<R, float>(b, rd);
-    HIPCHK(ctx, hipGetLastError());
-    std::vector<double> gt(rd.ntiles);
-    HIPCHK(ctx, hipMemcpyAsync(gt.data(), b->d_gtile + rd.tile0, sizeof(double) * rd.ntiles, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<double> gt;
+    if (X) {
+        HIPCHK(ctx, hipMemcpyAsync(b->d_phi + (size_t)rec * Dp, phi.data(), sizeof(double) * Dp, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(b->d_sqrt_phi, sphi.data(), sizeof(double) * Dp, hipMemcpyHostToDevice, ctx->stream));
+        // X -> staging -> rho, G
+        const size_t xbytes = (size_t)T * D * (x_dtype == VBX_F64 ? 8 : 4);
+        HIPCHK(ctx, hipMemcpyAsync(b->d_xstage, X, xbytes, hipMemcpyHostToDevice, ctx->stream));
+        if (x_dtype == VBX_F64) launch_prep<R, double>(b, rd); else launch_prep<R, float>(b, rd);
+        HIPCHK(ctx, hipGetLastError());
+        gt.resize(rd.ntiles);
+        HIPCHK(ctx, hipMemcpyAsync(gt.data(), b->d_gtile + rd.tile0, sizeof(double) * rd.ntiles, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        // shared rho: Phi (and with it sum_t G_t) of the recording this one shares its x-vectors with
+        const int src = b->share_src[rec];
+        HIPCHK(ctx, hipMemcpyAsync(b->d_phi + (size_t)rec * Dp, b->d_phi + (size_t)src * Dp, sizeof(double) * Dp, hipMemcpyDeviceToDevice, ctx->stream));
+    }
     // gamma0, pi0 (padded speakers: 0)
     std::vector<R> gp;
     if (g_dtype == VBX_F64) pack_matrix<R, double>(gp, (const double*)gamma0, T, S, Sp, (R)0);
@@ -895,9 +953,13 @@ int set_recording_impl(vbx_batch* b, int rec, const void* X, int x_dtype, const 
     HIPCHK(ctx, hipMemcpyAsync(b->d_state + rec, &st, sizeof st, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(b->d_tile_done + rd.tile0, 0, sizeof(int) * rd.ntiles, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // host vectors go out of scope below
-    double gsum = 0.0;
-    for (double g : gt) gsum += g;
-    rd.gsum = gsum;
+    if (X) {
+        double gsum = 0.0;
+        for (double g : gt) gsum += g;
+        rd.gsum = gsum;
+    } else {
+        rd.gsum = b->recs[b->share_src[rec]].gsum;
+    }
     return VBX_OK;
 }
 }  // namespace
@@ -975,6 +1037,7 @@ int get_labels_impl(vbx_batch* b, int rec, int32_t* first, int32_t* second) {
 }  // extern "C++"
 
 struct vbx_xvectors;
+static void own_rho(vbx_batch* b, int rec);
 static const double* xvectors_fea_rows(const vbx_xvectors* xv, int64_t row0, int64_t T, int D, int device);
 
 static int leaf_set_recording_resident(vbx_batch* b, int rec, const vbx_xvectors* xv, int64_t row0, const int32_t* labels,
@@ -992,6 +1055,7 @@ static int leaf_set_recording_resident(vbx_batch* b, int rec, const vbx_xvectors
     rd.lp = loopProb;
     rd.Fa = Fa;
     rd.Fb = Fb;
+    own_rho(b, rec);
     // softmax(smoothing * onehot) row (vbhmm.py:152, scipy.special.softmax: exp(x - max) / sum)
     const double z = std::exp(-init_smoothing), den = 1.0 + (rd.S - 1) * z;
     const double hi = 1.0 / den, lo = z / den;
@@ -1012,6 +1076,20 @@ static int leaf_get_labels(vbx_batch* b, int rec, int32_t* first, int32_t* secon
                                          : get_labels_impl<float>(b, rec, first, second);
 }
 
+// `rec` gets (back) a rho of its own: recordings that read its rows so far are unset, and it leaves the group it was in
+static void own_rho(vbx_batch* b, int rec) {
+    for (int i = 0; i < b->n_rec; ++i)
+        if (i != rec && b->share_src[i] == rec) {
+            b->share_src[i] = i;
+            b->recs[i].rho_row0 = b->recs[i].row0;
+            b->is_set[i] = 0;
+            b->order_dirty = true;
+        }
+    if (b->share_src[rec] != rec) b->order_dirty = true;
+    b->share_src[rec] = rec;
+    b->recs[rec].rho_row0 = b->recs[rec].row0;
+}
+
 static int leaf_set_recording(vbx_batch* b, int rec, const void* X, int x_dtype, const double* Phi, const double* pi0,
                             const void* gamma0, int g_dtype, const double* alpha0, const double* invL0,
                             double loopProb, double Fa, double Fb) {
@@ -1029,9 +1107,50 @@ static int leaf_set_recording(vbx_batch* b, int rec, const void* X, int x_dtype,
     rd.lp = loopProb;
     rd.Fa = Fa;
     rd.Fb = Fb;
+    own_rho(b, rec);
     int rc = b->precision == VBX_PREC_FP64
                  ? set_recording_impl<double>(b, rec, X, x_dtype, Phi, pi0, gamma0, g_dtype, alpha0, invL0)
                  : set_recording_impl<float>(b, rec, X, x_dtype, Phi, pi0, gamma0, g_dtype, alpha0, invL0);
+    if (rc != VBX_OK) return rc;
+    b->is_set[rec] = 1;
+    b->recs_dirty = true;
+    b->mpart_valid = false;
+    return VBX_OK;
+}
+
+// recording `rec` on the x-vectors (rho, Phi, sum G) of recording `src` of the same batch: an Fa / Fb / loopProb sweep
+// over one recording keeps one rho in HBM
+static int leaf_set_recording_shared(vbx_batch* b, int rec, int src, const double* pi0, const void* gamma0, int g_dtype,
+                                     const double* alpha0, const double* invL0, double loopProb, double Fa, double Fb) {
+    if (!b) return VBX_ERR_INVALID;
+    vbx_ctx* ctx = b->ctx;
+    if (rec < 0 || rec >= b->n_rec || src < 0 || src >= b->n_rec || src == rec)
+        FAIL(ctx, VBX_ERR_INVALID, "vbx_batch_set_recording_shared: recording %d / source %d out of range", rec, src);
+    if (!pi0 || !gamma0) FAIL(ctx, VBX_ERR_INVALID, "vbx_batch_set_recording_shared: NULL input");
+    if (g_dtype != VBX_F32 && g_dtype != VBX_F64) FAIL(ctx, VBX_ERR_INVALID, "bad element type");
+    if (!b->is_set[src]) FAIL(ctx, VBX_ERR_STATE, "recording %d (the source of the x-vectors) has not been set", src);
+    if (b->recs[src].T != b->recs[rec].T)
+        FAIL(ctx, VBX_ERR_INVALID, "recording %d has %d frames, its source %d has %d", rec, b->recs[rec].T, src, b->recs[src].T);
+    if ((alpha0 == nullptr) != (invL0 == nullptr)) { alpha0 = nullptr; invL0 = nullptr; }
+    if (!(loopProb >= 0.0 && loopProb <= 1.0)) FAIL(ctx, VBX_ERR_INVALID, "loopProb=%g outside [0,1]", loopProb);
+    if (!(Fa > 0.0) || !(Fb > 0.0)) FAIL(ctx, VBX_ERR_INVALID, "Fa and Fb must be positive");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    own_rho(b, rec);                                          // (whoever shared with `rec` must be set again)
+    const int owner = b->share_src[src];                      // a source that shares itself: its owner
+    RecDesc& rd = b->recs[rec];
+    rd.lp = loopProb;
+    rd.Fa = Fa;
+    rd.Fb = Fb;
+    rd.rho_row0 = b->recs[owner].row0;
+    b->share_src[rec] = owner;
+    b->order_dirty = true;
+    // the rows of rho this recording leaves unused lie behind another recording's: the last chunk of that one reads a whole
+    // tile (finite values that meet gamma = 0, vbx_chunk_post.hpp), so they must not hold whatever the block held before
+    HIPCHK(ctx, hipMemsetAsync((char*)b->d_rho + (size_t)rd.row0 * b->Dp * b->rsize, 0,
+                               (size_t)std::min(rd.T, kTileFrames) * b->Dp * b->rsize, ctx->stream));
+    int rc = b->precision == VBX_PREC_FP64
+                 ? set_recording_impl<double>(b, rec, nullptr, VBX_F64, nullptr, pi0, gamma0, g_dtype, alpha0, invL0)
+                 : set_recording_impl<float>(b, rec, nullptr, VBX_F64, nullptr, pi0, gamma0, g_dtype, alpha0, invL0);
     if (rc != VBX_OK) return rc;
     b->is_set[rec] = 1;
     b->recs_dirty = true;
@@ -1410,6 +1529,23 @@ int vbx_batch_set_recording(vbx_batch* b, int rec, const void* X, int x_dtype, c
     const int k = b->kid_of[rec];
     return kid_fail(b, k, leaf_set_recording(b->kids[k], b->local_of[rec], X, x_dtype, Phi, pi0, gamma0, g_dtype, alpha0,
                                              invL0, loopProb, Fa, Fb));
+}
+
+int vbx_batch_set_recording_shared(vbx_batch* b, int rec, int src_rec, const double* pi0, const void* gamma0, int g_dtype,
+                                   const double* alpha0, const double* invL0, double loopProb, double Fa, double Fb) {
+    if (!b) return VBX_ERR_INVALID;
+    if (b->kids.empty())
+        return leaf_set_recording_shared(b, rec, src_rec, pi0, gamma0, g_dtype, alpha0, invL0, loopProb, Fa, Fb);
+    if (rec < 0 || rec >= b->n_rec || src_rec < 0 || src_rec >= b->n_rec)
+        FAIL(b->ctx, VBX_ERR_INVALID, "vbx_batch_set_recording_shared: recording index out of range");
+    // a stream group deals its recordings to sub-batches with a device arena each: sharing works inside one of them
+    const int k = b->kid_of[rec];
+    if (b->kid_of[src_rec] != k)
+        FAIL(b->ctx, VBX_ERR_UNSUPPORTED, "recordings %d and %d live in different stream sub-batches: create the batch with "
+                                          "VBX_OPT_STREAMS = 1 (VBX_AMD_STREAMS=1) to share x-vectors between them", rec, src_rec);
+    b->any_set = true;
+    return kid_fail(b, k, leaf_set_recording_shared(b->kids[k], b->local_of[rec], b->local_of[src_rec], pi0, gamma0, g_dtype,
+                                                    alpha0, invL0, loopProb, Fa, Fb));
 }
 
 int vbx_batch_run(vbx_batch* b, int max_iters, double epsilon) {

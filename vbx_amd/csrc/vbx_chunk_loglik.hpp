@@ -42,7 +42,8 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)si
     __shared__ __attribute__((aligned(16))) R lds[kLds];
     R* const al = lds;                                 // alpha[:, k0 : k0 + kAlphaSlice], rows padded to AST
     R* const btile = lds;                              // b[kTileFrames][SP]
-    const int tile = blockIdx.x;
+    const int tile = tile_of_block(bt, blockIdx.x);
+    if (tile < 0) return;
     const int rec = bt.tile_rec[tile];
     if (bt.state[rec].done) return;
     const RecDesc rd = bt.recs[rec];
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)si
     // ---- phase 1: wave w owns frames [32w, 32w+32) of the chunk = 2 M-tiles ----------------------
     {
         const int f0 = t0 + 32 * wave;
-        const R* __restrict__ rho = bt.rho + rd.row0 * Dp;
+        const R* __restrict__ rho = bt.rho + rd.rho_row0 * Dp;
         const R* __restrict__ alpha = bt.alpha + (long long)rec * SP * Dp;
         acc_t acc[2][NT];
 #pragma unroll
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)si
     }
     VBX_STAMP();
 #ifdef VBX_PHASE_CLOCKS
-    if ((blockIdx.x % 1000) == 1 && (lane == 0) && bt.state[rec].n_iters == 3)
+    if ((tile % 1000) == 1 && (lane == 0) && bt.state[rec].n_iters == 3)
         printf("chunk_loglik wave %d: mfma %lld  epilogue %lld  wait %lld  operator %lld cycles\n", wave,
                clk[1] - clk[0], clk[2] - clk[1], clk[3] - clk[2], clk[4] - clk[3]);
 #endif

@@ -90,8 +90,8 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
     __shared__ double ent_w[4][SP];
     __shared__ double red[16];
 
-    const int tile = blockIdx.x;
-    if (!REPLAY && bt.tile_done[tile]) return;
+    const int tile = tile_of_block(bt, blockIdx.x);
+    if (tile < 0 || (!REPLAY && bt.tile_done[tile])) return;
     VBX_CLOCKS_DECL();
     // (the wave index as a scalar: roles, frame ranges and loop bounds of the re-run stay in SGPRs)
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
         const double lp_d = bt.recs[rec].lp;
         const int n_spk = bt.recs[rec].S;
         const R lp = (R)lp_d;
-        const R* __restrict__ rho = bt.rho + (trow - t0) * Dp;
+        const R* __restrict__ rho = bt.rho + bt.recs[rec].rho_row0 * Dp;
         R* const bl = region[0];                       // b, then a (rows >= m) / x (rows < m), then gamma
         R* const r1 = region[1];                       // a_f below the crossing of its half, x_f from it on
         VBX_STAMP();

@@ -19,6 +19,8 @@ namespace vbx {
 
 struct RecDesc {
     long long row0;   // first frame row of this recording in the frame-major arrays
+    long long rho_row0;   // first row of its rho: row0, or the rows of the recording it shares its x-vectors with (an Fa / Fb
+                          // sweep over one recording keeps ONE rho: vbx_batch_set_recording_shared)
     int T, S;         // frames, speakers (unpadded)
     int tile0;        // first workgroup tile
     int ntiles;       // tiles of kTileFrames frames
@@ -48,6 +50,8 @@ template <typename R> struct BatchView {
     const int* tile_t0;    // [ntiles_total]
     const int4* tile_desc; // [ntiles_total rounded up to 4] {recording, t0, frames, first row}; frames = 0 behind the last tile
     int* tile_done;        // [same] 1 once the tile's recording has converged (written by iter_fin)
+    const int* tile_order; // null, or [blocks of the per-chunk kernels] workgroup -> tile (-1: none): recordings that share a
+                           // rho are dealt so that the chunks reading one rho tile run side by side on one XCD (one L2)
     const double* phi;     // [n_rec][Dp]
     R* rho;
     R* gamma;
@@ -97,6 +101,11 @@ template <typename R> struct BatchView {
     // have room for two chunks per tile.
     int spt;
 };
+
+// the tile a workgroup of a per-chunk kernel works on (-1: none)
+template <typename R> __device__ __forceinline__ int tile_of_block(const BatchView<R>& bt, int block) {
+    return bt.tile_order ? bt.tile_order[block] : block;
+}
 
 constexpr int kScanHalf = kTileFrames / 2;
 __device__ __forceinline__ int chunk_count(const RecDesc& rd, int spt) {
@@ -154,7 +163,7 @@ __global__ __launch_bounds__(64) void mstep_acc_kernel(BatchView<R> bt) {
     const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
     const int d0 = blockIdx.y * 32;
     const R* __restrict__ gam = bt.gamma + rd.row0 * Sp;
-    const R* __restrict__ rho = bt.rho + rd.row0 * Dp;
+    const R* __restrict__ rho = bt.rho + rd.rho_row0 * Dp;
 
     acc_t acc[NT][2];
     R nsum[NT];
@@ -316,7 +325,7 @@ __global__ __launch_bounds__(256) void loglik_kernel(BatchView<R> bt, R* __restr
     const int Sp = bt.Sp, Dp = bt.Dp;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
     const int f0 = bt.tile_t0[tile] + 32 * wave;
-    const R* __restrict__ rho = bt.rho + rd.row0 * Dp;
+    const R* __restrict__ rho = bt.rho + rd.rho_row0 * Dp;
     const R* __restrict__ alpha = bt.alpha + (long long)rec * Sp * Dp;
 
     acc_t acc[2][NT];

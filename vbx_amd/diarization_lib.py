@@ -6,55 +6,21 @@
     thr, _ = twoGMMcalib_lin(scr_mx.ravel())         # diarization_lib.py:13-31, 20 EM passes over T*T scores
 
 Both functions keep the reference's signatures, return types and error behaviour; the work runs in HIP
-kernels (f64 MFMA for the similarity matrix, one streaming kernel per EM pass).  The score matrix stays
-resident in HBM between the two calls: ``cos_similarity`` remembers the device copy of the array it
-returns, and ``twoGMMcalib_lin`` recognises that array (or a flat view of it, as ``.ravel()`` gives)
-and calibrates the resident copy instead of uploading 8*T*T bytes again.  The returned matrix is read-only for that
-reason (``scr_mx.copy()`` gives an editable one, which is uploaded like any other array).  There is no CPU fallback.
+kernels (f64 MFMA for the similarity matrix, one streaming kernel per EM pass).  ``cos_similarity`` returns an
+ordinary, writable ndarray like the reference's (callers edit it in place: ``np.fill_diagonal``, ``scr_mx *= -1``,
+masks), and ``twoGMMcalib_lin`` uploads whatever vector it is handed: the host array is the only truth, so an in-place
+edit between the two calls cannot go unnoticed.  (Round 2 kept the device copy of the matrix alive behind a read-only
+array and spot-checked it; a full check costs more than the 8 T^2 bytes over PCIe it saved.)  Callers that want the
+matrix to stay in HBM between the two steps use ``vbx_amd._capi.Scores`` directly, as ``vbx_amd.vbhmm`` does.
+There is no CPU fallback.
 """
 from __future__ import annotations
-
-import weakref
 
 import numpy as np
 
 from . import _capi
 
 __all__ = ['cos_similarity', 'twoGMMcalib_lin']
-
-_resident = {}      # id(host array) -> (weakref to it, device copy)
-
-
-def _remember(arr, scores):
-    key = id(arr)
-
-    def _drop(_ref, key=key):
-        entry = _resident.pop(key, None)
-        if entry is not None:
-            entry[1].close()
-    _resident[key] = (weakref.ref(arr, _drop), scores)
-
-
-def _find_resident(s):
-    """The device copy of ``s`` if ``s`` is an array returned by cos_similarity() or a full flat / reshaped
-    view of one, and a spot check says the host copy has not been modified since."""
-    base = s
-    while isinstance(base, np.ndarray):
-        entry = _resident.get(id(base))
-        if entry is not None and entry[0]() is base:
-            scores = entry[1]
-            if (s.size == len(scores) and s.flags.c_contiguous and s.dtype == np.float64
-                    and s.__array_interface__['data'][0] == base.__array_interface__['data'][0]):
-                flat = s.reshape(-1)
-                probe = np.unique(np.linspace(0, flat.size - 1, 64).astype(np.int64))
-                if all(scores.get(int(k), 1)[0] == flat[k] for k in probe[:8]) and \
-                        np.array_equal(scores.get(int(probe[-1]), 1), flat[probe[-1]:probe[-1] + 1]):
-                    return scores
-                _resident.pop(id(base), None)          # someone forced a write: the device copy is stale for good
-                scores.close()
-            return None
-        base = base.base
-    return None
 
 
 def cos_similarity(x, *, device=None):
@@ -66,12 +32,12 @@ def cos_similarity(x, *, device=None):
     norm = np.sqrt(np.sum(np.square(x), axis=1, keepdims=True))
     xn_sq = np.sum(np.square(x / (norm + 1.0e-32)), axis=1)
     assert np.allclose(np.ones_like(xn_sq), xn_sq)
-    ctx = _capi.default_context(device)
-    scores = _capi.Scores.cos_similarity(ctx, x)
-    out = np.empty((x.shape[0], x.shape[0]))        # owns its memory: views of it (ravel) have it as .base
-    scores.get(out=out)
-    out.flags.writeable = False     # the device copy stands for this array: an in-place edit must not go unnoticed
-    _remember(out, scores)          # (callers that want to edit the scores take a copy, which is then uploaded)
+    scores = _capi.Scores.cos_similarity(_capi.default_context(device), x)
+    try:
+        out = np.empty((x.shape[0], x.shape[0]))
+        scores.get(out=out)
+    finally:
+        scores.close()
     return out
 
 
@@ -79,15 +45,11 @@ def twoGMMcalib_lin(s, niters=20, *, device=None):
     """Two-Gaussian GMM with shared variance over the scores ``s``: returns the threshold that separates
     the two Gaussians and the linearly calibrated log-odds of every score.  diarization_lib.py:13-31."""
     s = np.asarray(s)
-    scores = _find_resident(s) if s.dtype == np.float64 else None
-    owned = scores is None
-    if owned:
-        if s.ndim != 1:
-            raise ValueError('twoGMMcalib_lin expects a vector of scores')     # the reference's s[:, np.newaxis] needs 1-D
-        scores = _capi.Scores.upload(_capi.default_context(device), s)
+    if s.ndim != 1:
+        raise ValueError('twoGMMcalib_lin expects a vector of scores')     # the reference's s[:, np.newaxis] needs 1-D
+    scores = _capi.Scores.upload(_capi.default_context(device), s)
     try:
         threshold, llr = scores.two_gmm_calib(niters)
     finally:
-        if owned:
-            scores.close()
+        scores.close()
     return np.float64(threshold), llr

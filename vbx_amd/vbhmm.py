@@ -153,29 +153,53 @@ class DeviceStages:
             sc.close()
         return cut_linkage(lin_mat, thr, threshold), float(thr)
 
+    @staticmethod
+    def padded_states(n_states):
+        """The padded state count a batch of this many speakers runs with (vbx_capi.hip: powers of two from 16)."""
+        sp = 16
+        while sp < n_states:
+            sp *= 2
+        return sp
+
     def vb(self, ks, labels, init_smoothing, maxIters, epsilon, precision, loopProb, Fa, Fb):
-        """-> [(labels1st, labels2nd or None, iterations)] for the recordings ``ks`` with AHC labels ``labels``."""
+        """-> [(labels1st, labels2nd or None, iterations)] for the recordings ``ks`` with AHC labels ``labels``.
+
+        One ``vbx_batch`` per padded state count: every recording of a batch runs with the widest one's padding, and one
+        recording with more than 64 AHC clusters would push a whole archive from the fused kernels (responsibilities and
+        lattices on the chip) onto the wide scan -- about 5x slower per iteration."""
         S = [int(np.max(lab)) + 1 for lab in labels]
-        batch = self._capi.Batch(self.ctx, [self.T[k] for k in ks], S, self.lda_dim, precision=precision, max_iters=maxIters)
-        try:
-            for j, (k, lab) in enumerate(zip(ks, labels)):
-                batch.set_recording_resident(j, self.xv, self.row0[k], lab, init_smoothing, self.Phi, loopProb, Fa, Fb)
-            batch.run(maxIters, epsilon)
-            out = []
-            for j in range(len(ks)):
-                first, second = batch.labels(j)
-                out.append((first, second, batch.n_iters(j)))
-            return out
-        finally:
-            batch.close()
+        buckets = {}
+        for j, s in enumerate(S):
+            buckets.setdefault(self.padded_states(s), []).append(j)
+        out = [None] * len(ks)
+        for _sp, members in sorted(buckets.items()):
+            batch = self._capi.Batch(self.ctx, [self.T[ks[j]] for j in members], [S[j] for j in members], self.lda_dim,
+                                     precision=precision, max_iters=maxIters)
+            try:
+                for b, j in enumerate(members):
+                    batch.set_recording_resident(b, self.xv, self.row0[ks[j]], labels[j], init_smoothing, self.Phi,
+                                                 loopProb, Fa, Fb)
+                batch.run(maxIters, epsilon)
+                for b, j in enumerate(members):
+                    first, second = batch.labels(b)
+                    out[j] = (first, second, batch.n_iters(b))
+            finally:
+                batch.close()
+        return out
+
+    def close_thread_contexts(self):
+        """The per-thread contexts (a HIP stream each) of the AHC stage: closed before the VB batch creates its stream
+        group, so that the group's streams do not share hardware queues with idle ones (8 queues per process)."""
+        for ctx in self._thread_ctxs:
+            ctx.close()
+        self._thread_ctxs = []
+        self._local = __import__('threading').local()
 
     def close(self):
         if self.xv is not None:
             self.xv.close()
             self.xv = None
-        for ctx in self._thread_ctxs:
-            ctx.close()
-        self._thread_ctxs = []
+        self.close_thread_contexts()
 
 
 def _small_blas_pool():
@@ -300,6 +324,8 @@ def diarize(args, stages=None, log=print):
         with tune_host_process(), ThreadPoolExecutor(max_workers=n_workers) as pool:
             for file_name, st in pool.map(prepare, range(len(recordings))):      # results in archive order
                 state[file_name] = st
+        if hasattr(stages, 'close_thread_contexts'):
+            stages.close_thread_contexts()
         t_ahc = time.perf_counter()
 
         # ---- stage 2: every recording of this rank in one batch ------------------------------------------------------
@@ -387,13 +413,21 @@ def main(argv=None):
             torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
             os.environ.setdefault('VBX_AMD_DEVICE', os.environ.get('LOCAL_RANK', '0'))
         dist.init_process_group('nccl' if torch.cuda.is_available() else 'gloo')
+    error = None
+    timing = None
     try:
-        _state, timing = diarize(args)
+        try:
+            _state, timing = diarize(args)
+        except Exception as exc:           # the other ranks wait in the barrier below: meet them there first, then fail
+            error = exc
         if dist is not None:
             dist.barrier()
     finally:
         if dist is not None and dist.is_initialized():
             dist.destroy_process_group()
+    if error is not None:
+        print(f'vbhmm: {type(error).__name__}: {error}', file=sys.stderr)
+        return 1
     if args.timing:
         import json
         print(json.dumps(timing))
