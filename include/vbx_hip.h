@@ -39,7 +39,7 @@ extern "C" {
 #define VBX_ERR_NO_DEVICE (-4)   /* no gfx950-class GPU visible                            */
 #define VBX_ERR_STATE (-5)       /* call order violated (run before every recording is set) */
 
-#define VBX_MAX_SPEAKERS 256
+#define VBX_MAX_SPEAKERS 1024
 
 /* element types of caller buffers */
 #define VBX_F32 0

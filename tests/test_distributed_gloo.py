@@ -52,11 +52,18 @@ def _worker(rank, world, port, outdir):
     try:
         np.random.seed(7)                                       # gamma=None draws must agree on every rank
         res = VBx_batch_distributed(_recordings(), maxIters=4, epsilon=-np.inf, Fa=0.3, Fb=17.0,
-                                    run_shard=_oracle_shard, return_model=True)
+                                    run_shard=_oracle_shard, return_model=True, gather='all')
+        np.random.seed(7)
+        at_root = VBx_batch_distributed(_recordings(), maxIters=4, epsilon=-np.inf, Fa=0.3, Fb=17.0,
+                                        run_shard=_oracle_shard, return_model=True)       # default: one gather to rank 0
         np.random.seed(7)
         local_only = VBx_batch_distributed(_recordings(), maxIters=4, epsilon=-np.inf, Fa=0.3, Fb=17.0,
                                            run_shard=_oracle_shard, gather=False)
         mine = [b for b, r in enumerate(local_only) if r is not None]
+        have = [b for b, r in enumerate(at_root) if r is not None]
+        assert have == (list(range(len(res))) if rank == 0 else mine), (rank, have, mine)
+        for b in have:
+            assert all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(at_root[b], res[b]))
         np.savez(os.path.join(outdir, f'rank{rank}.npz'), mine=np.array(mine),
                  **{f'g{b}': r[0] for b, r in enumerate(res)}, **{f'pi{b}': r[1] for b, r in enumerate(res)},
                  **{f'L{b}': np.array(r[2]) for b, r in enumerate(res)},

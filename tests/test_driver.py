@@ -300,6 +300,38 @@ def test_driver_reproduces_the_reference_rttm_on_the_gpu(tmp_path, capsys):
 
 
 @pytest.mark.gpu
+def test_driver_takes_a_recording_with_more_than_256_ahc_clusters(tmp_path):
+    """AHC on a long or noisy file can leave VBx() hundreds of clusters (vbhmm.py:150-158 hands it one HMM state per
+    cluster) and the reference takes any number (VBx.py:76-85).  Round 2 reported and skipped such a recording; now it
+    runs (its own batch: the driver buckets recordings by padded state count) and the other recordings are untouched."""
+    from vbx_amd import vbhmm
+    from oracle import vbx_oracle
+    from scipy.special import softmax
+    paths = _write_inputs(tmp_path)
+    args = vbhmm.build_parser().parse_args(_argv(paths))
+
+    class Many(vbhmm.DeviceStages):
+        def ahc(self, k, threshold):
+            labels, thr = super().ahc(k, threshold)
+            if k == 1:                                        # recB (300 x-vectors): 290 clusters
+                labels = np.arange(len(labels)) % 290
+                self.fea_b = self.xv.get('fea', self.row0[k], self.T[k])
+            return labels, thr
+    stages = Many()
+    state, timing = vbhmm.diarize(args, stages=stages, log=lambda *_: None)
+    assert list(state) == list(RECS) and timing['recordings'] == 3
+    _check_rttm(paths, recs=('recA', 'recC'))
+    lab = np.arange(300) % 290
+    qinit = np.zeros((300, 290))
+    qinit[range(300), lab] = 1.0
+    qinit = softmax(qinit * args.init_smoothing, axis=1)
+    q, _, L = vbx_oracle.VBx(stages.fea_b, stages.Phi, pi=290, gamma=qinit, maxIters=40, epsilon=1e-6, loopProb=args.loopP,
+                             Fa=args.Fa, Fb=args.Fb)
+    assert state['recB']['n_iters'] == len(L)
+    assert np.array_equal(state['recB']['labels1st'], np.argsort(-q, axis=1, kind='stable')[:, 0])
+
+
+@pytest.mark.gpu
 def test_device_stages_against_what_the_reference_driver_computed(tmp_path):
     """The steps either side of VBx() on the device against the values captured from the UNCHANGED reference driver
     (tests/golden/frontend_split3.npz, make_golden_frontend.py): projected x-vectors (vbhmm.py:125-129), PLDA

@@ -74,3 +74,48 @@ def test_unchanged_vbhmm_runs_on_the_drop_in_module(tmp_path, monkeypatch, es200
         f = line.split()
         rows.append((float(f[3]), float(f[4]), int(f[7])))
     assert np.array_equal(np.array(rows), es2005a['rttm_produced'])
+
+
+def test_generated_minimal_caller_goes_through_the_same_redirection(tmp_path, monkeypatch, es2005a):
+    """tests/make_mini_vbhmm.py (what the -m gpu test tests/test_gpu_drop_in.py runs on the box without a reference
+    checkout): same launcher, same import lines, same call shape -- here with the oracle behind the drop-in."""
+    from oracle import vbx_oracle, ahc_oracle
+    import vbx_amd                                              # noqa: F401
+    import vbx_amd.diarization_lib as product_ahc
+    product = sys.modules['vbx_amd.VBx']
+    calls = []
+
+    def recording_vbx(X, Phi, **kw):
+        calls.append(dict(kw))
+        return vbx_oracle.VBx(X, Phi, **kw)
+
+    monkeypatch.setattr(product, 'VBx', recording_vbx)
+    monkeypatch.setattr(product_ahc, 'cos_similarity', ahc_oracle.cos_similarity)
+    monkeypatch.setattr(product_ahc, 'twoGMMcalib_lin', ahc_oracle.twoGMMcalib_lin)
+    stale = ('VBx', 'diarization_lib', '_reference_diarization_lib', 'kaldi_utils', 'run_vbhmm')
+    for name in stale:
+        monkeypatch.delitem(sys.modules, name, raising=False)
+    sys.path.insert(0, os.path.join(REPO, 'tools'))
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    out = tmp_path / 'rttm'
+    out.mkdir()
+    try:
+        import make_mini_vbhmm
+        import run_vbhmm
+        make_mini_vbhmm.emit(str(tmp_path / 'checkout'))
+        gold = os.path.join(REPO, 'tests', 'golden')
+        run_vbhmm.main(['--reference', str(tmp_path / 'checkout'), '--allow-shims', '--',
+                        '--fixture', os.path.join(gold, 'es2005a.npz'), '--ahc-fixture', os.path.join(gold, 'ahc_cases.npz'),
+                        '--out-rttm-dir', str(out), '--lda-dim', '128', '--Fa', '0.3', '--Fb', '17', '--loopP', '0.99'])
+        assert os.path.samefile(sys.modules['VBx'].__file__, os.path.join(REPO, 'vbx_drop_in', 'VBx.py'))
+        assert os.path.samefile(sys.modules['diarization_lib'].__file__, os.path.join(REPO, 'vbx_drop_in', 'diarization_lib.py'))
+    finally:
+        sys.path.remove(os.path.join(REPO, 'tools'))
+        sys.path.remove(os.path.join(REPO, 'tests'))
+        for name in stale:
+            sys.modules.pop(name, None)
+    assert len(calls) == 1 and (calls[0]['pi'], calls[0]['maxIters'], calls[0]['epsilon']) == (31, 40, 1e-6)    # vbhmm.py:154-158
+    assert np.array_equal(calls[0]['gamma'], es2005a['qinit'])
+    rows = [(float(f[3]), float(f[4]), int(f[7])) for f in (line.split() for line in open(out / 'ES2005a.rttm'))]
+    assert np.array_equal(np.array(rows), es2005a['rttm_produced'])
+    assert int(np.load(out / 'n_iters.npy')) == 13

@@ -1,0 +1,97 @@
+"""The multi-rank PRODUCT path on the GPU (-m gpu): several processes, each with its own ``vbx_ctx`` (stream, device
+arena), sharing the ONE device of a test box over a ``gloo`` rendezvous -- RCCL refuses two ranks on one GPU, and the
+data path has no collective anyway (on a node every rank has its own GPU and the same code runs
+over RCCL).  tests/test_distributed_gloo.py covers the host logic on CPU with the oracle injected; here the shards run
+on the HIP kernels:
+
+  * ``VBx_batch_distributed`` on two ranks == ``VBx_batch`` in one process, recording by recording;
+  * ``python -m torch.distributed.run --nproc-per-node 2 -m vbx_amd.vbhmm ...`` writes the RTTM files the unchanged
+    reference driver wrote for the same archive (tests/golden/driver_split3.npz), each exactly once.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _recordings():
+    from vbx_amd.synth import make_recording
+    recs = []
+    for k, (T, S) in enumerate([(3000, 12), (700, 5), (5200, 30), (129, 3), (1500, 9), (2600, 40)]):
+        X, Phi, _ = make_recording(T, S, seed=60 + k, kappa=0.05)
+        recs.append(dict(X=X, Phi=Phi, pi=S, loopProb=0.99 if k % 2 else 0.9))
+    return recs
+
+
+def _worker(rank, world, port, outdir):
+    sys.path.insert(0, REPO)
+    os.environ['VBX_AMD_DEVICE'] = '0'                          # every rank on the one device
+    import torch.distributed as dist
+    from vbx_amd import _capi
+    from vbx_amd.batch import VBx_batch_distributed
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+    try:
+        np.random.seed(11)                                      # gamma=None: the same draws on every rank
+        res = VBx_batch_distributed(_recordings(), maxIters=6, epsilon=1e-6, Fa=0.3, Fb=17.0, return_model=True)
+        have = [b for b, r in enumerate(res) if r is not None]
+        np.savez(os.path.join(outdir, f'rank{rank}.npz'), have=np.array(have), lib=np.array(_capi.library_path()),
+                 loaded=np.array(_capi._lib is not None),
+                 **{f'g{b}': res[b][0] for b in have}, **{f'pi{b}': res[b][1] for b in have},
+                 **{f'L{b}': np.array(res[b][2]) for b in have}, **{f'a{b}': res[b][3] for b in have})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_equal_one_process(tmp_path):
+    import torch.multiprocessing as mp
+    from vbx_amd.batch import VBx_batch, shard_recordings
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    np.random.seed(11)
+    single = VBx_batch(_recordings(), maxIters=6, epsilon=1e-6, Fa=0.3, Fb=17.0, return_model=True)
+    recs = _recordings()
+    assign = shard_recordings([r['X'].shape[0] * r['pi'] for r in recs], world)
+    ranks = [np.load(tmp_path / f'rank{r}.npz') for r in range(world)]
+    assert ranks[0]['have'].tolist() == list(range(len(recs)))                  # the gather ends at rank 0
+    assert ranks[1]['have'].tolist() == [b for b in range(len(recs)) if assign[b] == 1]
+    assert 0 < len(ranks[1]['have']) < len(recs)
+    for r in range(world):
+        assert bool(ranks[r]['loaded']) and str(ranks[r]['lib']).endswith('libvbx_hip.so')
+        for b in ranks[r]['have'].tolist():
+            # (a recording's arithmetic does not depend on which other recordings share its batch: fp64, same kernels)
+            np.testing.assert_allclose(ranks[r][f'g{b}'], single[b][0], rtol=0, atol=1e-12, err_msg=f'rank {r} recording {b}')
+            np.testing.assert_allclose(ranks[r][f'pi{b}'], single[b][1], rtol=0, atol=1e-13)
+            assert len(ranks[r][f'L{b}']) == len(single[b][2])
+            np.testing.assert_allclose(ranks[r][f'L{b}'].ravel(), np.array(single[b][2]).ravel(), rtol=1e-13)
+            np.testing.assert_allclose(ranks[r][f'a{b}'], single[b][3], rtol=0, atol=1e-12)
+
+
+def test_driver_under_torchrun_on_one_gpu(tmp_path):
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import test_driver as td
+    paths = td._write_inputs(tmp_path)
+    env = dict(os.environ, VBX_AMD_DEVICE='0', VBX_AMD_DIST_BACKEND='gloo', PYTHONFAULTHANDLER='1', PYTHONPATH=REPO + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), '-m', 'vbx_amd.vbhmm'] + td._argv(paths, ['--timing'])
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-3000:])
+    timings = [json.loads(line) for line in res.stdout.splitlines() if line.startswith('{"read"') or line.startswith('{')]
+    timings = [t for t in timings if 'world' in t]
+    assert sorted(t['rank'] for t in timings) == [0, 1] and all(t['world'] == 2 for t in timings), res.stdout
+    assert sorted(t['recordings'] for t in timings) == [1, 2]                  # recA on one rank, recB + recC on the other
+    td._check_rttm(paths)

@@ -17,7 +17,7 @@ OPT_FB_ALGO, OPT_CHECK_EVERY, OPT_PROFILE, OPT_CHUNK_FRAMES, OPT_FUSE, OPT_SCAN_
 OPT_TWO_LEVEL_FROM, OPT_STREAMS, OPT_SPLIT_TILES = 8, 10, 11
 K_NAMES = ['prep', 'mstep_acc', 'mstep_fin', 'loglik', 'fb', 'fb_aux', 'post', 'iter_fin', 'chunk_loglik',
            'chunk_post']
-MAX_SPEAKERS = 256
+MAX_SPEAKERS = 1024
 
 ABI_SYMBOLS = [
     'vbx_abi_version', 'vbx_create', 'vbx_destroy', 'vbx_last_error', 'vbx_device_info',

@@ -169,10 +169,17 @@ def VBx_batch_distributed(recordings, maxIters=10, epsilon=1e-4, precision=None,
                           run_shard=None, gather=True, **defaults):
     """Shard ``recordings`` over the ranks of the initialised ``torch.distributed`` group.
 
-    Every rank passes the same list; rank r computes the recordings assigned to it and, with
-    ``gather=True``, an ``all_gather_object`` hands every rank the complete result list (the
-    results are a few MB at most: no data-path collective).  ``run_shard(items, maxIters,
-    epsilon)`` defaults to the HIP path; the CPU test-suite injects the oracle here."""
+    Every rank passes the same list; rank r computes the recordings assigned to it (LPT on T x S) on its own GPU.  There
+    is no collective on the data path; what happens to the RESULTS afterwards is the caller's choice:
+
+      gather=True / 'root'   one ``gather_object`` to rank 0, which returns the complete list; every other rank returns
+                             its own results and ``None`` for the rest (the responsibilities are the bulk: 8 T S bytes per
+                             recording -- 2.4 MB at T = 10 000, S = 30, 19 MB per rank and 154 MB at rank 0 for BASELINE
+                             config 4 -- so they travel once, to the rank that writes them out)
+      gather='all'           ``all_gather_object``: every rank returns the complete list (world x as many bytes)
+      gather=False           nothing is exchanged: every rank returns its own results, ``None`` elsewhere
+
+    ``run_shard(items, maxIters, epsilon)`` defaults to the HIP path; the CPU test-suite injects the oracle here."""
     import torch.distributed as dist
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
@@ -185,12 +192,16 @@ def VBx_batch_distributed(recordings, maxIters=10, epsilon=1e-4, precision=None,
             return run_shard_hip(sub, mi, eps, precision=precision)
     local = run_shard([items[b] for b in mine], int(maxIters), epsilon) if mine else []
     local = {b: res for b, res in zip(mine, local)}
-    if not gather or world == 1:
-        merged = local
-    else:
-        parts = [None] * world
-        dist.all_gather_object(parts, local)
-        merged = {}
-        for p in parts:
+    if gather not in (True, False, 'root', 'all'):
+        raise ValueError(f"gather={gather!r}: expected True / 'root', 'all' or False")
+    merged = dict(local)
+    if gather and world > 1:
+        if gather == 'all':
+            parts = [None] * world
+            dist.all_gather_object(parts, local)
+        else:
+            parts = [None] * world if rank == 0 else None
+            dist.gather_object(local, parts, dst=0)
+        for p in parts or []:
             merged.update(p)
     return [(_as_tuple(merged[b], return_model) if b in merged else None) for b in range(len(items))]

@@ -246,8 +246,9 @@ struct LaunchScope {   // brackets one kernel launch with events when profiling 
 template <typename R> void launch_mstep_acc(vbx_batch* b, double eps) {
     auto v = b->view<R>(eps);
     LaunchScope ls(b, VBX_K_MSTEP_ACC);
-    dim3 grid(b->ntiles_total, b->Dp / 32);
-    NT_SWITCH(b->NT, hipLaunchKernelGGL((mstep_acc_kernel<R, kNT>), grid, dim3(64), 0, b->ctx->stream, v);)
+    const int nt = std::min(b->NT, 16);                       // (more than 256 speakers: blocks of 16 tiles along grid z)
+    dim3 grid(b->ntiles_total, b->Dp / 32, b->NT / nt);
+    NT_SWITCH(nt, hipLaunchKernelGGL((mstep_acc_kernel<R, kNT>), grid, dim3(64), 0, b->ctx->stream, v);)
 }
 
 static int small_kernel_threads(const vbx_batch* b, int from_tiles);
@@ -267,8 +268,11 @@ template <typename R> void launch_loglik(vbx_batch* b, double eps, bool raw) {
     auto v = b->view<R>(eps);
     LaunchScope ls(b, VBX_K_LOGLIK);
     R* lraw = raw ? (R*)b->d_lraw : nullptr;
-    NT_SWITCH(b->NT, hipLaunchKernelGGL((loglik_kernel<R, kNT>), dim3(b->ntiles_total), dim3(256), 0,
-                                        b->ctx->stream, v, lraw);)
+    const int nt = std::min(b->NT, 16);
+    NT_SWITCH(nt, hipLaunchKernelGGL((loglik_kernel<R, kNT>), dim3(b->ntiles_total, b->NT / nt), dim3(256), 0,
+                                     b->ctx->stream, v, lraw);)
+    if (b->NT > nt)          // the row maximum spans several speaker blocks
+        hipLaunchKernelGGL((rownorm_kernel<R>), dim3(b->ntiles_total), dim3(256), 0, b->ctx->stream, v);
 }
 
 // Block size of the per-recording reductions over tiles (mstep_fin, iter_fin): 1024 threads once a recording has more
@@ -277,7 +281,7 @@ template <typename R> void launch_loglik(vbx_batch* b, double eps, bool raw) {
 static int small_kernel_threads(const vbx_batch* b, int from_tiles) {
     int maxtiles = 0;
     for (auto& rd : b->recs) maxtiles = std::max(maxtiles, rd.ntiles);
-    return maxtiles > from_tiles ? 1024 : 256;
+    return (maxtiles > from_tiles || b->Sp > 256) ? 1024 : 256;        // (iter_fin: a thread per speaker)
 }
 
 // chunk_post over the tiles of the batch; REPLAY: the instance that only writes the responsibilities
@@ -379,6 +383,8 @@ template <typename R> void launch_fb(vbx_batch* b, double eps, bool fused_post =
         case 1: hipLaunchKernelGGL((fb_seq_kernel<R, 1>), dim3(b->n_rec), dim3(128), 0, b->ctx->stream, v); break;
         case 2: hipLaunchKernelGGL((fb_seq_kernel<R, 2>), dim3(b->n_rec), dim3(128), 0, b->ctx->stream, v); break;
         case 4: hipLaunchKernelGGL((fb_seq_kernel<R, 4>), dim3(b->n_rec), dim3(128), 0, b->ctx->stream, v); break;
+        case 8: hipLaunchKernelGGL((fb_seq_kernel<R, 8>), dim3(b->n_rec), dim3(128), 0, b->ctx->stream, v); break;
+        case 16: hipLaunchKernelGGL((fb_seq_kernel<R, 16>), dim3(b->n_rec), dim3(128), 0, b->ctx->stream, v); break;
         default: break;
     }
 }
@@ -393,6 +399,8 @@ template <typename R> void launch_post(vbx_batch* b, double eps) {
         case 64: hipLaunchKernelGGL((post_kernel<R, 64>), grid, block, 0, b->ctx->stream, v); break;
         case 128: hipLaunchKernelGGL((post_kernel<R, 128>), grid, block, 0, b->ctx->stream, v); break;
         case 256: hipLaunchKernelGGL((post_kernel<R, 256>), grid, block, 0, b->ctx->stream, v); break;
+        case 512: hipLaunchKernelGGL((post_kernel<R, 512>), grid, block, 0, b->ctx->stream, v); break;
+        case 1024: hipLaunchKernelGGL((post_kernel<R, 1024>), grid, block, 0, b->ctx->stream, v); break;
         default: break;
     }
 }
@@ -495,6 +503,10 @@ int choose_fb_algo(vbx_batch* b, bool step_api_logs) {
     for (auto& rd : b->recs) maxtiles = std::max(maxtiles, rd.ntiles);
     bool chunked = b->fb_algo == VBX_FB_CHUNKED || (b->fb_algo == VBX_FB_AUTO && maxtiles >= 3);
     if (step_api_logs) chunked = false;      // lfw/lbw reconstruction uses the sequential kernel's scales
+    // More than 256 states: an S x S transfer operator per chunk is 1 - 4 MB and its build S^2 operations per frame -- the
+    // O(T S) sequential walk (one wavefront per direction, 8 / 16 states per lane) is the better deal there.  The
+    // reference takes any S (VBx.py:76-85); this path is about taking it at all, not about speed.
+    if (b->Sp > 256) chunked = false;
     if (chunked && !b->d_op) {
         const size_t rs = b->rsize, nt = (size_t)b->ntiles_total, sp = (size_t)b->Sp;
         int rc = dmalloc_bytes(b->ctx, &b->d_op, nt * sp * sp * rs);

@@ -143,7 +143,8 @@ __global__ __launch_bounds__(256) void prep_kernel(const XT* __restrict__ X, con
 // =======================================================================================
 // M-step accumulation: C[s][d] = sum_t gamma[t][s] rho[t][d] for one tile of frames and one
 // 32-column slab of d, on MFMA 16x16x4 (A = gamma^T fragment, B = rho fragment).      VBx.py:96
-// grid = (ntiles_total, Dp/32), block = 64 (one wavefront).
+// grid = (ntiles_total, Dp/32, speaker blocks of 16 NT), block = 64 (one wavefront); more than 256 speakers: NT = 16 and
+// several speaker blocks.
 //   k-step = 4 frames: lane group g = lane>>4 supplies frame k0+g.
 //   B fragment: lane (j,g) loads rho[k0+g][d0+2j .. d0+2j+1] as one 8/16-byte load; the two
 //   values feed two N-tiles whose column j means d = d0 + 2j + {0,1} (free relabelling of N).
@@ -162,7 +163,8 @@ __global__ __launch_bounds__(64) void mstep_acc_kernel(BatchView<R> bt) {
     const int tend = min(t0 + kTileFrames, rd.T);
     const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
     const int d0 = blockIdx.y * 32;
-    const R* __restrict__ gam = bt.gamma + rd.row0 * Sp;
+    const int s0 = blockIdx.z * 16 * NT;              // first speaker of this block
+    const R* __restrict__ gam = bt.gamma + rd.row0 * Sp + s0;
     const R* __restrict__ rho = bt.rho + rd.rho_row0 * Dp;
 
     acc_t acc[NT][2];
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(64) void mstep_acc_kernel(BatchView<R> bt) {
             }
         }
     }
-    R* __restrict__ part = bt.mpart + (long long)tile * Sp * Dp;
+    R* __restrict__ part = bt.mpart + ((long long)tile * Sp + s0) * Dp;
 #pragma unroll
     for (int mu = 0; mu < NT; ++mu) {
 #pragma unroll
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(64) void mstep_acc_kernel(BatchView<R> bt) {
             R v = nsum[mu];
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
-            if (g == 0) bt.npart[(long long)tile * Sp + 16 * mu + i] = v;
+            if (g == 0) bt.npart[(long long)tile * Sp + s0 + 16 * mu + i] = v;
         }
     }
 }
@@ -309,7 +311,9 @@ __global__ __launch_bounds__(1024) void mstep_fin_kernel(BatchView<R> bt) {     
 //   l[t][s] = Fa * (rho_t . alpha_s + bias_s)      (the per-frame G term is left out: it
 //   cancels in gamma and pi and enters the ELBO once as Fa * sum_t G_t)
 // epilogue: m_t = max_s l, b = exp(l - m_t) -> bmat, mrow.
-// grid = ntiles_total, block = 256: wave w owns frames [t0+32w, t0+32w+32) = 2 M-tiles.
+// grid = (ntiles_total, speaker blocks of 16 NT), block = 256: wave w owns frames [t0+32w, t0+32w+32) = 2 M-tiles.  With
+// more than one speaker block (S > 256) the row maximum is not known here: the kernel leaves l itself in bmat and
+// rownorm_kernel turns it into m_t and b.
 //   K is relabelled so that lane group g supplies k = 16q + 4g + r for MFMA r of block q:
 //   one 16-byte load per lane feeds four MFMAs, for A (rho rows) and B (alpha rows) alike.
 // =======================================================================================
@@ -325,8 +329,10 @@ __global__ __launch_bounds__(256) void loglik_kernel(BatchView<R> bt, R* __restr
     const int Sp = bt.Sp, Dp = bt.Dp;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
     const int f0 = bt.tile_t0[tile] + 32 * wave;
+    const int s0 = blockIdx.y * 16 * NT;              // first speaker of this block
+    const bool tiled = gridDim.y > 1;
     const R* __restrict__ rho = bt.rho + rd.rho_row0 * Dp;
-    const R* __restrict__ alpha = bt.alpha + (long long)rec * Sp * Dp;
+    const R* __restrict__ alpha = bt.alpha + ((long long)rec * Sp + s0) * Dp;
 
     acc_t acc[2][NT];
 #pragma unroll
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(256) void loglik_kernel(BatchView<R> bt, R* __restr
     const R Fa = (R)rd.Fa;
     R biasv[NT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) biasv[n] = bt.bias[(long long)rec * Sp + 16 * n + i];
+    for (int n = 0; n < NT; ++n) biasv[n] = bt.bias[(long long)rec * Sp + s0 + 16 * n + i];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -387,21 +393,41 @@ __global__ __launch_bounds__(256) void loglik_kernel(BatchView<R> bt, R* __restr
             R mx = neg_inf<R>();
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                const int s = 16 * n + i;
+                const int s = s0 + 16 * n + i;
                 v[n] = (s < rd.S) ? Fa * (acc[m][n][r] + biasv[n]) : neg_inf<R>();
                 mx = vmax(mx, v[n]);
             }
             mx = allreduce_max<16>(mx);
             if (frame < rd.T) {
-                const long long cell = (rd.row0 + frame) * Sp;
+                const long long cell = (rd.row0 + frame) * Sp + s0;
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
-                    bt.bmat[cell + 16 * n + i] = exp_r(v[n] - mx);
+                    bt.bmat[cell + 16 * n + i] = tiled ? v[n] : exp_r(v[n] - mx);
                     if (lraw) lraw[cell + 16 * n + i] = v[n];
                 }
-                if (i == 0) bt.mrow[rd.row0 + frame] = mx;
+                if (!tiled && i == 0) bt.mrow[rd.row0 + frame] = mx;
             }
         }
+    }
+}
+
+// More than 256 speakers: m_t = max_s l, b = exp(l - m_t) over the rows loglik_kernel left in bmat (VBx.py:97 epilogue).
+// grid = ntiles_total, block = 256: one wavefront per frame row.
+template <typename R>
+__global__ __launch_bounds__(256) void rownorm_kernel(BatchView<R> bt) {
+    const int tile = blockIdx.x;
+    const int rec = bt.tile_rec[tile];
+    if (bt.state[rec].done) return;
+    const RecDesc rd = bt.recs[rec];
+    const int Sp = bt.Sp, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t0 = bt.tile_t0[tile], tend = min(t0 + kTileFrames, rd.T);
+    for (int f = t0 + wave; f < tend; f += 4) {
+        R* __restrict__ row = bt.bmat + (rd.row0 + f) * Sp;
+        R mx = neg_inf<R>();
+        for (int s = lane; s < Sp; s += 64) mx = vmax(mx, row[s]);
+        mx = allreduce_max<64>(mx);
+        for (int s = lane; s < Sp; s += 64) row[s] = exp_r(row[s] - mx);
+        if (lane == 0) bt.mrow[rd.row0 + f] = mx;
     }
 }
 
@@ -421,7 +447,7 @@ struct RowBlock {
 
 template <typename R, int NREG>
 __global__ __launch_bounds__(128) void fb_seq_kernel(BatchView<R> bt) {
-    constexpr int U = 8;
+    constexpr int U = NREG <= 4 ? 8 : NREG <= 8 ? 4 : 2;      // rows in flight per block: 2 x U x NREG registers
     const int rec = blockIdx.x;
     if (bt.state[rec].done) return;
     const RecDesc rd = bt.recs[rec];

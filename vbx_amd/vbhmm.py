@@ -208,10 +208,14 @@ def _small_blas_pool():
     if os.environ.get('VBX_AMD_TUNE_HOST', '1') == '0':
         return contextlib.nullcontext()
     try:
-        from threadpoolctl import threadpool_limits
-        return threadpool_limits(limits=4, user_api='blas')
+        from threadpoolctl import threadpool_info, threadpool_limits
     except ImportError:
         return contextlib.nullcontext()
+    # never RAISE a pool: a BLAS that started with one thread (torchrun exports OMP_NUM_THREADS=1) has per-thread buffers
+    # for one, and scipy.linalg.eigh on a pool widened to four crashed in LAPACK (SIGSEGV, seen on both ranks of a node)
+    now = [i.get('num_threads', 1) for i in threadpool_info() if i.get('user_api') == 'blas']
+    limit = min([4] + now)
+    return threadpool_limits(limits=limit, user_api='blas')
 
 
 def tune_host_process():
@@ -276,7 +280,7 @@ def diarize(args, stages=None, log=print):
     four methods built on its checkers).  Returns ``({recording: dict(labels1st, labels2nd, n_iters, thr)}, timing)``
     for the recordings of this rank.
 
-    A recording the device path cannot take (more than ``VBX_MAX_SPEAKERS`` = 256 AHC clusters, or one whose batch
+    A recording the device path cannot take (more than ``VBX_MAX_SPEAKERS`` = 1024 AHC clusters, or one whose batch
     fails) does not take the archive down with it: every other recording is diarized and written, then a
     ``RuntimeError`` names the ones left out.  RTTM files are written as soon as their labels exist."""
     from .batch import shard_recordings
@@ -409,10 +413,12 @@ def main(argv=None):
     if int(os.environ.get('WORLD_SIZE', 1)) > 1:                  # launched by torchrun: one process per GPU
         import torch
         import torch.distributed as dist
+        # one GPU per rank (LOCAL_RANK); VBX_AMD_DEVICE / VBX_AMD_DIST_BACKEND override both, e.g. several ranks sharing
+        # one device over gloo (RCCL refuses two ranks on one GPU)
         if torch.cuda.is_available():
-            torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
             os.environ.setdefault('VBX_AMD_DEVICE', os.environ.get('LOCAL_RANK', '0'))
-        dist.init_process_group('nccl' if torch.cuda.is_available() else 'gloo')
+            torch.cuda.set_device(int(os.environ['VBX_AMD_DEVICE']))
+        dist.init_process_group(os.environ.get('VBX_AMD_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo'))
     error = None
     timing = None
     try:
