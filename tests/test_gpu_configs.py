@@ -8,6 +8,25 @@ after ONE iteration its gamma rows miss summing to one by 1e-7 (T = 10 000) to 1
 feeds the next M-step -- the first ELBO agrees to 2e-13, the second to 6e-10 (T = 10 000) / 3e-9 (T = 50 000), with the
 f64 kernels and with a float64 NumPy model of the linear-domain recursion alike.  Every measured
 deviation is also written to gpurun_out/config_parity.json so that the margins can be read off a run.
+
+What "within 1e-4 on fp32" is applied to, quantity by quantity (check() below), with the margins of round 2
+(profiles/r02_config_parity.json; the fp32 path keeps N_s = sum_t gamma, every other reduction over T and all ELBO
+scalars in f64 from the per-chunk partial sums on -- mstep_fin / iter_fin -- so none of these is an accumulation error):
+
+  gamma, pi         max abs deviation <= 1e-4: the statement of BASELINE.json.  Largest: 8.9e-5 (headline shape after TWO
+                    iterations), 3.4e-5 (C3 after two), <= 1e-5 elsewhere, <= 5e-7 on every converged run.  Two or three
+                    iterations from a random start is where the EM map itself amplifies a rounding error most (DESIGN
+                    section 9: ~25x per iteration while speakers are still forming); the fixtures keep those points on purpose.
+  ELBO              relative <= 1e-6 (measured <= 4.4e-7).
+  alpha             max abs relative to max |alpha| <= 1e-4 (measured <= 1.4e-5).
+  invL              relative <= 2e-4: invL = 1 / (1 + Fa/Fb N_s Phi) carries the deviation of N_s = sum_t gamma of a speaker
+                    with little mass relative to ITS mass; measured 9.2e-5 (C3 after three iterations), 4.2e-5 (headline, two).
+  gamma_colsum_rel  |sum_t gamma - sum_t gamma_ref| / max(1, sum_t gamma_ref) <= 4e-4.  NOT a per-element figure: a sum over
+                    T = 10 000 ... 200 000 per-frame deviations that share a sign while mass is moving between two speakers,
+                    divided by the mass of the smaller one (floored at one frame).  Measured 1.16e-4 on C3 after two
+                    iterations (a speaker holding ~1 of 50 000 frames is off by 1e-4 frames), 1.2e-5 on the headline shape,
+                    <= 1e-5 elsewhere and <= 3e-7 converged.  The bound 4e-4 is the per-element bound times the few hundred
+                    frames such a speaker's deviations can add up over, relative to a floor of one frame.
 """
 import json
 import os
@@ -51,7 +70,7 @@ def check(name, precision, d, n_iters=None, T=10000):
     assert d['gamma'] <= tol, (name, precision, d)
     assert d['pi'] <= tol, (name, precision, d)
     assert d['Li_rel'] <= (2e-8 if precision == 'fp64' else 1e-6), (name, precision, d)
-    assert d['gamma_colsum_rel'] <= 4 * tol, (name, precision, d)      # (a sum over T frames)
+    assert d['gamma_colsum_rel'] <= 4 * tol, (name, precision, d)      # (a sum over T frames: module docstring)
     if 'alpha' in d:
         assert d['alpha'] <= tol and d['invL_rel'] <= 2 * tol, (name, precision, d)   # (invL through N_s = sum_t gamma)
 
