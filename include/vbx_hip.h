@@ -261,6 +261,12 @@ int vbx_scores_linkage_average(vbx_scores* sc, int64_t T, double* Z);
  * linkage matrix of scipy.cluster.hierarchy / fastcluster, bit for bit SciPy's.  Pure function, safe to call from
  * several threads at once (one recording per thread); needs no vbx_ctx. */
 int vbx_linkage_average(int64_t n, const double* condensed, double* Z);
+/* The same clustering in the form fastcluster 1.2 itself computes it (the package vbhmm.py:33,140-141 imports; SciPy is
+ * what this repository's fixtures were made with because fastcluster is not installed): weights divided before the update
+ * (d = s a + t b, s = n_a / (n_a + n_b)) and fastcluster's own chain bookkeeping (vbx_linkage.hpp).  Same tree and
+ * distances equal to rounding wherever no two candidate distances tie; selected by VBX_AMD_LINKAGE=fastcluster in the
+ * Python layer.  Restated from the published source -- parity with the package itself is unpinned. */
+int vbx_linkage_average_fastcluster(int64_t n, const double* condensed, double* Z);
 /* Flat clusters of the linkage matrix Z cut at cophenetic distance t: vbhmm.py:145-146 `fcluster(lin_mat, t,
  * criterion='distance')`.  labels: [n], numbered from 1 in SciPy's order (depth-first from the root). */
 int vbx_fcluster_distance(int64_t n, const double* Z, double t, int32_t* labels);

@@ -406,6 +406,90 @@ def test_device_linkage_is_the_host_linkage_bit_for_bit(kind):
         assert np.array_equal(np.signbit(got), np.signbit(want))
 
 
+def _upgma_check(y, Z):
+    """Z is a valid average-linkage dendrogram of the condensed distances y: every merge distance is the mean pairwise
+    distance between the two merged clusters (to rounding), heights do not decrease, sizes add up."""
+    from scipy.spatial.distance import squareform
+    n = len(Z) + 1
+    full = squareform(y) if n > 2 else np.array([[0.0, y[0]], [y[0], 0.0]])
+    members = {i: [i] for i in range(n)}
+    for k, (a, b, d, m) in enumerate(Z):
+        A, B = members.pop(int(a)), members.pop(int(b))
+        assert a < b and m == len(A) + len(B)
+        np.testing.assert_allclose(d, full[np.ix_(A, B)].mean(), rtol=1e-12, atol=1e-13)
+        members[n + k] = A + B
+    assert np.all(np.diff(Z[:, 2]) >= -1e-13)
+
+
+@pytest.mark.parametrize('case', ['cosine', 'real', 'ties', 'near_ties'])
+def test_fastcluster_form_of_the_average_linkage(case):
+    """vbhmm.py:140-141 calls fastcluster.linkage; every fixture here was made with SciPy's linkage because fastcluster is
+    not installed.  ``linkage_average(y, 'fastcluster')`` restates the package's own routine (weights divided before the
+    update, its own chain bookkeeping: vbx_linkage.hpp).  Without ties: the same tree as SciPy's form, distances equal
+    to a few units in the last place, the same flat clusters at any threshold that is not within rounding of a merge
+    height.  With exact or near ties either form may pick another, equally valid, merge: both are checked to be average
+    linkage dendrograms of the input."""
+    from vbx_amd import _capi
+    from scipy.cluster.hierarchy import fcluster
+    rng = np.random.default_rng(11)
+    ys = []
+    if case == 'cosine':
+        for n in (2, 3, 4, 9, 64, 257, 700):
+            x = rng.standard_normal((n, 12))
+            x /= np.linalg.norm(x, axis=1, keepdims=True)
+            ys.append(np.ascontiguousarray(-(x @ x.T)[np.triu_indices(n, 1)]))
+    elif case == 'real':
+        x = np.load(GOLD)['xvecs'].astype(np.float64)         # the example recording, raw x-vectors
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+        ys = [np.ascontiguousarray(-(x[:400] @ x[:400].T)[np.triu_indices(400, 1)]),
+              np.ascontiguousarray(-(x @ x.T)[np.triu_indices(len(x), 1)])]
+    elif case == 'ties':
+        ys = [rng.integers(0, 4, size=n * (n - 1) // 2).astype(float) for n in (5, 6, 33, 150)]
+    else:
+        for n in (30, 200):                                    # distances that differ in their last bits only
+            base = rng.integers(1, 5, size=n * (n - 1) // 2).astype(float)
+            ys.append(base * (1.0 + rng.integers(-2, 3, size=base.size) * 2.0 ** -52))
+    for y in ys:
+        n = int(round((1 + np.sqrt(1 + 8 * y.size)) / 2))
+        Zs, Zf = _capi.linkage_average(y, 'scipy'), _capi.linkage_average(y, 'fastcluster')
+        shift = abs(y.min()) + 1.0                             # (the UPGMA check wants non-negative distances)
+        _upgma_check(y + shift, np.column_stack([Zs[:, :2], Zs[:, 2] + shift, Zs[:, 3]]))
+        _upgma_check(y + shift, np.column_stack([Zf[:, :2], Zf[:, 2] + shift, Zf[:, 3]]))
+        if case in ('cosine', 'real'):
+            assert np.array_equal(Zs[:, [0, 1, 3]], Zf[:, [0, 1, 3]]), (case, n)
+            assert np.abs(Zs[:, 2] - Zf[:, 2]).max() <= 4 * np.finfo(float).eps * max(1.0, np.abs(Zs[:, 2]).max())
+            if n > 2:
+                Zs2, Zf2 = Zs.copy(), Zf.copy()                  # (SciPy's fcluster wants non-negative heights: vbhmm.py:142-144)
+                Zs2[:, 2] += shift
+                Zf2[:, 2] += shift
+                for t in np.quantile(Zs2[:, 2], [0.3, 0.7, 0.95]) + 1e-9:
+                    assert np.array_equal(fcluster(Zs2, t, 'distance'), fcluster(Zf2, t, 'distance'))
+    with pytest.raises(ValueError):
+        _capi.linkage_average(np.zeros(3), 'ward')
+
+
+def test_both_linkage_forms_give_the_committed_example_clustering(monkeypatch):
+    """The one artefact made with the REAL fastcluster is the reference's exp/ES2005a.rttm (es2005a.npz: rttm_committed
+    equals what the SciPy stand-in produced, up to the numbering of the speakers).  It cannot tell the two forms apart:
+    on the example's score matrix both give the same tree and the same 31 clusters at the calibrated threshold."""
+    from vbx_amd import vbhmm
+    from oracle import ahc_oracle
+    ahc = np.load(os.path.join(os.path.dirname(GOLD), 'ahc_cases.npz'))
+    es = np.load(os.path.join(os.path.dirname(GOLD), 'es2005a.npz'))
+    x = ahc['es2005a/x']
+    scr = ahc_oracle.cos_similarity(x)
+    cond = np.ascontiguousarray(-scr[np.triu_indices(len(x), 1)])
+    labels = {}
+    for variant in ('scipy', 'fastcluster'):
+        monkeypatch.setenv('VBX_AMD_LINKAGE', variant)
+        labels[variant] = vbhmm.cluster(cond.copy(), float(ahc['es2005a/thr']), -0.015)
+    assert np.array_equal(labels['scipy'], labels['fastcluster'])
+    assert labels['scipy'].max() + 1 == es['qinit'].shape[1] == 31
+    assert np.array_equal(labels['scipy'], np.argmax(es['qinit'], axis=1))      # the labels the reference driver went on with
+    same = (es['rttm_committed'][:, :2] == es['rttm_produced'][:, :2]).all()
+    assert same and len(set(zip(es['rttm_committed'][:, 2], es['rttm_produced'][:, 2]))) == len(set(es['rttm_committed'][:, 2]))
+
+
 def test_top2_ties_keep_their_index_order():
     """(host-side statement of the tie rule the device arg-sort follows: a stable sort of -q)"""
     q = np.array([[0.5, 0.5, 0.0], [0.2, 0.4, 0.4], [0.0, 0.0, 1.0]])

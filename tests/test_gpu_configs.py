@@ -11,7 +11,7 @@ deviation is also written to gpurun_out/config_parity.json so that the margins c
 
 What "within 1e-4 on fp32" is applied to, quantity by quantity (check() below), with the margins of round 2
 (profiles/r02_config_parity.json; the fp32 path keeps N_s = sum_t gamma, every other reduction over T and all ELBO
-scalars in f64 from the per-chunk partial sums on -- mstep_fin / iter_fin -- so none of these is an accumulation error):
+scalars in f64 from the per-chunk partial sums on -- fin_kernel -- so none of these is an accumulation error):
 
   gamma, pi         max abs deviation <= 1e-4: the statement of BASELINE.json.  Largest: 8.9e-5 (headline shape after TWO
                     iterations), 3.4e-5 (C3 after two), <= 1e-5 elsewhere, <= 5e-7 on every converged run.  Two or three

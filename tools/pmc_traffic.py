@@ -27,7 +27,7 @@ def short(name):
     return 'chunk_post_replay' if m.group(1) == 'chunk_post' and m.group(2).rstrip().endswith('true') else m.group(1)
 
 
-ITERATION_KERNELS = ('mstep_fin', 'chunk_loglik', 'scan2', 'scan_compose', 'chunk_post', 'iter_fin')
+ITERATION_KERNELS = ('fin', 'chunk_loglik', 'scan2', 'scan_compose', 'chunk_post')     # (fin: M-step + iteration end, one launch)
 
 
 def per_kernel(path, counter):

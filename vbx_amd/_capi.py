@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     'vbx_batch_run', 'vbx_batch_get_result', 'vbx_batch_last_run_ms', 'vbx_batch_kernel_times',
     'vbx_run', 'vbx_forward_backward', 'vbx_forward_backward_dense', 'vbx_mstep', 'vbx_loglik',
     'vbx_cos_similarity', 'vbx_scores_upload', 'vbx_scores_count', 'vbx_scores_get', 'vbx_scores_get_condensed', 'vbx_scores_linkage_average',
-    'vbx_linkage_average', 'vbx_fcluster_distance', 'vbx_ark_index', 'vbx_gather_rows', 'vbx_batch_streams',
+    'vbx_linkage_average', 'vbx_linkage_average_fastcluster', 'vbx_fcluster_distance', 'vbx_ark_index', 'vbx_gather_rows', 'vbx_batch_streams',
     'vbx_scores_two_gmm_calib',
     'vbx_scores_destroy',
     'vbx_xvectors_project', 'vbx_xvectors_get', 'vbx_xvectors_destroy', 'vbx_cos_similarity_resident',
@@ -91,6 +91,7 @@ def load():
     lib.vbx_scores_get_condensed.argtypes = [vp, i64, dbl, vp]
     lib.vbx_scores_linkage_average.argtypes = [vp, i64, vp]
     lib.vbx_linkage_average.argtypes = [i64, vp, vp]
+    lib.vbx_linkage_average_fastcluster.argtypes = [i64, vp, vp]
     lib.vbx_fcluster_distance.argtypes = [i64, vp, dbl, vp]
     lib.vbx_ark_index.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp]
     lib.vbx_ark_index.restype = i64
@@ -485,9 +486,23 @@ class Batch:
 _default_ctx = {}
 
 
-def linkage_average(condensed):
-    """``scipy.cluster.hierarchy.linkage(condensed, method='average')`` (= ``fastcluster.linkage``) as native host
-    code: the (n - 1) x 4 linkage matrix, bit for bit SciPy's.  The call releases the GIL: one recording per thread."""
+def linkage_variant():
+    """'scipy' (default) or 'fastcluster' ($VBX_AMD_LINKAGE): which package's arithmetic the average linkage follows."""
+    v = os.environ.get('VBX_AMD_LINKAGE', 'scipy').lower()
+    if v not in ('scipy', 'fastcluster'):
+        raise ValueError(f"VBX_AMD_LINKAGE={v!r}: expected 'scipy' or 'fastcluster'")
+    return v
+
+
+def linkage_average(condensed, variant=None):
+    """``linkage(condensed, method='average')`` as native host code: the (n - 1) x 4 linkage matrix.  ``variant='scipy'``
+    (default, or $VBX_AMD_LINKAGE): bit for bit ``scipy.cluster.hierarchy.linkage``; ``'fastcluster'``: the form
+    ``fastcluster.linkage`` computes (vbhmm.py:140-141) -- weights divided before the update, its own chain bookkeeping --
+    restated from the package's published source.  Same tree, distances equal to rounding, wherever no two candidate
+    distances tie.  The call releases the GIL: one recording per thread."""
+    variant = variant or linkage_variant()
+    if variant not in ('scipy', 'fastcluster'):
+        raise ValueError(f"linkage_average: variant {variant!r}: expected 'scipy' or 'fastcluster'")
     y = np.ascontiguousarray(condensed, dtype=np.float64)
     if y.ndim != 1:
         raise ValueError('linkage_average expects a condensed distance vector')
@@ -495,7 +510,8 @@ def linkage_average(condensed):
     if n * (n - 1) // 2 != y.size or n < 2:
         raise ValueError(f'{y.size} is not the length n (n - 1) / 2 of a condensed distance vector')
     Z = np.empty((n - 1, 4))
-    rc = load().vbx_linkage_average(n, _ptr(y), _ptr(Z))
+    fn = load().vbx_linkage_average_fastcluster if variant == 'fastcluster' else load().vbx_linkage_average
+    rc = fn(n, _ptr(y), _ptr(Z))
     if rc != 0:
         raise VbxError(f'vbx_linkage_average failed ({rc})')
     return Z

@@ -141,7 +141,10 @@ struct vbx_batch {
     double* d_pi_prev = nullptr;
     // device memory
     RecDesc* d_recs = nullptr;
-    RecState* d_state = nullptr;
+    RecState* d_state = nullptr;                  // two copies of [n_rec] (fin_kernel): the latest one is d_state + state_cur * n_rec
+    int state_cur = 0;
+    bool fin_pending = false;                     // an iteration has been launched whose finishing role has not run yet
+    double run_epsilon = 0.0;
     int *d_tile_rec = nullptr, *d_tile_t0 = nullptr, *d_tile_done = nullptr;
     // recordings that share a rho (vbx_batch_set_recording_shared): who shares with whom, and the workgroup -> tile table
     // that puts the chunks reading one rho tile side by side on one XCD
@@ -190,7 +193,9 @@ struct vbx_batch {
         BatchView<R> v;
         v.n_rec = n_rec; v.Sp = Sp; v.Dp = Dp; v.D = D; v.max_iters = max_iters;
         v.ntiles_total = ntiles_total;
-        v.recs = d_recs; v.state = d_state; v.tile_rec = d_tile_rec; v.tile_t0 = d_tile_t0; v.tile_desc = d_tile_desc; v.tile_done = d_tile_done;
+        v.recs = d_recs; v.state = d_state + (size_t)state_cur * n_rec; v.state_out = d_state + (size_t)(state_cur ^ 1) * n_rec;
+        v.model_stride = (long long)n_rec * Sp * Dp; v.vec_stride = n_rec * Sp;
+        v.tile_rec = d_tile_rec; v.tile_t0 = d_tile_t0; v.tile_desc = d_tile_desc; v.tile_done = d_tile_done;
         v.tile_order = d_tile_order;
         v.phi = d_phi;
         v.rho = (R*)d_rho; v.gamma = (R*)d_gamma; v.bmat = (R*)d_bmat; v.mrow = (R*)d_mrow;
@@ -253,15 +258,18 @@ template <typename R> void launch_mstep_acc(vbx_batch* b, double eps) {
 
 static int small_kernel_threads(const vbx_batch* b, int from_tiles);
 
-template <typename R> void launch_mstep_fin(vbx_batch* b, double eps) {
+// fin_kernel (vbx_kernels.hpp): mode 1 = start an iteration (M-step), 2 = finish one (ELBO, pi, convergence), 3 = finish
+// the previous one and start the next in the same launch.  A launch with a finishing role writes the other state copy.
+template <typename R> void launch_fin(vbx_batch* b, double eps, int mode) {
     auto v = b->view<R>(eps);
-    LaunchScope ls(b, VBX_K_MSTEP_FIN);
-    hipLaunchKernelGGL((mstep_fin_kernel<R>), dim3(b->n_rec, b->Sp), dim3(small_kernel_threads(b, 640)), 0, b->ctx->stream, v);
+    LaunchScope ls(b, mode == 2 ? VBX_K_ITER_FIN : VBX_K_MSTEP_FIN);
+    hipLaunchKernelGGL((fin_kernel<R>), dim3(b->n_rec, b->Sp + 1), dim3(small_kernel_threads(b, 80)), 0, b->ctx->stream, v, mode);
+    if (mode & 2) b->state_cur ^= 1;
 }
 
 template <typename R> void launch_mstep(vbx_batch* b, double eps) {
     launch_mstep_acc<R>(b, eps);
-    launch_mstep_fin<R>(b, eps);
+    launch_fin<R>(b, eps, 1);
 }
 
 template <typename R> void launch_loglik(vbx_batch* b, double eps, bool raw) {
@@ -405,19 +413,17 @@ template <typename R> void launch_post(vbx_batch* b, double eps) {
     }
 }
 
-template <typename R> void launch_iter_fin(vbx_batch* b, double eps) {
-    auto v = b->view<R>(eps);
-    LaunchScope ls(b, VBX_K_ITER_FIN);
-    hipLaunchKernelGGL((iter_fin_kernel<R>), dim3(b->n_rec), dim3(small_kernel_threads(b, 80)), 0, b->ctx->stream, v);
-}
-
 template <typename R> void launch_iteration(vbx_batch* b, double eps) {
     b->fused_now = fused_available<R>(b);
+    // the previous iteration of this run (if any) is finished by the launch that starts this one; the last one of a run
+    // by run_end
+    const int fin_mode = b->fin_pending ? 3 : 1;
+    b->fin_pending = true;
     if (b->fused_now) {
         // chunk_post leaves gamma^T rho of the gamma it has just written in mpart/npart, so only the
         // first iteration after an upload needs the stand-alone accumulation
         if (!b->mpart_valid) launch_mstep_acc<R>(b, eps);
-        launch_mstep_fin<R>(b, eps);
+        launch_fin<R>(b, eps, fin_mode);
         const bool fl = fused_loglik_available<R>(b);
         // half-tile re-runs: most where the chains' latency is exposed (one recording 65 -> 58 us per iteration, fp64
         // batches -13 %), a few percent with thousands of f32 tiles in flight (there the operator build is
@@ -425,16 +431,15 @@ template <typename R> void launch_iteration(vbx_batch* b, double eps) {
         b->half_ops_now = fl && b->split_tiles != 2;
         if (!fl) launch_loglik<R>(b, eps, false);
         launch_fb<R>(b, eps, true, fl);
-        launch_iter_fin<R>(b, eps);
         b->mpart_valid = true;
         b->gamma_stale = true;
         return;
     }
-    launch_mstep<R>(b, eps);
+    launch_mstep_acc<R>(b, eps);
+    launch_fin<R>(b, eps, fin_mode);
     launch_loglik<R>(b, eps, false);
     launch_fb<R>(b, eps);
     launch_post<R>(b, eps);
-    launch_iter_fin<R>(b, eps);
     b->mpart_valid = false;
 }
 
@@ -816,7 +821,7 @@ static int leaf_create(vbx_ctx* ctx, int n_rec, const int64_t* T, const int32_t*
     int rc = VBX_OK;
 #define ALLOC(expr) if (rc == VBX_OK) rc = (expr)
     ALLOC(dmalloc(ctx, &b->d_recs, n_rec));
-    ALLOC(dmalloc(ctx, &b->d_state, n_rec));
+    ALLOC(dmalloc(ctx, &b->d_state, (size_t)2 * n_rec));
     ALLOC(dmalloc(ctx, &b->d_tile_rec, b->ntiles_total));
     ALLOC(dmalloc(ctx, &b->d_tile_t0, b->ntiles_total));
     const int ntiles_pad = (b->ntiles_total + 3) / 4 * 4;
@@ -830,12 +835,12 @@ static int leaf_create(vbx_ctx* ctx, int n_rec, const int64_t* T, const int32_t*
     ALLOC(dmalloc_bytes(ctx, &b->d_gamma, cells * rs));
     ALLOC(dmalloc_bytes(ctx, &b->d_bmat, (cells + (size_t)kTileFrames * b->Sp) * rs));     // (+ one tile, like rho)
     ALLOC(dmalloc_bytes(ctx, &b->d_mrow, (size_t)b->sum_T * rs));
-    ALLOC(dmalloc_bytes(ctx, &b->d_alpha, (size_t)n_rec * b->Sp * b->Dp * rs));
-    ALLOC(dmalloc_bytes(ctx, &b->d_invL, (size_t)n_rec * b->Sp * b->Dp * rs));
-    ALLOC(dmalloc_bytes(ctx, &b->d_bias, (size_t)n_rec * b->Sp * rs));
+    ALLOC(dmalloc_bytes(ctx, &b->d_alpha, (size_t)2 * n_rec * b->Sp * b->Dp * rs));     // (two copies: fin_kernel)
+    ALLOC(dmalloc_bytes(ctx, &b->d_invL, (size_t)2 * n_rec * b->Sp * b->Dp * rs));
+    ALLOC(dmalloc_bytes(ctx, &b->d_bias, (size_t)2 * n_rec * b->Sp * rs));
     ALLOC(dmalloc_bytes(ctx, &b->d_mpart, (size_t)b->ntiles_total * b->Sp * b->Dp * rs));
     ALLOC(dmalloc_bytes(ctx, &b->d_npart, (size_t)b->ntiles_total * b->Sp * rs));
-    ALLOC(dmalloc(ctx, &b->d_emodel, (size_t)n_rec * b->Sp));
+    ALLOC(dmalloc(ctx, &b->d_emodel, (size_t)2 * n_rec * b->Sp));
     ALLOC(dmalloc(ctx, &b->d_pi, (size_t)n_rec * b->Sp));
     ALLOC(dmalloc(ctx, &b->d_pi_prev, (size_t)n_rec * b->Sp));
     ALLOC(dmalloc_bytes(ctx, &b->d_gamma0, (size_t)n_rec * b->Sp * rs));
@@ -855,7 +860,7 @@ static int leaf_create(vbx_ctx* ctx, int n_rec, const int64_t* T, const int32_t*
         (e = hipMemset(b->d_tile_done, 0, sizeof(int) * ntiles_pad)) != hipSuccess ||
         (e = hipMemset(b->d_pi_prev, 0, sizeof(double) * (size_t)n_rec * b->Sp)) != hipSuccess ||
         (e = hipMemset((char*)b->d_bmat + cells * rs, 0, (size_t)kTileFrames * b->Sp * rs)) != hipSuccess ||
-        (e = hipMemset(b->d_state, 0, sizeof(RecState) * n_rec)) != hipSuccess ||
+        (e = hipMemset(b->d_state, 0, sizeof(RecState) * 2 * n_rec)) != hipSuccess ||
         (e = hipMemset(b->d_gamma, 0, cells * rs)) != hipSuccess ||
         (e = hipMemset((char*)b->d_rho + (size_t)b->sum_T * b->Dp * rs, 0, (size_t)kTileFrames * b->Dp * rs)) != hipSuccess ||
         (e = hipDeviceSynchronize()) != hipSuccess ||      // null-stream memsets vs. our non-blocking stream
@@ -963,6 +968,7 @@ int set_recording_impl(vbx_batch* b, int rec, const void* X, int x_dtype, const 
     RecState st;
     std::memset(&st, 0, sizeof st);
     HIPCHK(ctx, hipMemcpyAsync(b->d_state + rec, &st, sizeof st, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(b->d_state + b->n_rec + rec, &st, sizeof st, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(b->d_tile_done + rd.tile0, 0, sizeof(int) * rd.ntiles, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // host vectors go out of scope below
     if (X) {
@@ -1018,6 +1024,7 @@ int set_recording_resident_impl(vbx_batch* b, int rec, const double* d_fea, cons
     RecState st;
     std::memset(&st, 0, sizeof st);
     HIPCHK(ctx, hipMemcpyAsync(b->d_state + rec, &st, sizeof st, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(b->d_state + b->n_rec + rec, &st, sizeof st, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(b->d_tile_done + rd.tile0, 0, sizeof(int) * rd.ntiles, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipGetLastError());
@@ -1191,6 +1198,7 @@ static int run_begin(vbx_batch* b, int max_iters) {
 }
 
 static void run_launch(vbx_batch* b, double epsilon) {
+    b->run_epsilon = epsilon;
     if (b->precision == VBX_PREC_FP64) launch_iteration<double>(b, epsilon);
     else launch_iteration<float>(b, epsilon);
     ++b->iters_launched;
@@ -1200,7 +1208,7 @@ static void run_launch(vbx_batch* b, double epsilon) {
 static int run_all_done(vbx_batch* b, bool* all_done) {
     vbx_ctx* ctx = b->ctx;
     std::vector<RecState> st(b->n_rec);
-    HIPCHK(ctx, hipMemcpyAsync(st.data(), b->d_state, sizeof(RecState) * b->n_rec, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(st.data(), b->d_state + (size_t)b->state_cur * b->n_rec, sizeof(RecState) * b->n_rec, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     *all_done = true;
     for (auto& s : st) *all_done = *all_done && s.done;
@@ -1227,6 +1235,11 @@ template <typename R> void launch_gamma_replay(vbx_batch* b) {
 
 static int run_end(vbx_batch* b) {
     vbx_ctx* ctx = b->ctx;
+    if (b->fin_pending) {                     // the last iteration launched: ELBO, pi, history, convergence
+        if (b->precision == VBX_PREC_FP64) launch_fin<double>(b, b->run_epsilon, 2);
+        else launch_fin<float>(b, b->run_epsilon, 2);
+        b->fin_pending = false;
+    }
     if (b->gamma_stale) {
         if (b->precision == VBX_PREC_FP64) launch_gamma_replay<double>(b);
         else launch_gamma_replay<float>(b);
@@ -1265,7 +1278,7 @@ int get_result_impl(vbx_batch* b, int rec, double* gamma, double* pi, double* Li
     const RecDesc& rd = b->recs[rec];
     const int Sp = b->Sp, Dp = b->Dp, S = rd.S, D = b->D;
     RecState st;
-    HIPCHK(ctx, hipMemcpy(&st, b->d_state + rec, sizeof st, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(&st, b->d_state + (size_t)b->state_cur * b->n_rec + rec, sizeof st, hipMemcpyDeviceToHost));
     if (n_iters) *n_iters = st.n_iters;
     if (warned) *warned = st.warned;
     if (gamma) {
@@ -1284,9 +1297,12 @@ int get_result_impl(vbx_batch* b, int rec, double* gamma, double* pi, double* Li
         if (n > 0) HIPCHK(ctx, hipMemcpy(Li, b->d_Li + (size_t)rec * b->max_iters, sizeof(double) * n, hipMemcpyDeviceToHost));
     }
     if (alpha || invL) {
+        // the model of the last iteration that ran, n_iters - 1, lives in copy (n_iters - 1) & 1 (fin_kernel); before any
+        // iteration: copy 0, where a caller's alpha / invL went
+        const size_t copy = st.n_iters > 0 ? (size_t)((st.n_iters - 1) & 1) * b->n_rec * Sp * Dp : 0;
         std::vector<R> a((size_t)Sp * Dp), il((size_t)Sp * Dp);
-        HIPCHK(ctx, hipMemcpy(a.data(), (R*)b->d_alpha + (size_t)rec * Sp * Dp, sizeof(R) * a.size(), hipMemcpyDeviceToHost));
-        HIPCHK(ctx, hipMemcpy(il.data(), (R*)b->d_invL + (size_t)rec * Sp * Dp, sizeof(R) * il.size(), hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(a.data(), (R*)b->d_alpha + copy + (size_t)rec * Sp * Dp, sizeof(R) * a.size(), hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(il.data(), (R*)b->d_invL + copy + (size_t)rec * Sp * Dp, sizeof(R) * il.size(), hipMemcpyDeviceToHost));
         for (int s = 0; s < S; ++s)
             for (int d = 0; d < D; ++d) {
                 if (alpha) alpha[(size_t)s * D + d] = (double)a[(size_t)s * Dp + d];
@@ -1699,7 +1715,7 @@ int fb_step_impl(vbx_batch* b, int64_t T, int32_t S, const double* lls, double* 
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipGetLastError());
     RecState st;
-    HIPCHK(ctx, hipMemcpy(&st, b->d_state, sizeof st, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(&st, b->d_state + (size_t)b->state_cur * b->n_rec, sizeof st, hipMemcpyDeviceToHost));
     if (b->use_chunked) {
         std::vector<double> tp((size_t)b->ntiles_total);
         HIPCHK(ctx, hipMemcpy(tp.data(), b->d_tllpart, sizeof(double) * tp.size(), hipMemcpyDeviceToHost));
@@ -1924,7 +1940,7 @@ int vbx_loglik(vbx_ctx* ctx, int64_t T, int32_t S, int32_t D, const double* X, c
         auto go = [&](auto tag) {
             using R = decltype(tag);
             auto v = b->view<R>(0.0);
-            hipLaunchKernelGGL((mstep_fin_kernel<R>), dim3(b->n_rec, b->Sp), dim3(small_kernel_threads(b, 640)), 0, ctx->stream, v);
+            launch_fin<R>(b, 0.0, 1);
             launch_loglik<R>(b, 0.0, true);
         };
         if (precision == VBX_PREC_FP64) go(double{}); else go(float{});
@@ -2186,6 +2202,17 @@ int vbx_linkage_average(int64_t n, const double* condensed, double* Z) {
         vbx::average_linkage(n, condensed, Z);
     } catch (const std::bad_alloc&) {
         return VBX_ERR_HIP - 100;                            // host allocation failure (no ctx to carry a message)
+    }
+    return VBX_OK;
+}
+
+int vbx_linkage_average_fastcluster(int64_t n, const double* condensed, double* Z) {
+    if (n < 1 || (n > 1 && (!condensed || !Z))) return VBX_ERR_INVALID;
+    if (n > 65536) return VBX_ERR_UNSUPPORTED;
+    try {
+        vbx::average_linkage_fastcluster(n, condensed, Z);
+    } catch (const std::bad_alloc&) {
+        return VBX_ERR_HIP - 100;
     }
     return VBX_OK;
 }

@@ -45,7 +45,9 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)si
     const int tile = tile_of_block(bt, blockIdx.x);
     if (tile < 0) return;
     const int rec = bt.tile_rec[tile];
-    if (bt.state[rec].done) return;
+    const RecState st = bt.state[rec];
+    if (st.done) return;
+    const int par = st.n_iters & 1;                    // the model of the iteration in flight (fin_kernel)
     const RecDesc rd = bt.recs[rec];
     const int Dp = bt.Dp;
     // (the wave index as a scalar: everything derived from it -- frame ranges, loop bounds, roles -- stays in SGPRs)
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)si
     {
         const int f0 = t0 + 32 * wave;
         const R* __restrict__ rho = bt.rho + rd.rho_row0 * Dp;
-        const R* __restrict__ alpha = bt.alpha + (long long)rec * SP * Dp;
+        const R* __restrict__ alpha = bt.alpha + (long long)par * bt.model_stride + (long long)rec * SP * Dp;
         acc_t acc[2][NT];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)si
         const R Fa = (R)rd.Fa;
         R biasv[NT];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) biasv[n] = bt.bias[(long long)rec * SP + 16 * n + i];
+        for (int n = 0; n < NT; ++n) biasv[n] = bt.bias[(long long)par * bt.vec_stride + (long long)rec * SP + 16 * n + i];
         // (a full chunk -- all but the last one of a recording -- stores without per-row conditions: each of them is a
         //  branch around the store)
         auto epilogue = [&](auto full_tag) {
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)si
     }
     VBX_STAMP();
 #ifdef VBX_PHASE_CLOCKS
-    if ((tile % 1000) == 1 && (lane == 0) && bt.state[rec].n_iters == 3)
+    if ((tile % 1000) == 1 && (lane == 0) && st.n_iters == 3)
         printf("chunk_loglik wave %d: mfma %lld  epilogue %lld  wait %lld  operator %lld cycles\n", wave,
                clk[1] - clk[0], clk[2] - clk[1], clk[3] - clk[2], clk[4] - clk[3]);
 #endif

@@ -45,7 +45,13 @@ template <typename R> struct BatchView {
     int n_rec, Sp, Dp, D, max_iters;
     int ntiles_total;
     const RecDesc* recs;
-    RecState* state;
+    RecState* state;       // [n_rec] the latest state (what every kernel but fin_kernel reads)
+    RecState* state_out;   // fin_kernel only: where the iteration-finishing role writes the next state.  The state is
+                           // double-buffered so that the two roles of one launch see ONE snapshot (`state`) whatever the
+                           // order their workgroups run in; the host swaps the buffers after such a launch
+    long long model_stride;   // elements between the two copies of alpha / invL (M-step k writes copy k & 1: a launch that
+    int vec_stride;           // finishes iteration k-1 and starts iteration k must not clobber the model of a recording
+                              // that turns out to have converged at k-1); vec_stride: the same for bias / emodel
     const int* tile_rec;   // [ntiles_total]
     const int* tile_t0;    // [ntiles_total]
     const int4* tile_desc; // [ntiles_total rounded up to 4] {recording, t0, frames, first row}; frames = 0 behind the last tile
@@ -224,26 +230,106 @@ __global__ __launch_bounds__(64) void mstep_acc_kernel(BatchView<R> bt) {
 }
 
 // =======================================================================================
-// M-step finalisation for one speaker row: N_s, invL, alpha (VBx.py:95-96), the per-speaker
-// bias of eq. 23 (VBx.py:97) and the speaker's share of the ELBO model term (VBx.py:100).
-// Tile partials are combined in f64.  grid = (n_rec, Sp), block = 128.
+// fin_kernel: everything per recording that sits between two passes over the frames, in ONE launch.
+//   role ITER  (blockIdx.y == Sp)  finishes iteration j = state.n_iters: ELBO (VBx.py:100), pi update (VBx.py:101-104),
+//              history (VBx.py:105), convergence test (VBx.py:122-125), the c of the operator recursion from the new pi
+//   role MSTEP (blockIdx.y = s)    starts iteration k: N_s, invL, alpha (VBx.py:95-96), the per-speaker bias of VBx.py:97
+//              and the speaker's share of the ELBO model term (VBx.py:100); tile partials combined in f64
+// mode 1: MSTEP only (first launch of a run: nothing to finish, k = n_iters); 2: ITER only (end of a run); 3: both
+// (k = n_iters + 1).  Round 2 had two kernels, iter_fin at the end of an iteration and mstep_fin at the start of the
+// next: two dependent launches of a few workgroups each, ~14 us of an iteration of ONE recording (55 us) and nothing the
+// GPU could overlap with anything.  In one launch neither role may depend on what the other writes:
+//   * both read the state snapshot `state`; ITER writes `state_out` (the host swaps the two afterwards);
+//   * MSTEP of iteration k writes copy k & 1 of alpha / invL / bias / emodel, ITER reads emodel of iteration j from copy
+//     j & 1, and whoever reads the model of the iteration in flight takes copy n_iters & 1 of the NEW state.  A recording
+//     ITER finds converged keeps its model: the M-step this launch did for it went to the other copy;
+//   * the recursion's c comes from the new pi: ITER writes it (MSTEP only in mode 1, from the pi it finds).
+// grid = (n_rec, Sp + 1), block = 256, or 1024 for long recordings.
 // =======================================================================================
 template <typename R>
-__global__ __launch_bounds__(1024) void mstep_fin_kernel(BatchView<R> bt) {      // block = 256, or 1024 for long recordings
+__global__ __launch_bounds__(1024) void fin_kernel(BatchView<R> bt, int mode) {
     __shared__ double lds[16];
-    __shared__ double csum[1024];
-    const int rec = blockIdx.x, s = blockIdx.y;
-    const RecState st = bt.state[rec];
-    if (st.done) return;
+    __shared__ double sh[1024];
+    __shared__ int done_sh;
+    const int rec = blockIdx.x, Sp = bt.Sp, Dp = bt.Dp;
+    const RecState st_in = bt.state[rec];
     const RecDesc rd = bt.recs[rec];
-    const int Sp = bt.Sp, Dp = bt.Dp;
-    const bool given = (st.n_iters == 0 && rd.has_model);
-    if (threadIdx.x == 0 && bt.cop) {      // the c of the operator recursion (vbx_operator.hpp) for this speaker
+    const int u0 = rd.tile0, nu = rd.ntiles;
+    if ((int)blockIdx.y == Sp) {
+        // ---------------------------------------------------------------- ITER: finish iteration j = st.n_iters
+        if (!(mode & 2)) return;
+        RecState st = st_in;
+        if (st.done) {                                     // frozen: the state just moves to the other buffer
+            if (threadIdx.x == 0) bt.state_out[rec] = st;
+            return;
+        }
+        const int j = threadIdx.x;
+        // "entered" statistic: thread (slot, state) sums tiles slot, slot+nslot, ... ; Sp divides the block
+        const int nslot = blockDim.x / Sp, slot = threadIdx.x / Sp, sj = threadIdx.x % Sp;
+        double part = 0.0;
+        for (int tl = slot; tl < nu; tl += 16 * nslot) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                v[u] = (tl + u * nslot < nu) ? bt.epart[(long long)(u0 + tl + u * nslot) * Sp + sj] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) part += v[u];
+        }
+        sh[threadIdx.x] = part;
+        double tpart = 0.0;
+        if (bt.tllpart)
+            for (int tl = threadIdx.x; tl < nu; tl += blockDim.x) tpart += bt.tllpart[u0 + tl];
+        __syncthreads();
+        double pn = 0.0, em = 0.0, pj = 0.0;
+        if (j < rd.S) {
+            double ent = 0.0;
+            for (int q = 0; q < nslot; ++q) ent += sh[q * Sp + j];
+            pj = bt.pi[(long long)rec * Sp + j];
+            const double g0 = bt.gamma0 ? (double)bt.gamma0[(long long)rec * Sp + j] : (double)bt.gamma[rd.row0 * Sp + j];
+            pn = g0 + (1.0 - rd.lp) * pj * ent;
+            em = bt.emodel[(long long)(st.n_iters & 1) * bt.vec_stride + (long long)rec * Sp + j];
+        }
+        const double tot = block_sum(pn, lds);
+        const double emt = block_sum(em, lds);
+        const double tll = bt.tllpart ? block_sum(tpart, lds) : st.tll;
+        if (j < Sp) {
+            const double pnew = pn / tot;
+            bt.pi_prev[(long long)rec * Sp + j] = pj;       // what this iteration's forward-backward pass ran with
+            bt.pi[(long long)rec * Sp + j] = pnew;
+            if (bt.cop) {                                   // the c of the operator recursion (vbx_operator.hpp) for the next pass
+                const double cj = j < rd.S ? (1.0 - rd.lp) * pnew + 1e-8 : 0.0;
+                bt.cop[(long long)rec * Sp + j] = (R)(rd.lp >= 0x1p-20 ? cj / rd.lp : cj);
+            }
+        }
+        if (j == 0) {
+            const double elbo = tll + rd.Fa * rd.gsum + 0.5 * rd.Fb * emt;
+            const int it = st.n_iters;
+            if (it < bt.max_iters) bt.Li[(long long)rec * bt.max_iters + it] = elbo;
+            if (it > 0 && elbo - st.elbo_prev < bt.epsilon) {
+                st.done = 1;
+                if (elbo - st.elbo_prev < 0) st.warned = 1;
+            }
+            st.tll = tll;
+            st.elbo_prev = elbo;
+            st.n_iters = it + 1;
+            bt.state_out[rec] = st;
+            done_sh = st.done;
+        }
+        __syncthreads();
+        if (done_sh)
+            for (int tl = threadIdx.x; tl < rd.ntiles; tl += blockDim.x) bt.tile_done[rd.tile0 + tl] = 1;
+        return;
+    }
+    // -------------------------------------------------------------------- MSTEP: speaker s, iteration k
+    if (!(mode & 1) || st_in.done) return;
+    const int s = blockIdx.y;
+    const int k = st_in.n_iters + ((mode & 2) ? 1 : 0);
+    const bool given = (k == 0 && rd.has_model);
+    if (mode == 1 && threadIdx.x == 0 && bt.cop) {
         const double cj = s < rd.S ? (1.0 - rd.lp) * bt.pi[(long long)rec * Sp + s] + 1e-8 : 0.0;
         bt.cop[(long long)rec * Sp + s] = (R)(rd.lp >= 0x1p-20 ? cj / rd.lp : cj);
     }
     const double fafb = rd.Fa / rd.Fb;
-    const int u0 = rd.tile0, nu = rd.ntiles;
     double N = 0.0;
     if (!given) {
         double part = 0.0;
@@ -251,7 +337,7 @@ __global__ __launch_bounds__(1024) void mstep_fin_kernel(BatchView<R> bt) {     
             part += (double)bt.npart[(long long)(u0 + tl) * Sp + s];
         N = block_sum(part, lds);
     }
-    const long long sd = ((long long)rec * Sp + s) * Dp;
+    const long long sd = (long long)(k & 1) * bt.model_stride + ((long long)rec * Sp + s) * Dp;
     double bsum = 0.0, esum = 0.0;
     // thread = (feature d, slice of the tile range: 2 slices, 8 in a block of 1024 threads -- a recording of T = 200 000
     // has 1563 partials per speaker, twenty dependent rounds of loads on two slices); loads are clamped instead of
@@ -275,7 +361,7 @@ __global__ __launch_bounds__(1024) void mstep_fin_kernel(BatchView<R> bt) {     
                 for (int u = 0; u < LB; ++u) C += (tl + u < hi) ? (double)v[u] : 0.0;
             }
         }
-        csum[threadIdx.x] = C;
+        sh[threadIdx.x] = C;
         __syncthreads();
         if (slice == 0 && dok) {
             const double phi = bt.phi[(long long)rec * Dp + d];
@@ -284,7 +370,7 @@ __global__ __launch_bounds__(1024) void mstep_fin_kernel(BatchView<R> bt) {     
                 il = (double)bt.invL[sd + d];
                 al = (double)bt.alpha[sd + d];
             } else {
-                for (int k = 1; k < nsl; ++k) C += csum[threadIdx.x + 128 * k];
+                for (int q = 1; q < nsl; ++q) C += sh[threadIdx.x + 128 * q];
                 il = 1.0 / (1.0 + fafb * N * phi);
                 al = fafb * il * C;
                 const R ilr = (R)il, alr = (R)al;      // the values every later kernel sees
@@ -301,8 +387,9 @@ __global__ __launch_bounds__(1024) void mstep_fin_kernel(BatchView<R> bt) {     
     bsum = block_sum(bsum, lds);
     esum = block_sum(esum, lds);
     if (threadIdx.x == 0) {
-        bt.bias[(long long)rec * Sp + s] = (R)(-0.5 * bsum);
-        bt.emodel[(long long)rec * Sp + s] = esum;
+        const long long vi = (long long)(k & 1) * bt.vec_stride + (long long)rec * Sp + s;
+        bt.bias[vi] = (R)(-0.5 * bsum);
+        bt.emodel[vi] = esum;
     }
 }
 
@@ -324,7 +411,9 @@ __global__ __launch_bounds__(256) void loglik_kernel(BatchView<R> bt, R* __restr
     using R4 = typename Vec<R>::v4;
     const int tile = blockIdx.x;
     const int rec = bt.tile_rec[tile];
-    if (bt.state[rec].done) return;
+    const RecState st = bt.state[rec];
+    if (st.done) return;
+    const int par = st.n_iters & 1;                    // the model of the iteration in flight (fin_kernel)
     const RecDesc rd = bt.recs[rec];
     const int Sp = bt.Sp, Dp = bt.Dp;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
@@ -332,7 +421,7 @@ __global__ __launch_bounds__(256) void loglik_kernel(BatchView<R> bt, R* __restr
     const int s0 = blockIdx.y * 16 * NT;              // first speaker of this block
     const bool tiled = gridDim.y > 1;
     const R* __restrict__ rho = bt.rho + rd.rho_row0 * Dp;
-    const R* __restrict__ alpha = bt.alpha + ((long long)rec * Sp + s0) * Dp;
+    const R* __restrict__ alpha = bt.alpha + (long long)par * bt.model_stride + ((long long)rec * Sp + s0) * Dp;
 
     acc_t acc[2][NT];
 #pragma unroll
@@ -383,7 +472,7 @@ __global__ __launch_bounds__(256) void loglik_kernel(BatchView<R> bt, R* __restr
     const R Fa = (R)rd.Fa;
     R biasv[NT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) biasv[n] = bt.bias[(long long)rec * Sp + s0 + 16 * n + i];
+    for (int n = 0; n < NT; ++n) biasv[n] = bt.bias[(long long)par * bt.vec_stride + (long long)rec * Sp + s0 + 16 * n + i];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -648,72 +737,6 @@ __global__ __launch_bounds__(256) void post_kernel(BatchView<R> bt) {
         part = block_sum(part, tl_lds);
         if (threadIdx.x == 0) bt.tllpart[tile] = part;
     }
-}
-
-// =======================================================================================
-// End of an iteration: ELBO (VBx.py:100), pi update (VBx.py:101-104), history (VBx.py:105)
-// and the convergence test (VBx.py:122-125).  grid = n_rec, block = 256 (thread = speaker).
-// =======================================================================================
-template <typename R>
-__global__ __launch_bounds__(1024) void iter_fin_kernel(BatchView<R> bt) {       // block = 256, or 1024 for long recordings
-    __shared__ double lds[16];
-    __shared__ double ent_sh[1024];
-    __shared__ int done_sh;
-    const int rec = blockIdx.x;
-    RecState st = bt.state[rec];
-    if (st.done) return;
-    const RecDesc rd = bt.recs[rec];
-    const int Sp = bt.Sp, j = threadIdx.x;
-    // "entered" statistic: thread (slot, state) sums tiles slot, slot+nslot, ... ; Sp divides 256
-    const int u0 = rd.tile0, nu = rd.ntiles;
-    const int nslot = blockDim.x / Sp, slot = threadIdx.x / Sp, sj = threadIdx.x % Sp;
-    double part = 0.0;
-    for (int tl = slot; tl < nu; tl += 16 * nslot) {
-        double v[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-            v[u] = (tl + u * nslot < nu) ? bt.epart[(long long)(u0 + tl + u * nslot) * Sp + sj] : 0.0;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) part += v[u];
-    }
-    ent_sh[threadIdx.x] = part;
-    double tpart = 0.0;
-    if (bt.tllpart)
-        for (int tl = threadIdx.x; tl < nu; tl += blockDim.x) tpart += bt.tllpart[u0 + tl];
-    __syncthreads();
-    double pn = 0.0, em = 0.0, pj = 0.0;
-    if (j < rd.S) {
-        double ent = 0.0;
-        for (int q = 0; q < nslot; ++q) ent += ent_sh[q * Sp + j];
-        pj = bt.pi[(long long)rec * Sp + j];
-        const double g0 = bt.gamma0 ? (double)bt.gamma0[(long long)rec * Sp + j] : (double)bt.gamma[rd.row0 * Sp + j];
-        pn = g0 + (1.0 - rd.lp) * pj * ent;
-        em = bt.emodel[(long long)rec * Sp + j];
-    }
-    const double tot = block_sum(pn, lds);
-    const double emt = block_sum(em, lds);
-    const double tll = bt.tllpart ? block_sum(tpart, lds) : st.tll;
-    if (j < Sp) {
-        bt.pi_prev[(long long)rec * Sp + j] = pj;       // what this iteration's forward-backward pass ran with
-        bt.pi[(long long)rec * Sp + j] = pn / tot;
-    }
-    if (j == 0) {
-        const double elbo = tll + rd.Fa * rd.gsum + 0.5 * rd.Fb * emt;
-        const int it = st.n_iters;
-        if (it < bt.max_iters) bt.Li[(long long)rec * bt.max_iters + it] = elbo;
-        if (it > 0 && elbo - st.elbo_prev < bt.epsilon) {
-            st.done = 1;
-            if (elbo - st.elbo_prev < 0) st.warned = 1;
-        }
-        st.tll = tll;
-        st.elbo_prev = elbo;
-        st.n_iters = it + 1;
-        bt.state[rec] = st;
-        done_sh = st.done;
-    }
-    __syncthreads();
-    if (done_sh)
-        for (int tl = threadIdx.x; tl < rd.ntiles; tl += blockDim.x) bt.tile_done[rd.tile0 + tl] = 1;
 }
 
 }  // namespace vbx

@@ -154,6 +154,78 @@ inline void average_linkage(int64_t n, const double* cond, double* Z) {
     finish_linkage(n, merges.data(), Z);
 }
 
+// The same clustering as fastcluster 1.2 computes it (fastcluster.cpp: NN_chain_core<METHOD_METR_AVERAGE> +
+// generate_SciPy_dendrogram; D. Muellner, "fastcluster: Fast Hierarchical, Agglomerative Clustering Routines for R and
+// Python", J. Stat. Softw. 53(9), 2013) -- the package vbhmm.py:140-141 actually calls, not installed here, restated from
+// its published source.  Two things differ from SciPy's routine above:
+//   * the update: d(i, x u y) = s d(i,x) + t d(i,y) with s = n_x / (n_x + n_y), t = n_y / (n_x + n_y) divided FIRST
+//     (f_average), against (n_x d(i,x) + n_y d(i,y)) / (n_x + n_y) -- the same number up to its last bits;
+//   * the chain: a new chain starts at the lowest live index with that cluster's nearest neighbour found by a scan in
+//     index order (strict <: the lowest index wins ties); after a merge THREE elements leave the chain and the walk
+//     resumes at the element before them, its predecessor being the candidate that wins ties.
+// Without ties both give the same tree (reciprocal nearest neighbours are unique) and distances that agree to rounding;
+// with ties either may pick another -- equally valid -- merge.  Same output convention (stable sort + union-find).
+// Parity of this routine with the real package is UNPINNED (no fastcluster here, no fixture of it besides the RTTM of the
+// example, which both routines reproduce: tests/test_driver.py).
+inline void average_linkage_fastcluster(int64_t n, const double* cond, double* Z) {
+    if (n < 2) return;
+    std::vector<double> Dm((size_t)n * (size_t)(n - 1) / 2);
+    std::memcpy(Dm.data(), cond, sizeof(double) * Dm.size());
+    // condensed index of (r, c), r < c  (fastcluster's D_ macro)
+    auto D = [&](int64_t r, int64_t c) -> double& { return Dm[(size_t)(((2 * n - 3 - r) * r) >> 1) + (size_t)c - 1]; };
+    std::vector<int64_t> succ((size_t)n + 1), pred((size_t)n + 1);      // doubly linked list of the live clusters
+    for (int64_t i = 0; i <= n; ++i) { succ[(size_t)i] = i + 1; pred[(size_t)i] = i - 1; }
+    int64_t start = 0;
+    auto remove = [&](int64_t idx) {
+        if (idx == start) start = succ[(size_t)idx];
+        else {
+            succ[(size_t)pred[(size_t)idx]] = succ[(size_t)idx];
+            pred[(size_t)succ[(size_t)idx]] = pred[(size_t)idx];
+        }
+        succ[(size_t)idx] = 0;                                          // (marks idx as dead, as fastcluster does)
+    };
+    std::vector<int64_t> chain((size_t)n);
+    std::vector<double> members((size_t)n, 1.0);
+    std::vector<ChainMerge> merges((size_t)(n - 1));
+    int64_t tip = 0, idx1 = 0, idx2 = 0;
+    double mn = 0.0;
+    for (int64_t j = 0; j < n - 1; ++j) {
+        if (tip <= 3) {
+            chain[0] = idx1 = start;
+            tip = 1;
+            idx2 = succ[(size_t)idx1];
+            mn = D(idx1, idx2);
+            for (int64_t i = succ[(size_t)idx2]; i < n; i = succ[(size_t)i])
+                if (D(idx1, i) < mn) { mn = D(idx1, i); idx2 = i; }
+        } else {
+            tip -= 3;
+            idx1 = chain[(size_t)(tip - 1)];
+            idx2 = chain[(size_t)tip];
+            mn = idx1 < idx2 ? D(idx1, idx2) : D(idx2, idx1);
+        }
+        do {
+            chain[(size_t)tip] = idx2;
+            for (int64_t i = start; i < idx2; i = succ[(size_t)i])
+                if (D(i, idx2) < mn) { mn = D(i, idx2); idx1 = i; }
+            for (int64_t i = succ[(size_t)idx2]; i < n; i = succ[(size_t)i])
+                if (D(idx2, i) < mn) { mn = D(idx2, i); idx1 = i; }
+            idx2 = idx1;
+            idx1 = chain[(size_t)tip++];
+        } while (idx2 != chain[(size_t)(tip - 2)]);
+        if (idx1 > idx2) std::swap(idx1, idx2);
+        merges[(size_t)j] = ChainMerge{(int)idx1, (int)idx2, mn};
+        const double size1 = members[(size_t)idx1], size2 = members[(size_t)idx2];
+        members[(size_t)idx2] += members[(size_t)idx1];
+        remove(idx1);
+        const double s = size1 / (size1 + size2), t = size2 / (size1 + size2);
+        int64_t i = start;
+        for (; i < idx1; i = succ[(size_t)i]) D(i, idx2) = s * D(i, idx1) + t * D(i, idx2);
+        for (; i < idx2; i = succ[(size_t)i]) D(i, idx2) = s * D(idx1, i) + t * D(i, idx2);
+        for (i = succ[(size_t)idx2]; i < n; i = succ[(size_t)i]) D(idx2, i) = s * D(idx1, i) + t * D(idx2, i);
+    }
+    finish_linkage(n, merges.data(), Z);
+}
+
 // Second half of the algorithm, shared with the device chain (vbx_ahc.hpp nn_chain_kernel): the n - 1 merges in the
 // order the chain found them -> Z.
 inline void finish_linkage(int64_t n, const ChainMerge* merges_in, double* Z) {

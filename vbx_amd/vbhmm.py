@@ -145,8 +145,8 @@ class DeviceStages:
         sc = self._capi.Scores.cos_similarity_resident(self._thread_ctx(), self.xv, self.row0[k], self.T[k])
         try:
             thr, _ = sc.two_gmm_calib(20, want_llr=False)
-            if self.T[k] >= self.DEVICE_LINKAGE_FROM:
-                lin_mat = sc.linkage_average(self.T[k])
+            if self.T[k] >= self.DEVICE_LINKAGE_FROM and self._capi.linkage_variant() == 'scipy':
+                lin_mat = sc.linkage_average(self.T[k])                # (the device chain follows SciPy's arithmetic)
             else:                                     # short recording: the host chain beats the device's step latency
                 lin_mat = self._capi.linkage_average(sc.get_condensed(self.T[k], -1.0)) if self.T[k] > 1 else np.empty((0, 4))
         finally:
