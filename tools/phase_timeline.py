@@ -29,6 +29,7 @@ def main(nrec=64, T=10000, S=30, out='gpurun_out/phase_timeline.npy'):
     buf = np.zeros((8192, 2, 8), np.int64)
     rc = lib.vbx_debug_clocks(buf.ctypes.data_as(C.c_void_p), buf.size)
     assert rc == 0, rc
+    ntile = min(ntile, 8192)
     buf = buf[:ntile]
     np.save(out, buf)
     w0 = buf[:, 0, :]
@@ -56,4 +57,5 @@ def main(nrec=64, T=10000, S=30, out='gpurun_out/phase_timeline.npy'):
 
 
 if __name__ == '__main__':
-    main()
+    a = [int(v) for v in sys.argv[1:4]]          # [recordings T S]
+    main(*a) if a else main()
