@@ -569,9 +569,10 @@ def single_two_iters(ctx, X, Phi, g0, S, fa, fb):
 
 @pytest.mark.parametrize('precision,tol', [('fp64', 1e-11), ('fp32', 2e-5)])
 def test_two_level_boundary_walk_equals_flat_chain(ctx, precision, tol):
-    """Groups of chunk operators composed on the device (scan_compose) + walks at group and chunk level give
-    the same boundaries as the flat chain: same gamma / pi / ELBO, for ragged recordings, group sizes that do
-    and do not divide the chunk count, S padded to 16 / 32 / 64, and a loopProb = 0 / zero-prior corner."""
+    """Groups of chunk operators composed on the device (scan_compose) + walks at group and chunk level -- and, for very
+    long recordings, groups of groups on top (three levels) -- give the same boundaries as the flat chain: same gamma / pi
+    / ELBO, for ragged recordings, group sizes that do and do not divide the chunk / group count (down to level-2 groups
+    of a single group), S padded to 16 / 32 / 64, and a loopProb = 0 / zero-prior corner."""
     from vbx_amd import _capi
     from vbx_amd.synth import make_recording
     cases = [(4000, 12, 0.9, None), (6533, 30, 0.99, None), (2900, 50, 0.8, None), (1500, 7, 0.0, None)]
@@ -585,26 +586,28 @@ def test_two_level_boundary_walk_equals_flat_chain(ctx, precision, tol):
             pi0 = np.array([0.5, 0.0, 0.2, 0.0, 0.3, 0.0, 0.0])          # c_j = 1e-8 for the empty priors
         recs.append((X, Phi, pi0, g0, lp))
     out = {}
-    for group in (1, 2, 5, 64):
+    levels = [(1, 1), (2, 1), (5, 1), (64, 1), (2, 2), (3, 4), (5, 3), (2, 64), (7, 7)]      # (chunks per group, groups per level-2 group)
+    for group, group2 in levels:
         res = []
         for S_group in ([0, 3], [1], [2]):                                   # batches by padded width 16 / 32 / 64
             idx = S_group
             batch = _capi.Batch(ctx, [recs[i][0].shape[0] for i in idx], [len(recs[i][2]) for i in idx], 128,
                                 precision=precision, max_iters=4)
             batch.set_option(_capi.OPT_SCAN_GROUP, group)
+            batch.set_option(_capi.OPT_SCAN_GROUP2, group2)
             for j, i in enumerate(idx):
                 X, Phi, pi0, g0, lp = recs[i]
                 batch.set_recording(j, X, Phi, pi0, g0, lp, 0.3, 17.0)
             batch.run(4, -np.inf)
             res += [(i, batch.result(j, want_model=False)) for j, i in enumerate(idx)]
             batch.close()
-        out[group] = dict(res)
-    for group in (2, 5, 64):
+        out[group, group2] = dict(res)
+    for key in levels[1:]:
         for i in range(len(recs)):
-            a, b = out[group][i], out[1][i]
-            assert np.abs(a['gamma'] - b['gamma']).max() <= tol, (group, i, np.abs(a['gamma'] - b['gamma']).max())
-            assert np.abs(a['pi'] - b['pi']).max() <= tol, (group, i)
-            assert rel_err(a['Li'], b['Li']) <= tol, (group, i)
+            a, b = out[key][i], out[1, 1][i]
+            assert np.abs(a['gamma'] - b['gamma']).max() <= tol, (key, i, np.abs(a['gamma'] - b['gamma']).max())
+            assert np.abs(a['pi'] - b['pi']).max() <= tol, (key, i)
+            assert rel_err(a['Li'], b['Li']) <= tol, (key, i)
 
 
 @pytest.mark.parametrize('S,D', [(1, 128), (16, 40), (17, 200), (33, 128), (64, 96), (65, 128), (5, 300), (128, 128),

@@ -14,7 +14,7 @@ VBX_F32, VBX_F64 = 0, 1
 PREC_FP32, PREC_FP64 = 0, 1
 FB_AUTO, FB_SEQUENTIAL, FB_CHUNKED = 0, 1, 2
 OPT_FB_ALGO, OPT_CHECK_EVERY, OPT_PROFILE, OPT_CHUNK_FRAMES, OPT_FUSE, OPT_SCAN_GROUP = 1, 2, 3, 4, 5, 6
-OPT_TWO_LEVEL_FROM, OPT_STREAMS, OPT_SPLIT_TILES = 8, 10, 11
+OPT_TWO_LEVEL_FROM, OPT_STREAMS, OPT_SPLIT_TILES, OPT_SCAN_GROUP2, OPT_THREE_LEVEL_FROM = 8, 10, 11, 12, 13
 K_NAMES = ['prep', 'mstep_acc', 'mstep_fin', 'loglik', 'fb', 'fb_aux', 'post', 'iter_fin', 'chunk_loglik',
            'chunk_post']
 MAX_SPEAKERS = 1024
@@ -363,6 +363,9 @@ class Batch:
         group = os.environ.get('VBX_AMD_SCAN_GROUP')      # chunks per group of the two-level boundary walk
         if group is not None:
             self.set_option(OPT_SCAN_GROUP, int(group))
+        group2 = os.environ.get('VBX_AMD_SCAN_GROUP2')    # level-2 groups of the three-level walk (0 auto, 1 off)
+        if group2 is not None:
+            self.set_option(OPT_SCAN_GROUP2, int(group2))
         split = os.environ.get('VBX_AMD_SPLIT_TILES')     # 1 / 2: half-tile re-runs on / off (0: the library's choice)
         if split is not None:
             self.set_option(OPT_SPLIT_TILES, int(split))

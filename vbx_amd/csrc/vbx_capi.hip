@@ -178,6 +178,12 @@ struct vbx_batch {
     int spt = 1;                                  // scan chunks per tile in effect (2: fused kernels, half-tile operators)
     void* d_sop = nullptr;
     int *d_sopexp = nullptr, *d_sup_rec = nullptr, *d_sup_idx = nullptr;
+    // third level of the walk (very long recordings): groups of sgroup2 groups
+    int scan_group2 = 0;                          // option: 0 auto, 1 off, >= 2 groups per level-2 group
+    int three_level_from = 600;                   // chunks from which the automatic choice adds the third level
+    int sgroup2 = 1, nsup2_total = 0;             // in effect
+    void* d_sop2 = nullptr;
+    int *d_sopexp2 = nullptr, *d_sup2_rec = nullptr, *d_sup2_idx = nullptr;
     void* d_xstage = nullptr;
     size_t xstage_bytes = 0;
     // timing
@@ -209,6 +215,8 @@ struct vbx_batch {
         v.tllpart = use_chunked ? d_tllpart : nullptr; v.sfw = (R*)d_sfw; v.dump = (R*)d_dump;
         v.sop = (R*)d_sop; v.sopexp = d_sopexp; v.sup_rec = d_sup_rec; v.sup_idx = d_sup_idx;
         v.sgroup = sgroup; v.nsup_total = nsup_total; v.spt = spt;
+        v.sop2 = (R*)d_sop2; v.sopexp2 = d_sopexp2; v.sup2_rec = d_sup2_rec; v.sup2_idx = d_sup2_idx;
+        v.sgroup2 = sgroup2; v.nsup2_total = nsup2_total;
         v.gamma0 = fused_now ? (R*)d_gamma0 : nullptr; v.pi_prev = d_pi_prev;
         return v;
     }
@@ -314,8 +322,14 @@ template <typename R, int SP> void launch_scan(vbx_batch* b, const BatchView<R>&
     }
     {
         LaunchScope ls(b, VBX_K_FB_AUX);
-        if (b->sgroup > 1) {     // long recordings: group operators, boundaries at the group edges, then inside the groups
-            hipLaunchKernelGGL((scan_compose_kernel<R, SP>), dim3(b->nsup_total), dim3(256), 0, st, v);
+        if (b->sgroup > 1 && b->sgroup2 > 1) {   // very long recordings: groups of groups on top
+            hipLaunchKernelGGL((scan_compose_kernel<R, SP>), dim3(b->nsup_total), dim3(256), 0, st, v, 1);
+            hipLaunchKernelGGL((scan_compose_kernel<R, SP>), dim3(b->nsup2_total), dim3(256), 0, st, v, 2);
+            hipLaunchKernelGGL((scan2_kernel<R, SP>), dim3(b->n_rec, 2), dim3(256), 0, st, v, 4);
+            hipLaunchKernelGGL((scan2_kernel<R, SP>), dim3(b->nsup2_total, 2), dim3(256), 0, st, v, 5);
+            hipLaunchKernelGGL((scan2_kernel<R, SP>), dim3(b->nsup_total, 2), dim3(256), 0, st, v, 3);
+        } else if (b->sgroup > 1) {     // long recordings: group operators, boundaries at the group edges, then inside the groups
+            hipLaunchKernelGGL((scan_compose_kernel<R, SP>), dim3(b->nsup_total), dim3(256), 0, st, v, 1);
             hipLaunchKernelGGL((scan2_kernel<R, SP>), dim3(b->n_rec, 2), dim3(256), 0, st, v, 2);
             hipLaunchKernelGGL((scan2_kernel<R, SP>), dim3(b->nsup_total, 2), dim3(256), 0, st, v, 3);
         } else {
@@ -562,24 +576,44 @@ int choose_fb_algo(vbx_batch* b, bool step_api_logs) {
         else if (b->scan_group == 0 && (maxchunks >= b->two_level_from || (b->n_rec <= 4 && maxchunks >= 32)))
             group = g_auto;
     }
-    if (group != b->sgroup || spt != b->spt || (group > 1 && !b->d_sop)) {
-        for (void* p : {(void*)b->d_sop, (void*)b->d_sopexp, (void*)b->d_sup_rec, (void*)b->d_sup_idx}) ctx_free(b->ctx, p);
+    // Third level: with products worth ~4 walk steps the chain 4 (g - 1) + 4 (g2 - 1) + K / (g g2) + g2 + g is shortest
+    // near g = g2 = (K / 8)^(1/3) rounded up: K = 1563 (T = 200 000): 7 x 7 -> 94 step equivalents against 173 on two
+    // levels; K = 391 (T = 50 000): 56 against 84, which the two extra launches nearly eat -- so only from 600 chunks.
+    int group2 = 1;
+    if (group > 1) {
+        if (b->scan_group2 >= 2) group2 = b->scan_group2;
+        else if (b->scan_group2 == 0 && b->scan_group == 0 && maxchunks >= b->three_level_from) {
+            group = group2 = std::max(4, (int)std::ceil(std::cbrt((double)maxchunks / 8.0)) + 1);
+        }
+    }
+    if (group != b->sgroup || group2 != b->sgroup2 || spt != b->spt || (group > 1 && !b->d_sop) || (group2 > 1 && !b->d_sop2)) {
+        for (void* p : {(void*)b->d_sop, (void*)b->d_sopexp, (void*)b->d_sup_rec, (void*)b->d_sup_idx,
+                        (void*)b->d_sop2, (void*)b->d_sopexp2, (void*)b->d_sup2_rec, (void*)b->d_sup2_idx}) ctx_free(b->ctx, p);
         b->d_sop = nullptr; b->d_sopexp = nullptr; b->d_sup_rec = nullptr; b->d_sup_idx = nullptr;
+        b->d_sop2 = nullptr; b->d_sopexp2 = nullptr; b->d_sup2_rec = nullptr; b->d_sup2_idx = nullptr;
         b->sgroup = group;
+        b->sgroup2 = group2;
         b->spt = spt;
-        b->nsup_total = 0;
+        b->nsup_total = b->nsup2_total = 0;
         if (group > 1) {
-            std::vector<int> sup_rec, sup_idx;
+            std::vector<int> sup_rec, sup_idx, sup2_rec, sup2_idx;
             for (int i = 0; i < b->n_rec; ++i) {
                 b->recs[i].sup0 = (int)sup_rec.size();
+                b->recs[i].sup20 = (int)sup2_rec.size();
                 const int kc = spt == 2 ? (b->recs[i].T + kTileFrames / 2 - 1) / (kTileFrames / 2) : b->recs[i].ntiles;
                 const int ns = (kc + group - 1) / group;
                 for (int s = 0; s < ns; ++s) {
                     sup_rec.push_back(i);
                     sup_idx.push_back(s);
                 }
+                if (group2 > 1)
+                    for (int s = 0; s < (ns + group2 - 1) / group2; ++s) {
+                        sup2_rec.push_back(i);
+                        sup2_idx.push_back(s);
+                    }
             }
             b->nsup_total = (int)sup_rec.size();
+            b->nsup2_total = (int)sup2_rec.size();
             const size_t sp = (size_t)b->Sp;
             int rc = dmalloc_bytes(b->ctx, &b->d_sop, (size_t)b->nsup_total * sp * sp * b->rsize);
             if (rc == VBX_OK) rc = dmalloc(b->ctx, &b->d_sopexp, (size_t)b->nsup_total * sp);
@@ -588,7 +622,16 @@ int choose_fb_algo(vbx_batch* b, bool step_api_logs) {
             if (rc != VBX_OK) return rc;
             HIPCHK(b->ctx, hipMemcpy(b->d_sup_rec, sup_rec.data(), sizeof(int) * sup_rec.size(), hipMemcpyHostToDevice));
             HIPCHK(b->ctx, hipMemcpy(b->d_sup_idx, sup_idx.data(), sizeof(int) * sup_idx.size(), hipMemcpyHostToDevice));
-            b->recs_dirty = true;        // sup0 changed
+            if (group2 > 1) {
+                rc = dmalloc_bytes(b->ctx, &b->d_sop2, (size_t)b->nsup2_total * sp * sp * b->rsize);
+                if (rc == VBX_OK) rc = dmalloc(b->ctx, &b->d_sopexp2, (size_t)b->nsup2_total * sp);
+                if (rc == VBX_OK) rc = dmalloc(b->ctx, &b->d_sup2_rec, sup2_rec.size());
+                if (rc == VBX_OK) rc = dmalloc(b->ctx, &b->d_sup2_idx, sup2_idx.size());
+                if (rc != VBX_OK) return rc;
+                HIPCHK(b->ctx, hipMemcpy(b->d_sup2_rec, sup2_rec.data(), sizeof(int) * sup2_rec.size(), hipMemcpyHostToDevice));
+                HIPCHK(b->ctx, hipMemcpy(b->d_sup2_idx, sup2_idx.data(), sizeof(int) * sup2_idx.size(), hipMemcpyHostToDevice));
+            }
+            b->recs_dirty = true;        // sup0 / sup20 changed
         }
     }
     return VBX_OK;
@@ -746,6 +789,7 @@ static int leaf_destroy(vbx_batch* b) {
                     b->d_bias, b->d_mpart, b->d_npart, b->d_lraw, b->d_emodel, b->d_pi, b->d_epart, b->d_Li,
                     b->d_xstage, b->d_ip, b->d_fw_scale, b->d_bw_scale, b->d_op, b->d_fbound, b->d_gbound,
                     b->d_opexp, b->d_tllpart, b->d_sfw, b->d_dump, b->d_sop, b->d_sopexp, b->d_sup_rec, b->d_sup_idx,
+                    b->d_sop2, b->d_sopexp2, b->d_sup2_rec, b->d_sup2_idx,
                     b->d_gamma0, b->d_pi_prev, b->d_oph, b->d_ophexp, b->d_cop, b->d_lppow, b->d_tile_order};
     (void)hipStreamSynchronize(b->ctx->stream);               // nothing of this batch may still be running when its
     for (void* p : ptrs) ctx_free(b->ctx, p);                 // blocks go back to the spare list
@@ -903,6 +947,14 @@ static int leaf_set_option(vbx_batch* b, int option, int64_t value) {
         case VBX_OPT_SCAN_GROUP:
             if (value < 0 || value > 4096) FAIL(b->ctx, VBX_ERR_INVALID, "scan group must be in [0, 4096]");
             b->scan_group = (int)value;
+            return VBX_OK;
+        case VBX_OPT_SCAN_GROUP2:
+            if (value < 0 || value > 4096) FAIL(b->ctx, VBX_ERR_INVALID, "level-2 scan group must be in [0, 4096]");
+            b->scan_group2 = (int)value;
+            return VBX_OK;
+        case VBX_OPT_THREE_LEVEL_FROM:
+            if (value < 4) FAIL(b->ctx, VBX_ERR_INVALID, "three-level threshold must be >= 4 chunks");
+            b->three_level_from = (int)value;
             return VBX_OK;
         case VBX_OPT_CHUNK_FRAMES:
             if (value < 0) FAIL(b->ctx, VBX_ERR_INVALID, "chunk_frames must be >= 0");

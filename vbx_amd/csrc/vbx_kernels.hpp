@@ -25,7 +25,8 @@ struct RecDesc {
     int tile0;        // first workgroup tile
     int ntiles;       // tiles of kTileFrames frames
     int has_model;    // alpha/invL supplied by the caller: skip the first M-step (VBx.py:94)
-    int sup0;         // first group operator of this recording (two-level boundary walk)
+    int sup0;         // first group operator of this recording (two- / three-level boundary walk)
+    int sup20;        // first level-2 group operator of this recording (three-level walk)
     double lp, Fa, Fb;
     double gsum;      // sum_t G_t (VBx.py:87)
 };
@@ -101,6 +102,12 @@ template <typename R> struct BatchView {
     const int* sup_rec;    // [nsup_total] recording of a group
     const int* sup_idx;    // [nsup_total] index of the group within its recording
     int sgroup, nsup_total;
+    // third level (very long recordings): operators of groups of `sgroup2` consecutive level-1 groups
+    R* sop2;               // [nsup2_total][Sp][Sp]
+    int* sopexp2;          // [nsup2_total][Sp]
+    const int* sup2_rec;   // [nsup2_total] recording of a level-2 group
+    const int* sup2_idx;   // [nsup2_total] index of the level-2 group within its recording
+    int sgroup2, nsup2_total;
     // scan chunks per tile: 1 = one transfer operator / boundary pair per tile of kTileFrames frames;
     // 2 = per half tile (kScanHalf frames), chunk index 2*tile + half -- the fused kernels use it to re-run the
     // two halves of a tile on separate waves (half the dependent chain).  op / opexp / fbound / gbound always

@@ -128,18 +128,21 @@ template <typename R, int SP> struct Scan2Cfg {
     static constexpr int NBUF = (2 * RB * kOpBytes <= kBudget) ? 2 : 1;
 };
 
-// The walk is used at three levels (`level` argument of scan2_kernel):
+// The walk is used at several levels (`level` argument of scan2_kernel):
 //   0  flat: every chunk operator of a recording, from the initial vector          (grid.x = recording)
 //   2  the group operators of scan_compose_kernel: boundaries at the group edges     (grid.x = recording)
-//   3  inside one group, from the boundary level 2 left at its edge                  (grid.x = group)
-// A chain of K-1 dependent mat-vecs costs 0.3-0.9 us each; with groups of G ~ sqrt(K) chunks the critical
-// path is G products + K/G + G mat-vecs instead.
+//   3  inside one group, from the boundary left at its edge                          (grid.x = group)
+//   4  the level-2 group operators (groups of G2 groups): boundaries at their edges  (grid.x = recording)
+//   5  inside one level-2 group over its group operators, from the boundary level 4 left at its edge (grid.x = level-2 group)
+// A chain of K-1 dependent mat-vecs costs 0.3-0.9 us each; with groups of G chunks the critical path is G products +
+// K/G + G mat-vecs (levels 2, 3); for very long recordings a third level (4, 5, 3) makes it G + G2 products and
+// K/(G G2) + G2 + G mat-vecs: T = 200 000 (K = 1563): 17 products + 104 mat-vecs -> 14 products + 40 mat-vecs.
 template <typename R, int SP, int dir>
 __device__ __forceinline__ void scan2_body(const BatchView<R>& bt, int level, R* ring, int* exps, R* wl) {
     using Cfg = Scan2Cfg<R, SP>;
     using R4 = typename Vec<R>::v4;
     constexpr int HL = 64 / SP, NI = SP / HL, RB = Cfg::RB, NBUF = Cfg::NBUF, OPSZ = Cfg::kOpElems;
-    const int rec = level == 3 ? bt.sup_rec[blockIdx.x] : blockIdx.x;
+    const int rec = level == 3 ? bt.sup_rec[blockIdx.x] : level == 5 ? bt.sup2_rec[blockIdx.x] : blockIdx.x;
     if (bt.state[rec].done) return;
     const RecDesc rd = bt.recs[rec];
     const int K = chunk_count(rd, bt.spt), G = bt.sgroup;      // chunks of this recording, first one cb0
@@ -163,6 +166,27 @@ __device__ __forceinline__ void scan2_body(const BatchView<R>& bt, int level, R*
         nops = (int)(b - 1 - a);
         op0 = b0 = binit = dir == 0 ? a : b - 1;
         if (nops <= 0) return;
+    } else if (level == 4) {                    // over the level-2 group operators of the recording
+        const int G2 = bt.sgroup2, n1 = (K + G - 1) / G, n2 = (n1 + G2 - 1) / G2;
+        ops = bt.sop2;
+        oexp = bt.sopexp2;
+        nops = n2 - 1;
+        op0 = dir == 0 ? rd.sup20 : rd.sup20 + n2 - 1;
+        bs = dir == 0 ? G * G2 : -G * G2;
+        b0 = dir == 0 ? cb0 : cb0 + (long long)n2 * G * G2 - 1;
+    } else if (level == 5) {                    // inside one level-2 group: over its (level-1) group operators
+        const int G2 = bt.sgroup2, n1 = (K + G - 1) / G;
+        const int a = bt.sup2_idx[blockIdx.x] * G2, b = min(a + G2, n1);      // level-1 groups [a, b) of this recording
+        ops = bt.sop;
+        oexp = bt.sopexp;
+        nops = b - 1 - a;
+        if (nops <= 0) return;
+        op0 = dir == 0 ? rd.sup0 + a : rd.sup0 + b - 1;
+        bs = dir == 0 ? G : -G;
+        // forward: from the vector entering the first chunk of the level-2 group; backward: from the vector at the last
+        // chunk it really has (the recording's last group may be short), written to the regular positions below it
+        binit = dir == 0 ? cb0 + (long long)a * G : min(cb0 + (long long)b * G, cb0 + K) - 1;
+        b0 = dir == 0 ? binit : cb0 + (long long)b * G - 1;
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = lane / HL, h = lane % HL;
@@ -201,7 +225,7 @@ __device__ __forceinline__ void scan2_body(const BatchView<R>& bt, int level, R*
 
     R y = 0;
     if (wave == 0) {
-        if (level == 3) {
+        if (level == 3 || level == 5) {
             y = bound[binit * SP + j];
         } else {
             if (dir == 0) y = (j < rd.S) ? (R)(bt.ip[(long long)rec * SP + j] + 1e-8) : (R)0;
@@ -304,8 +328,9 @@ template <int W> __device__ __forceinline__ int group_max(int v) {
 // Round 2: the products were S^2 LDS reads per thread on the VALU before (7 us per product at SP = 64, the largest
 // part of the boundary walk of a long recording).  Model: oracle/chunked_scan.py::compose.
 // =======================================================================================
+// `level` 1: groups of chunk operators (op -> sop); 2: groups of group operators (sop -> sop2, three-level walk).
 template <typename R, int SP>
-__global__ __launch_bounds__(256) void scan_compose_kernel(BatchView<R> bt) {
+__global__ __launch_bounds__(256) void scan_compose_kernel(BatchView<R> bt, int level) {
     using M = Mfma16<R>;
     using acc_t = typename M::acc_t;
     using R4 = typename Vec<R>::v4;
@@ -316,32 +341,49 @@ __global__ __launch_bounds__(256) void scan_compose_kernel(BatchView<R> bt) {
     __shared__ __attribute__((aligned(16))) R Wt[SP * SP];
     __shared__ int eF[SP];
     const int sup = blockIdx.x;
-    const int rec = bt.sup_rec[sup];
+    const int rec = level == 2 ? bt.sup2_rec[sup] : bt.sup_rec[sup];
     if (bt.state[rec].done) return;
     const RecDesc rd = bt.recs[rec];
     const int G = bt.sgroup;
     const long long cb0 = (long long)rd.tile0 * bt.spt;
-    const long long a = cb0 + (long long)bt.sup_idx[sup] * G, b = min(a + G, cb0 + chunk_count(rd, bt.spt));
+    // the operators [a, b) multiplied here, in the array they come from, and where the product goes
+    long long a, b;
+    const R* __restrict__ in_op = bt.op;
+    const int* __restrict__ in_exp = bt.opexp;
+    R* __restrict__ out_op = bt.sop;
+    int* __restrict__ out_exp = bt.sopexp;
+    if (level == 2) {
+        const int n1 = (chunk_count(rd, bt.spt) + G - 1) / G;
+        a = rd.sup0 + (long long)bt.sup2_idx[sup] * bt.sgroup2;
+        b = min(a + bt.sgroup2, (long long)rd.sup0 + n1);
+        in_op = bt.sop;
+        in_exp = bt.sopexp;
+        out_op = bt.sop2;
+        out_exp = bt.sopexp2;
+    } else {
+        a = cb0 + (long long)bt.sup_idx[sup] * G;
+        b = min(a + G, cb0 + chunk_count(rd, bt.spt));
+    }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l16 = lane & 15, g = lane >> 4;
     const bool mul = wave < NT;                        // the waves that hold columns of P
     const int i = (mul ? 16 * wave : 0) + l16;         // my column
     R pv[NT][4];
     int eP = kNoMass;
     if (mul) {
-        eP = bt.opexp[(long long)a * SP + i];
+        eP = in_exp[(long long)a * SP + i];
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pv[mt][r] = bt.op[((long long)a * SP + i) * SP + 16 * mt + M::row(lane, r)];
+            for (int r = 0; r < 4; ++r) pv[mt][r] = in_op[((long long)a * SP + i) * SP + 16 * mt + M::row(lane, r)];
     }
     R4 fr[VPT];
     int efr = 0;
     auto fetch = [&](long long k) {                        // chunk operator k: global -> registers
-        const R4* __restrict__ src = reinterpret_cast<const R4*>(bt.op + (long long)k * SP * SP);
+        const R4* __restrict__ src = reinterpret_cast<const R4*>(in_op + (long long)k * SP * SP);
 #pragma unroll
         for (int u = 0; u < VPT; ++u)
             if (u * 256 + tid < SP * SP / 4) fr[u] = src[u * 256 + tid];
-        if (tid < SP) efr = bt.opexp[(long long)k * SP + tid];
+        if (tid < SP) efr = in_exp[(long long)k * SP + tid];
     };
     if (a + 1 < b) fetch(a + 1);
     for (long long k = a + 1; k < b; ++k) {
@@ -409,12 +451,12 @@ __global__ __launch_bounds__(256) void scan_compose_kernel(BatchView<R> bt) {
         __syncthreads();                                   // Fl / Wt are rewritten by the next product
     }
     if (mul) {
-        R* __restrict__ dst = bt.sop + ((long long)sup * SP + i) * SP;
+        R* __restrict__ dst = out_op + ((long long)sup * SP + i) * SP;
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) dst[16 * mt + M::row(lane, r)] = pv[mt][r];
-        if (g == 0) bt.sopexp[(long long)sup * SP + i] = eP;
+        if (g == 0) out_exp[(long long)sup * SP + i] = eP;
     }
 }
 
