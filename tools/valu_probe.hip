@@ -92,6 +92,42 @@ template <int MODE> __global__ __launch_bounds__(1024) void probe(float* out, lo
     if (acc == 12345.678f) out[0] = acc;
 }
 
+// Do f32 MFMAs and packed-f32 VALU work of DIFFERENT waves overlap on one SIMD?  Even waves of a workgroup issue
+// v_mfma_f32_16x16x4_f32 on 8 independent accumulators, odd waves v_pk_fma_f32 on 8 independent pairs; each role stamps
+// its own loop.  ROLE 0: all waves MFMA, 1: all waves VALU, 2: mixed (half and half on every SIMD).
+typedef float float4_t __attribute__((ext_vector_type(4)));
+template <int ROLE> __global__ __launch_bounds__(1024) void probe_mix(float* out, long long* ticks, int iters) {
+    const int wave = threadIdx.x >> 6;
+    // waves go to SIMDs round-robin: waves w and w + 4 share a SIMD; mixed = waves 0-3 MFMA, 4-7 VALU, ...
+    const bool mfma = ROLE == 0 || (ROLE == 2 && ((wave >> 2) & 1) == 0);
+    const float s = 1.0f + 1e-7f * threadIdx.x;
+    float4_t acc[8];
+    float2_t p[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { acc[k] = float4_t{s, s, s, s}; p[k] = float2_t{s + k, s - k}; }
+    const float2_t c2 = float2_t{0.999f, 1.001f}, m2 = float2_t{0.9999f, 1.0001f};
+    __syncthreads();
+    const long long c0 = clock64();
+    if (mfma) {
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(s, 0.5f, acc[k], 0, 0, 0);
+    } else {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)            // 32 packed FMAs per iteration: about the issue time of 8 MFMAs
+#pragma unroll
+                for (int k = 0; k < 8; ++k) PKFMA(p[k], c2, m2);
+        }
+    }
+    const long long c1 = clock64();
+    float accs = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) accs += acc[k].x + acc[k].y + acc[k].z + acc[k].w + p[k].x + p[k].y;
+    if (blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == 256)) ticks[threadIdx.x ? 1 : 0] = c1 - c0;
+    if (accs == 12345.678f) out[0] = accs;
+}
+
 int main() {
     float* out; long long* ticks; long long h;
     (void)hipMalloc(&out, 64); (void)hipMalloc(&ticks, 16);
@@ -117,6 +153,20 @@ int main() {
             printf("  %d w/SIMD: %6.2f cyc/inst (%7.1f cyc/iter/wave)", wps, (double)h / ((double)iters * ninst[mode] * wps), (double)h / iters);
         }
         printf("\n");
+    }
+    printf("\nf32 MFMA 16x16x4 (8 per iteration) and v_pk_fma_f32 (32 per iteration) of different waves on one SIMD, 1024-thread workgroups "
+           "(4 waves per SIMD):\n");
+    long long h2[2];
+    const char* rn[] = {"all 16 waves MFMA", "all 16 waves packed VALU", "waves 0-3, 8-11 MFMA / waves 4-7, 12-15 VALU"};
+    for (int role = 0; role < 3; ++role) {
+        for (int rep = 0; rep < 2; ++rep) {
+            if (role == 0) probe_mix<0><<<256, 1024>>>(out, ticks, 2000);
+            if (role == 1) probe_mix<1><<<256, 1024>>>(out, ticks, 2000);
+            if (role == 2) probe_mix<2><<<256, 1024>>>(out, ticks, 2000);
+            (void)hipDeviceSynchronize();
+        }
+        (void)hipMemcpy(h2, ticks, 16, hipMemcpyDeviceToHost);
+        printf("  %-48s wave 0: %8.1f ticks per iteration   wave 4: %8.1f ticks per iteration\n", rn[role], (double)h2[0] / 2000, (double)h2[1] / 2000);
     }
     return 0;
 }
