@@ -343,7 +343,7 @@ def main():
                 'kernels_avg_us': {k: round(v['avg_us'], 2) for k, v in pk.items()}, 'elbo_last': elbo}
 
     configs = {}
-    if rank == 0 and not args.no_configs:
+    if rank == 0 and world == 1 and not args.no_configs:      # (a multi-GPU run measures the sharded batch only)
         def single(T, S, precision, lp):
             def make(mi, st):
                 from vbx_amd.synth import make_recording
@@ -380,7 +380,7 @@ def main():
         f64 = (t64, pk64, dk64, ms64)
 
     single_rec = None
-    if not args.no_single and rank == 0:
+    if not args.no_single and rank == 0 and world == 1:
         b1 = make_batch(ctx, 1, args.T, args.S, args.D, args.precision, seed0=0, max_iters=W + 4 * K)
         b1.run(W, -np.inf)
         ts = []
