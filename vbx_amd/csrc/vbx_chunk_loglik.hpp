@@ -27,15 +27,21 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)si
     using acc_t = typename M::acc_t;
     using R4 = typename Vec<R>::v4;
     constexpr int NT = SP / 16;
-    // operator build: PH lanes share a column and hold NR states each.  Fewer lanes per column = fewer issue
-    // slots per frame (the column sum needs log2(PH) DPP stages with their wait states): 72 / 46 / 39 slots per
-    // chunk-frame for PH = 8 / 4 / 2 at SP = 32, but also fewer wavefronts to hide each other's latency.
-    // Measured on 64 recordings of T = 10 000: 171 / 163 / 176 us per launch, so PH = 4 (two wavefronts build
-    // the operator, the other two retire after phase 1).  With the packed two-operation frame of phase 2,
-    // PH = 8 and PH = 4 measure the same (346 vs 344-349 us per iteration).
-    constexpr int kOperatorLanes = 4;
+    // operator build: PH lanes share a column and hold NR states each; a thread can build NC columns side by side
+    // (independent recursions on the same rows of b: vbx_operator.hpp).  Fewer lanes per column = fewer issue slots per
+    // frame (the column sum needs log2(PH) DPP stages with their wait states) but fewer wavefronts to hide each other's
+    // latency.  One column per thread: PH = 8 / 4 / 2 at SP = 32 measured 171 / 163 / 176 us per launch of 64 recordings
+    // (round 1), so PH = 4.  Round 3 tried NC = 2 columns per thread on PH = 8 lanes (same thread count, half the LDS reads,
+    // two independent chains per wavefront) against the phase's 800 cycles per frame and wave at SP = 64: SLOWER everywhere --
+    // chunk_loglik 137 -> 147 us (SP = 32, f32), 250 -> 274 (f64), 823 -> 854 (SP = 64, the C5 sweep): the third DPP stage
+    // and the second set of sums cost more issue slots than the second chain hides (A/B builds, -DVBX_OP_COLS=2).
+#ifndef VBX_OP_COLS
+#define VBX_OP_COLS 1
+#endif
+    constexpr int NC = (SP >= 32) ? VBX_OP_COLS : 1;
+    constexpr int kOperatorLanes = 4 * NC;
     constexpr int kLanesWanted = SP / 4 < kOperatorLanes ? SP / 4 : kOperatorLanes;     // a lane keeps >= 4 states
-    constexpr int PH = (SP * kLanesWanted <= 256) ? kLanesWanted : 256 / SP, NR = SP / PH;
+    constexpr int PH = (SP * kLanesWanted / NC <= 256) ? kLanesWanted : 256 * NC / SP, NR = SP / PH;
     constexpr int AST = kAlphaSlice + 4;               // padded row of the alpha slice: conflict-free fragment reads
     // one LDS region, two lives: the alpha slice during the MFMA pass, then b of the chunk
     constexpr int kLds = kTileFrames * SP > SP * AST ? kTileFrames * SP : SP * AST;
@@ -175,7 +181,8 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)si
     // scan_compose_kernel multiplies chunk operators (weights 2^E shifted by the largest exponent on a column's
     // support, the column's scale kept as an integer exponent).
     {
-        constexpr int NOPT = SP * PH;                      // threads that build one operator
+        constexpr int NOPT = SP * PH / NC;                 // threads that build one operator
+        constexpr int CS = SP / NC;                        // a thread's columns: colbase, colbase + CS, ...
         constexpr int H = kTileFrames / 2;
         constexpr bool kSideBySide = 2 * NOPT <= 256;
         constexpr int kNoMass = -(1 << 24), kNever = -(1 << 28);
@@ -184,20 +191,26 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)si
         const bool two = split && len > H;                 // (uniform) the tile has a second half
         const int my_half = !kSideBySide ? 0 : (NOPT % 64 == 0) ? wave / (NOPT / 64) : tid / NOPT;   // (scalar: loop bounds)
         const int otid = kSideBySide ? tid % NOPT : tid;
-        const int col = otid / PH, part = otid % PH, j0 = part * NR;
+        const int colbase = otid / PH, part = otid % PH, j0 = part * NR;
         const bool builder = kSideBySide ? tid < 2 * NOPT : tid < NOPT;
-        R x[2][NR];                                        // [0]: my operator (side by side) or P1; [1]: P2 (SP = 64)
-        int expo[2] = {kNoMass, kNoMass};
+        R x[2][NC][NR];                                    // [0]: my operator (side by side) or P1; [1]: P2 (SP = 64)
+        int expo[2][NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) expo[0][k] = expo[1][k] = kNoMass;
         const R* c_rec = bt.cop + (long long)rec * SP;
         const LpPow* lppow = bt.lppow + (long long)rec * (kTileFrames + 1);
-        auto build = [&](int half, R (&xo)[NR], int& eo) {
+        auto build = [&](int half, R (&xo)[NC][NR], int (&eo)[NC]) {
             const int lo = half * H, hi = (half == 0 && split) ? min(len, H) : len;
-            operator_column<R, SP, PH>(btile, lo, hi, t0 + lo == 0, col, part, rd.lp, c_rec, lppow, xo, eo);
+            operator_columns<R, SP, PH, NC>(btile, lo, hi, t0 + lo == 0, colbase, part, rd.lp, c_rec, lppow, xo, eo);
             if (bt.oph) {
-                R* __restrict__ dst = bt.oph + (((long long)tile * 2 + half) * SP + col) * SP + j0;
 #pragma unroll
-                for (int r = 0; r < NR; ++r) dst[r] = xo[r];
-                if (part == 0) bt.ophexp[((long long)tile * 2 + half) * SP + col] = eo;
+                for (int k = 0; k < NC; ++k) {
+                    const int col = colbase + k * CS;
+                    R* __restrict__ dst = bt.oph + (((long long)tile * 2 + half) * SP + col) * SP + j0;
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) dst[r] = xo[k][r];
+                    if (part == 0) bt.ophexp[((long long)tile * 2 + half) * SP + col] = eo[k];
+                }
             }
         };
         if (builder) {
@@ -210,10 +223,14 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)si
         }
         if (!two) {                                        // P = P1
             if (builder && my_half == 0) {
-                R* __restrict__ dst = bt.op + ((long long)tile * SP + col) * SP + j0;
 #pragma unroll
-                for (int r = 0; r < NR; ++r) dst[r] = x[0][r];
-                if (part == 0) bt.opexp[(long long)tile * SP + col] = expo[0];
+                for (int k = 0; k < NC; ++k) {
+                    const int col = colbase + k * CS;
+                    R* __restrict__ dst = bt.op + ((long long)tile * SP + col) * SP + j0;
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) dst[r] = x[0][k][r];
+                    if (part == 0) bt.opexp[(long long)tile * SP + col] = expo[0][k];
+                }
             }
         } else {
             // P = P2 P1.  F = P2 as built (column j contiguous) and W[j][i] = P1[j, i] 2^(E2_j - top_i) go through the
@@ -225,29 +242,36 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)si
             const bool holds_p2 = builder && (kSideBySide ? my_half == 1 : true);
             const bool holds_p1 = builder && my_half == 0;
             if (holds_p2) {
-                const R (&x2)[NR] = x[kSideBySide ? 0 : 1];
+                const R (&x2)[NC][NR] = x[kSideBySide ? 0 : 1];
 #pragma unroll
-                for (int r = 0; r < NR; ++r) Fl[col * SP + j0 + r] = x2[r];
-                if (part == 0) eF[col] = expo[kSideBySide ? 0 : 1];
+                for (int k = 0; k < NC; ++k) {
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) Fl[(colbase + k * CS) * SP + j0 + r] = x2[k][r];
+                    if (part == 0) eF[colbase + k * CS] = expo[kSideBySide ? 0 : 1][k];
+                }
             }
             __syncthreads();
             if (holds_p1) {
-                int tj[NR], top = kNever;
 #pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    const int e = eF[j0 + r];
-                    tj[r] = (x[0][r] > (R)0 && e > kNoMass / 2) ? e + exponent_of(x[0][r]) : kNever;
-                    top = max(top, tj[r]);
+                for (int k = 0; k < NC; ++k) {
+                    const int col = colbase + k * CS;
+                    int tj[NR], top = kNever;
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        const int e = eF[j0 + r];
+                        tj[r] = (x[0][k][r] > (R)0 && e > kNoMass / 2) ? e + exponent_of(x[0][k][r]) : kNever;
+                        top = max(top, tj[r]);
+                    }
+                    if (PH >= 2) top = max(top, dpp_mov<0xB1>(top));
+                    if (PH >= 4) top = max(top, dpp_mov<0x4E>(top));
+                    if (PH >= 8) top = max(top, dpp_mov<0x141>(top));
+                    if (PH >= 16) top = max(top, dpp_mov<0x140>(top));
+                    const bool alive = top > -(1 << 27) && expo[0][k] > kNoMass / 2;
+#pragma unroll
+                    for (int r = 0; r < NR; ++r)
+                        Wt[(j0 + r) * SP + col] = (alive && tj[r] > -(1 << 27)) ? scale2(x[0][k][r], eF[j0 + r] - top) : (R)0;
+                    if (part == 0) eW[col] = alive ? expo[0][k] + top : kNoMass;
                 }
-                if (PH >= 2) top = max(top, dpp_mov<0xB1>(top));
-                if (PH >= 4) top = max(top, dpp_mov<0x4E>(top));
-                if (PH >= 8) top = max(top, dpp_mov<0x141>(top));
-                if (PH >= 16) top = max(top, dpp_mov<0x140>(top));
-                const bool alive = top > -(1 << 27) && expo[0] > kNoMass / 2;
-#pragma unroll
-                for (int r = 0; r < NR; ++r)
-                    Wt[(j0 + r) * SP + col] = (alive && tj[r] > -(1 << 27)) ? scale2(x[0][r], eF[j0 + r] - top) : (R)0;
-                if (part == 0) eW[col] = alive ? expo[0] + top : kNoMass;
             }
             __syncthreads();
             if (wave < NT) {

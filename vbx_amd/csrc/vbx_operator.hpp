@@ -18,17 +18,21 @@ namespace vbx {
 
 // btile: b of the tile in LDS, [frames][SP].  first_plain: frame lo is frame 0 of the recording (x <- b_0 x, VBx.py:163:
 // no transition).  c_rec: the recursion's c of the recording, [SP] (c / lp in the scaled form: BatchView::cop, written by
-// mstep_fin); lppow: lp^n as (mantissa, exponent) for n = 0 .. kTileFrames (BatchView::lppow, host table) -- a dozen f64
+// fin_kernel); lppow: lp^n as (mantissa, exponent) for n = 0 .. kTileFrames (BatchView::lppow, host table) -- a dozen f64
 // divisions, a log2 and an exp2 per wave and operator used to be a fifth of chunk_loglik's vector instructions.
-// -> x[NR] (column sums in [0.5, 1)), expo (the column is x * 2^expo; -(1 << 24) for an all-zero column, which must
+// A thread builds NC columns at once -- colbase, colbase + SP / NC, ... -- on the same NR states: the rows of b and c are
+// fetched once for all of them and the NC recursions are independent instruction streams.  NC = 1 is what runs: two
+// columns per thread (on twice the lanes per column, the same thread count) measured 4-7 % slower on every shape
+// (vbx_chunk_loglik.hpp).
+// -> x[k][NR] (column sums in [0.5, 1)), expo[k] (the column is x * 2^expo; -(1 << 24) for an all-zero column, which must
 // never win an exponent maximum).
-template <typename R, int SP, int PH>
-__device__ __forceinline__ void operator_column(const R* btile, int lo, int hi, bool first_plain, int col, int part,
-                                                double lp_d, const R* __restrict__ c_rec, const LpPow* __restrict__ lppow,
-                                                R (&x)[SP / PH], int& expo) {
+template <typename R, int SP, int PH, int NC>
+__device__ __forceinline__ void operator_columns(const R* btile, int lo, int hi, bool first_plain, int colbase, int part,
+                                                 double lp_d, const R* __restrict__ c_rec, const LpPow* __restrict__ lppow,
+                                                 R (&x)[NC][SP / PH], int (&expo)[NC]) {
     using R2 = typename Vec<R>::v2;
     using R4 = typename Vec<R>::v4;
-    constexpr int NR = SP / PH, NP = NR / 2;
+    constexpr int NR = SP / PH, NP = NR / 2, CS = SP / NC;
     static_assert(NR % 4 == 0, "operator lanes hold a multiple of four states");
     const int j0 = part * NR;
     const R lp = (R)lp_d;
@@ -40,91 +44,118 @@ __device__ __forceinline__ void operator_column(const R* btile, int lo, int hi, 
         c[4 * q] = c4.x; c[4 * q + 1] = c4.y; c[4 * q + 2] = c4.z; c[4 * q + 3] = c4.w;
     }
 #pragma unroll
-    for (int r = 0; r < NR; ++r) x[r] = (j0 + r == col) ? (R)1 : (R)0;
-    expo = 0;
+    for (int k = 0; k < NC; ++k) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) x[k][r] = (j0 + r == colbase + k * CS) ? (R)1 : (R)0;
+        expo[k] = 0;
+    }
     int step = lo;
     if (first_plain) {
 #pragma unroll
-        for (int r = 0; r < NR; ++r) x[r] *= btile[lo * SP + j0 + r];
+        for (int k = 0; k < NC; ++k)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) x[k][r] *= btile[lo * SP + j0 + r];
         step = lo + 1;
     }
     const int transitions = hi - step;
     auto recursion = [&](auto scaled_tag) {
-        R2 x2[NP], c2[NP];
+        R2 x2[NC][NP], c2[NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            x2[p] = R2{x[2 * p], x[2 * p + 1]};
             c2[p] = R2{c[2 * p], c[2 * p + 1]};
+#pragma unroll
+            for (int k = 0; k < NC; ++k) x2[k][p] = R2{x[k][2 * p], x[k][2 * p + 1]};
         }
         const R2 lp2 = R2{lp, lp};
-        auto colsum2 = [&]() {                   // pairwise: packed adds
+        auto colsum2 = [&](int k) {              // pairwise: packed adds
             R2 v[NP];
 #pragma unroll
-            for (int p = 0; p < NP; ++p) v[p] = x2[p];
+            for (int p = 0; p < NP; ++p) v[p] = x2[k][p];
 #pragma unroll
             for (int w = NP / 2; w >= 1; w >>= 1)
 #pragma unroll
                 for (int p = 0; p < w; ++p) v[p] += v[p + w];
             return column_sum<PH>(v[0].x + v[0].y);
         };
-        auto frame = [&](int f, R sig) {
-            const R2 sig2 = R2{sig, sig};
+        auto frame = [&](int f, const R (&sig)[NC]) {
             const R* row = btile + f * SP + j0;
 #pragma unroll
             for (int q = 0; q < NR / 4; ++q) {
                 const R4 b4 = *reinterpret_cast<const R4*>(row + 4 * q);
                 const R2 b0 = R2{b4.x, b4.y}, b1 = R2{b4.z, b4.w};
-                if (decltype(scaled_tag)::value) {
-                    x2[2 * q] = b0 * (c2[2 * q] * sig2 + x2[2 * q]);
-                    x2[2 * q + 1] = b1 * (c2[2 * q + 1] * sig2 + x2[2 * q + 1]);
-                } else {
-                    x2[2 * q] = b0 * (lp2 * x2[2 * q] + c2[2 * q] * sig2);
-                    x2[2 * q + 1] = b1 * (lp2 * x2[2 * q + 1] + c2[2 * q + 1] * sig2);
+#pragma unroll
+                for (int k = 0; k < NC; ++k) {
+                    const R2 sig2 = R2{sig[k], sig[k]};
+                    if (decltype(scaled_tag)::value) {
+                        x2[k][2 * q] = b0 * (c2[2 * q] * sig2 + x2[k][2 * q]);
+                        x2[k][2 * q + 1] = b1 * (c2[2 * q + 1] * sig2 + x2[k][2 * q + 1]);
+                    } else {
+                        x2[k][2 * q] = b0 * (lp2 * x2[k][2 * q] + c2[2 * q] * sig2);
+                        x2[k][2 * q + 1] = b1 * (lp2 * x2[k][2 * q + 1] + c2[2 * q + 1] * sig2);
+                    }
                 }
             }
         };
-        auto renorm = [&]() {                    // column sum back to [0.5, 1): one exact product per pair
-            R sig = colsum2();
+        auto renorm = [&](int k) {               // column sum back to [0.5, 1): one exact product per pair
+            R sig = colsum2(k);
             const int e = rescale_exponent(sig);
-            expo += e;
+            expo[k] += e;
             const R sc = scale2((R)1, -e);
             const R2 sc2 = R2{sc, sc};
 #pragma unroll
-            for (int p = 0; p < NP; ++p) x2[p] *= sc2;
+            for (int p = 0; p < NP; ++p) x2[k][p] *= sc2;
             return sig * sc;
         };
+        R sig[NC];
         for (; step + 4 <= hi; step += 4) {
-            frame(step, renorm());
 #pragma unroll
-            for (int k = 1; k < 4; ++k) frame(step + k, colsum2());
-        }
-        for (; step < hi; ++step) frame(step, renorm());
+            for (int k = 0; k < NC; ++k) sig[k] = renorm(k);
+            frame(step, sig);
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            x[2 * p] = x2[p].x;
-            x[2 * p + 1] = x2[p].y;
+            for (int u = 1; u < 4; ++u) {
+#pragma unroll
+                for (int k = 0; k < NC; ++k) sig[k] = colsum2(k);
+                frame(step + u, sig);
+            }
         }
+        for (; step < hi; ++step) {
+#pragma unroll
+            for (int k = 0; k < NC; ++k) sig[k] = renorm(k);
+            frame(step, sig);
+        }
+#pragma unroll
+        for (int k = 0; k < NC; ++k)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                x[k][2 * p] = x2[k][p].x;
+                x[k][2 * p + 1] = x2[k][p].y;
+            }
     };
+    R mant = (R)1;
+    int fl = 0;
     if (scaled) {
         recursion(std::true_type{});
         const LpPow pw = lppow[transitions];                 // lp^transitions = mant * 2^fl, mant in [1, 2)
-        const R mant = (R)pw.mant;
-        expo += pw.fl;
-#pragma unroll
-        for (int r = 0; r < NR; ++r) x[r] *= mant;
+        mant = (R)pw.mant;
+        fl = pw.fl;
     } else {
         recursion(std::false_type{});
     }
-    {   // final power-of-two normalisation: column sums end in [0.5, 1)
-        R v = x[0];
 #pragma unroll
-        for (int r = 1; r < NR; ++r) v += x[r];
+    for (int k = 0; k < NC; ++k) {   // lp^transitions, then the final power-of-two normalisation: column sums end in [0.5, 1)
+        expo[k] += fl;
+        R v = 0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            x[k][r] *= mant;
+            v += x[k][r];
+        }
         const R sig = column_sum<PH>(v);
         const int e = rescale_exponent(sig);
-        expo += e;
+        expo[k] += e;
 #pragma unroll
-        for (int r = 0; r < NR; ++r) x[r] = scale2(x[r], -e);
-        if (!(sig > (R)0)) expo = -(1 << 24);
+        for (int r = 0; r < NR; ++r) x[k][r] = scale2(x[k][r], -e);
+        if (!(sig > (R)0)) expo[k] = -(1 << 24);
     }
 }
 
