@@ -538,6 +538,38 @@ def test_fa_fb_sweep_on_one_shared_rho_equals_independent_recordings(ctx, precis
     other.close()
 
 
+def test_sharing_across_stream_sub_batches_is_refused_with_a_way_out(ctx, monkeypatch):
+    """A batch on several streams deals its recordings to sub-batches with a device arena each; x-vectors are shared inside
+    one arena.  Across two of them the call fails and names the remedy; with one stream the same calls go through."""
+    from vbx_amd import _capi
+    from vbx_amd.synth import make_recording
+    T, S = 1500, 8
+    X, Phi, _ = make_recording(T, S, seed=2, kappa=0.05)
+    g0 = np.random.default_rng(3).gamma(1.0, size=(T, S))
+    g0 /= g0.sum(1, keepdims=True)
+    monkeypatch.setenv('VBX_AMD_STREAMS', '2')
+    batch = _capi.Batch(ctx, [T] * 4, [S] * 4, 128, precision='fp64', max_iters=3)
+    assert batch.streams == 2
+    batch.set_recording(0, X, Phi, np.ones(S) / S, g0, 0.9, 0.3, 17.0)
+    hit = 0
+    for k in (1, 2, 3):                                   # (recordings 0..3 alternate between the two sub-batches)
+        try:
+            batch.set_recording_shared(k, 0, np.ones(S) / S, g0, 0.9, 0.2 + 0.1 * k, 17.0)
+        except _capi.VbxError as exc:
+            assert 'VBX_OPT_STREAMS' in str(exc)
+            hit += 1
+    assert hit >= 1
+    batch.close()
+    monkeypatch.setenv('VBX_AMD_STREAMS', '1')
+    batch = _capi.Batch(ctx, [T] * 4, [S] * 4, 128, precision='fp64', max_iters=3)
+    batch.set_recording(0, X, Phi, np.ones(S) / S, g0, 0.9, 0.3, 17.0)
+    for k in (1, 2, 3):
+        batch.set_recording_shared(k, 0, np.ones(S) / S, g0, 0.9, 0.2 + 0.1 * k, 17.0)
+    batch.run(3, -np.inf)
+    assert all(len(batch.result(k, want_gamma=False, want_model=False)['Li']) == 3 for k in range(4))
+    batch.close()
+
+
 def test_python_sweep_api_equals_one_call_per_point(synth_cases):
     """vbx_amd.batch.VBx_sweep == [VBx(X, Phi, **point) ...]: same tuples, same global-RNG draws in list order."""
     import vbx_amd
