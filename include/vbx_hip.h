@@ -62,8 +62,8 @@ extern "C" {
 #define VBX_OPT_CHUNK_FRAMES 4  /* frames per scan chunk for VBX_FB_CHUNKED (0 = auto)         */
 #define VBX_OPT_SCAN_GROUP 6    /* chunks per group of the two-level boundary walk: 0 auto (sqrt(chunks / 5) once a
                                    recording has >= 160 chunks, or >= 32 in a batch of <= 4), 1 flat chain, >= 2 explicit */
-#define VBX_OPT_SCAN_GROUP2 12   /* groups per level-2 group of the THREE-level walk: 0 auto (from 600 chunks per recording --
-                                   T = 77 000 -- both group sizes become (chunks / 8)^(1/3) + 1), 1 off, >= 2 explicit (on top of
+#define VBX_OPT_SCAN_GROUP2 12   /* groups per level-2 group of the THREE-level walk: 0 auto (from 300 chunks per recording --
+                                   T = 38 400 -- both group sizes become (chunks / 8)^(1/3) + 1), 1 off, >= 2 explicit (on top of
                                    the VBX_OPT_SCAN_GROUP in effect)                                                     */
 #define VBX_OPT_THREE_LEVEL_FROM 13 /* chunk count from which VBX_OPT_SCAN_GROUP2 = 0 adds the third level            */
 #define VBX_OPT_SPLIT_TILES 11  /* fused path: tiles re-run as two halves side by side (four 64-frame chains per tile instead of two

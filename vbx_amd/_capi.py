@@ -366,6 +366,8 @@ class Batch:
         group2 = os.environ.get('VBX_AMD_SCAN_GROUP2')    # level-2 groups of the three-level walk (0 auto, 1 off)
         if group2 is not None:
             self.set_option(OPT_SCAN_GROUP2, int(group2))
+        if os.environ.get('VBX_AMD_THREE_LEVEL_FROM') is not None:
+            self.set_option(OPT_THREE_LEVEL_FROM, int(os.environ['VBX_AMD_THREE_LEVEL_FROM']))
         split = os.environ.get('VBX_AMD_SPLIT_TILES')     # 1 / 2: half-tile re-runs on / off (0: the library's choice)
         if split is not None:
             self.set_option(OPT_SPLIT_TILES, int(split))

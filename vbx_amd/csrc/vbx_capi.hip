@@ -180,7 +180,7 @@ struct vbx_batch {
     int *d_sopexp = nullptr, *d_sup_rec = nullptr, *d_sup_idx = nullptr;
     // third level of the walk (very long recordings): groups of sgroup2 groups
     int scan_group2 = 0;                          // option: 0 auto, 1 off, >= 2 groups per level-2 group
-    int three_level_from = 600;                   // chunks from which the automatic choice adds the third level
+    int three_level_from = 300;                   // chunks from which the automatic choice adds the third level
     int sgroup2 = 1, nsup2_total = 0;             // in effect
     void* d_sop2 = nullptr;
     int *d_sopexp2 = nullptr, *d_sup2_rec = nullptr, *d_sup2_idx = nullptr;
@@ -578,7 +578,8 @@ int choose_fb_algo(vbx_batch* b, bool step_api_logs) {
     }
     // Third level: with products worth ~4 walk steps the chain 4 (g - 1) + 4 (g2 - 1) + K / (g g2) + g2 + g is shortest
     // near g = g2 = (K / 8)^(1/3) rounded up: K = 1563 (T = 200 000): 7 x 7 -> 94 step equivalents against 173 on two
-    // levels; K = 391 (T = 50 000): 56 against 84, which the two extra launches nearly eat -- so only from 600 chunks.
+    // levels; K = 391 (T = 50 000): 56 against 84 -- measured walk 36.0 -> 33.7 us (fp64 47.8 -> 39.8), T = 70 000: 40.5 ->
+    // 36.9; K = 235 (T = 30 000): 28.9 -> 31.3, the two extra launches cost more than the shorter chain saves.  From 300.
     int group2 = 1;
     if (group > 1) {
         if (b->scan_group2 >= 2) group2 = b->scan_group2;
