@@ -139,3 +139,18 @@ def test_drop_in_module_exports_reference_names():
     assert (d['loopProb'], d['Fa'], d['Fb'], d['pi'], d['maxIters'], d['epsilon'], d['alphaQInit']) == \
         (0.9, 1.0, 1.0, 10, 10, 1e-4, 1.0)
     assert callable(mod.forward_backward) and callable(mod.DER)
+
+
+def test_sweep_api_host_side():
+    """VBx_sweep: argument handling before the device is touched (the GPU tests compare its results with VBx() calls)."""
+    from vbx_amd.batch import VBx_sweep
+    X = np.random.default_rng(0).standard_normal((12, 8))
+    Phi = np.ones(8)
+    g0 = np.full((12, 3), 1 / 3)
+    out = VBx_sweep(X, Phi, [dict(Fa=0.2), dict(Fa=0.4, Fb=6.0)], maxIters=0, pi=3, gamma=g0, return_model=True)
+    assert len(out) == 2 and all(len(t) == 5 and t[0] is g0 and t[2] == [] and t[3] is None for t in out)
+    assert VBx_sweep(X, Phi, [], maxIters=5) == []
+    with pytest.raises(TypeError, match='Fc'):
+        VBx_sweep(X, Phi, [dict(Fc=1.0)], maxIters=0, pi=3, gamma=g0)
+    with pytest.raises(AssertionError):                           # VBx.py:85 per point
+        VBx_sweep(X, Phi, [dict(pi=4)], maxIters=0, gamma=g0)
