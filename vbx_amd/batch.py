@@ -65,17 +65,27 @@ def _normalise(rec, defaults):
                 Fb=kw['Fb'], alpha=kw['alpha'], invL=kw['invL'])
 
 
+def _padded_states(n_states):
+    """The padded state count a vbx_batch of this many speakers runs with (vbx_capi.hip: powers of two from 16)."""
+    sp = 16
+    while sp < n_states:
+        sp *= 2
+    return sp
+
+
 def run_shard_hip(items, maxIters, epsilon, precision=None, device=None):
-    """Run normalised recordings on the local GPU, one vbx_batch per feature dimension.  ``precision=None`` is
-    VBx()'s rule (VBX_AMD_PRECISION, else fp32 only when every X of the batch is float32)."""
+    """Run normalised recordings on the local GPU, one vbx_batch per (feature dimension, padded state count): every
+    recording of a batch runs with the widest one's padding, and one recording with more than 64 speakers would push the
+    others from the fused kernels onto the wide scan.  ``precision=None`` is VBx()'s rule (VBX_AMD_PRECISION, else fp32
+    only when every X of the batch is float32)."""
     from . import _capi
     from .VBx import _pick_precision
     ctx = _capi.default_context(device)
     results = [None] * len(items)
     by_dim = {}
     for k, it in enumerate(items):
-        by_dim.setdefault(it['X'].shape[1], []).append(k)
-    for D, idx in by_dim.items():
+        by_dim.setdefault((it['X'].shape[1], _padded_states(len(it['pi']))), []).append(k)
+    for (D, _sp), idx in by_dim.items():
         prec = {_pick_precision(precision, items[k]['X']) for k in idx}
         batch = _capi.Batch(ctx, [items[k]['X'].shape[0] for k in idx], [len(items[k]['pi']) for k in idx], D,
                             precision='fp64' if 'fp64' in prec else prec.pop(), max_iters=maxIters)
