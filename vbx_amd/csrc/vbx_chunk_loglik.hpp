@@ -221,6 +221,7 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)si
                 if (two) build(1, x[1], expo[1]);
             }
         }
+        VBX_STAMP();                                       // (the operators are built and stored)
         if (!two) {                                        // P = P1
             if (builder && my_half == 0) {
 #pragma unroll
@@ -306,8 +307,8 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)si
     VBX_STAMP();
 #ifdef VBX_PHASE_CLOCKS
     if ((tile % 1000) == 1 && (lane == 0) && st.n_iters == 3)
-        printf("chunk_loglik wave %d: mfma %lld  epilogue %lld  wait %lld  operator %lld cycles\n", wave,
-               clk[1] - clk[0], clk[2] - clk[1], clk[3] - clk[2], clk[4] - clk[3]);
+        printf("chunk_loglik wave %d: mfma %lld  epilogue %lld  wait %lld  operators built %lld  composed / stored %lld cycles\n", wave,
+               clk[1] - clk[0], clk[2] - clk[1], clk[3] - clk[2], clk[4] - clk[3], clk[5] - clk[4]);
 #endif
 }
 
