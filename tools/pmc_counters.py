@@ -60,7 +60,15 @@ def main(path, out=None):
             a = d.get('SQ_ACTIVE_INST_ANY', [])
             act = (sum(a) / max(sum(w), 1.0)) if w and a else float('nan')
             util = busy / (1024 * us * 2400.0) if us > 0 else float('nan')
-            lines.append(f'{k:24s} mfma_busy_simd_cycles {busy:14.0f}   duration_us {us:9.2f}   mfma_util {util:7.4f}   active/wave_cycles {act:7.4f}')
+            line = f'{k:24s} mfma_busy_simd_cycles {busy:14.0f}   duration_us {us:9.2f}   mfma_util {util:7.4f}   active/wave_cycles {act:7.4f}'
+            va = d.get('SQ_ACTIVE_INST_VALU', [])
+            if va:
+                # SQ_ACTIVE_INST_* count quad-cycles (4 clocks) of a SIMD issuing that class; same rows-per-launch scaling
+                va = va[len(va) // 2:]
+                valu = (sum(va) / len(va)) * rows_per_launch * 4.0
+                vutil = valu / (1024 * us * 2400.0) if us > 0 else float('nan')
+                line += f'   valu_issue_simd_cycles {valu:14.0f}   valu_util {vutil:7.4f}   valu+mfma {vutil + util:7.4f}'
+            lines.append(line)
     text = '\n'.join(lines) + '\n'
     if out:
         open(out, 'w').write(text)

@@ -17,11 +17,14 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $out/trace -o trace -- $common >
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/fetch -o fetch -- $common > $out/fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/write -o write -- $common > $out/write.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY $SQ_EXTRA -d $out/sq -o sq -- $common > $out/sq.log 2>&1
+# (optional second SQ pass, SQ2="counter ...": what the SIMDs issue -- SQ_ACTIVE_INST_VALU / _LDS / _SCA beside the matrix pipes)
+[ -n "$SQ2" ] && timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES $SQ2 -d $out/sq2 -o sq2 -- $common > $out/sq2.log 2>&1
 [ -z "$NO_BENCH" ] && timeout 900 rocprofv3 --kernel-trace --stats -d $out/bench -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --cpu-iters 0 --no-f64 --no-single --no-configs $BENCH_ARGS > $out/bench.log 2>&1
 cd $GRAFT_REPO_ROOT
 python tools/rocpd_stats.py $out/trace/trace_results.db $out/kernel_stats.txt > /dev/null
 [ -z "$NO_BENCH" ] && python tools/rocpd_stats.py $out/bench/bench_results.db $out/bench_py_kernel_stats.txt > /dev/null
 python tools/pmc_counters.py $out/sq/sq_results.db $out/sq_counters.txt > /dev/null
+[ -n "$SQ2" ] && python tools/pmc_counters.py $out/sq2/sq2_results.db $out/sq2_counters.txt > /dev/null
 [ -z "$NO_BENCH" ] && tail -1 $out/bench.log > $out/bench_py_line.json
 # HBM bytes per launch, stamped with the workload profile_target.py printed and the commit the library was built from
 python tools/pmc_traffic.py $out/fetch/fetch_results.db $out/write/write_results.db $out/pmc_traffic.json $(grep '^workload ' $out/trace.log | cut -d' ' -f2-) > $out/pmc_traffic.txt 2>&1
