@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VBX_ABI_VERSION 4
+#define VBX_ABI_VERSION 5
 
 /* error codes */
 #define VBX_OK 0
@@ -75,6 +75,14 @@ extern "C" {
                                    1536 chunks, 2 from 12 and 768, else 1; env VBX_AMD_STREAMS overrides).  Before the
                                    first recording. */
 #define VBX_OPT_TWO_LEVEL_FROM 8 /* chunk count from which VBX_OPT_SCAN_GROUP = 0 picks the two-level walk           */
+#define VBX_OPT_GEMM 14         /* how the fp32 path multiplies rho alpha^T (VBx.py:97) and gamma^T rho (VBx.py:96):
+                                   VBX_GEMM_EXACT (default) v_mfma_f32_16x16x4_f32, the exact f32 product at the f32 vector
+                                   rate; VBX_GEMM_SPLIT v_mfma_f32_16x16x32_f16 on error-compensated f16 operand pairs
+                                   (x 2^e = hi + lo, three products, f32 accumulation: 2^-22 per product; rho kept in HBM
+                                   as such pairs in MFMA fragment order -- vbx_amd/csrc/vbx_split.hpp).  fp32 batches on
+                                   the fused kernels (S <= 64) only; ignored elsewhere.  env VBX_AMD_GEMM=exact|split   */
+#define VBX_GEMM_EXACT 0
+#define VBX_GEMM_SPLIT 1
 #define VBX_OPT_FUSE 5          /* per-chunk fused kernels when the lattices fit in LDS: 0 none, 1 chunk_post,
                                    2 (default) chunk_post + chunk_loglik.  On the fused path the responsibilities are
                                    written once, when vbx_batch_run returns (they are not needed between iterations) */
@@ -157,6 +165,9 @@ int vbx_batch_last_run_ms(vbx_batch* batch, double* total_ms, int* iters_launche
 int vbx_batch_kernel_times(vbx_batch* batch, double* ms, int64_t* launches);
 /* Number of HIP streams (sub-batches) this batch runs on: VBX_OPT_STREAMS in effect. */
 int vbx_batch_streams(const vbx_batch* b);
+/* VBX_GEMM_EXACT or VBX_GEMM_SPLIT: how the iterations of the last vbx_batch_run multiplied (VBX_OPT_GEMM asks, the
+ * batch's precision and kernels decide: fp64 batches, S > 64 and the unfused kernels always answer VBX_GEMM_EXACT). */
+int vbx_batch_gemm_in_effect(const vbx_batch* b);
 
 /* ---- one-shot: a single recording, host buffers in / out (= one reference VBx call) ---- */
 typedef struct {

@@ -13,6 +13,9 @@ pi, the ELBO history, alpha / invL in full (S x D) and gamma on 2000 fixed sampl
   config_c3.npz        C3: T=50 000, S=30, gamma=None (seed 1): after 2, 3 and 40 iterations
   config_c4.npz        C4: recordings 0, 31 and 63 of the 64-recording batch bench.py runs (T=10 000, S=30): 4 iterations
   config_c5.npz        C5: T=200 000, S=50, loopProb .9, sweep points (Fa, Fb) = (.3, 17) and (.2, 6): 2 iterations
+  config_c5sweep.npz   C5: all nine points Fa in {.2,.3,.4} x Fb in {6,17,64} (DIHARD2_run.sh:45-46, AMI_run.sh:47,
+                       CALLHOME_run.sh:45-46) after 2 iterations (gamma on 500 sampled rows), one process per point
+  config_c5stop.npz    C5: the point (.3, 17) run to the reference's own stop (maxIters=40, epsilon=1e-4)
 
 usage: make_golden_configs.py [c2 headline c3 c4 c5]      (no argument: all, one process per config)
 """
@@ -146,14 +149,64 @@ def c5(ref):
     return out
 
 
-CONFIGS = {'c2': c2, 'headline': headline, 'c3': c3, 'c4': c4, 'c5': c5}
+C5_GRID = [(fa, fb) for fa in (0.2, 0.3, 0.4) for fb in (6.0, 17.0, 64.0)]
+
+
+def c5_inputs(out):
+    T, S = 200000, 50
+    g0 = soft_init(T, S, 4)
+    X, Phi = inputs(out, 'c5', T, S, 3, 0.05, g0)
+    rows = sample_rows(T)[::4]                              # 500 of the 2000 rows of config_c5.npz
+    out['c5/rows'] = rows
+    return X, Phi, g0, rows, S
+
+
+def c5point(ref, k):
+    """One point of the nine-point sweep (its own process: 2 x 40 s of reference time each)."""
+    out = {}
+    X, Phi, g0, rows, S = c5_inputs(out)
+    fa, fb = C5_GRID[k]
+    tag = f'c5/fa{fa}_fb{fb:g}'
+    out[tag + '/hyper'] = np.asarray([0.9, fa, fb])
+    run_ref(ref, out, tag + '/it2', X, Phi, rows, loopProb=0.9, Fa=fa, Fb=fb, pi=S, gamma=g0, maxIters=2,
+            epsilon=-1e300)
+    return out
+
+
+def c5sweep(ref):
+    import subprocess
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), f'c5point{k}']) for k in range(len(C5_GRID))]
+    if max(p.wait() for p in procs):
+        raise SystemExit('a sweep point failed')
+    out = {}
+    for k in range(len(C5_GRID)):
+        part = os.path.join(HERE, f'config_c5point{k}.npz')
+        with np.load(part) as z:
+            out.update({key: z[key] for key in z.files})
+        os.remove(part)
+    return out
+
+
+def c5stop(ref):
+    out = {}
+    X, Phi, g0, rows, S = c5_inputs(out)
+    out['c5/fa0.3_fb17/hyper'] = np.asarray([0.9, 0.3, 17.0])
+    run_ref(ref, out, 'c5/fa0.3_fb17/stop', X, Phi, rows, loopProb=0.9, Fa=0.3, Fb=17.0, pi=S, gamma=g0, maxIters=40,
+            epsilon=1e-4)
+    return out
+
+
+CONFIGS = {'c2': c2, 'headline': headline, 'c3': c3, 'c4': c4, 'c5': c5, 'c5sweep': c5sweep, 'c5stop': c5stop}
+for _k in range(len(C5_GRID)):
+    CONFIGS[f'c5point{_k}'] = (lambda ref, k=_k: c5point(ref, k))
 
 
 def main():
     names = sys.argv[1:]
     if not names:
         import subprocess
-        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), n]) for n in CONFIGS]
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), n]) for n in CONFIGS
+                 if not n.startswith('c5point')]
         sys.exit(max(p.wait() for p in procs))
     ref = ref_module()
     for n in names:

@@ -55,7 +55,13 @@ def _worker(rank, world, port, outdir):
                                     run_shard=_oracle_shard, return_model=True, gather='all')
         np.random.seed(7)
         at_root = VBx_batch_distributed(_recordings(), maxIters=4, epsilon=-np.inf, Fa=0.3, Fb=17.0,
-                                        run_shard=_oracle_shard, return_model=True)       # default: one gather to rank 0
+                                        run_shard=_oracle_shard, return_model=True, gather='root')   # one gather to rank 0
+        np.random.seed(7)
+        default = VBx_batch_distributed(_recordings(), maxIters=4, epsilon=-np.inf, Fa=0.3, Fb=17.0,
+                                        run_shard=_oracle_shard, return_model=True)       # default (True): every rank, all
+        assert all(r is not None for r in default)
+        for x, y in zip(default, res):
+            assert all(np.array_equal(np.asarray(u), np.asarray(v)) for u, v in zip(x, y))
         np.random.seed(7)
         local_only = VBx_batch_distributed(_recordings(), maxIters=4, epsilon=-np.inf, Fa=0.3, Fb=17.0,
                                            run_shard=_oracle_shard, gather=False)

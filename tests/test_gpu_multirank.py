@@ -45,7 +45,8 @@ def _worker(rank, world, port, outdir):
     dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
     try:
         np.random.seed(11)                                      # gamma=None: the same draws on every rank
-        res = VBx_batch_distributed(_recordings(), maxIters=6, epsilon=1e-6, Fa=0.3, Fb=17.0, return_model=True)
+        res = VBx_batch_distributed(_recordings(), maxIters=6, epsilon=1e-6, Fa=0.3, Fb=17.0, return_model=True,
+                                    gather='root')
         have = [b for b, r in enumerate(res) if r is not None]
         np.savez(os.path.join(outdir, f'rank{rank}.npz'), have=np.array(have), lib=np.array(_capi.library_path()),
                  loaded=np.array(_capi._lib is not None),

@@ -182,6 +182,29 @@ def test_forward_backward_with_arbitrary_transition_matrices(fb_dense_cases, pre
     np.testing.assert_allclose(a[1], b[1], rtol=1e-11 if precision == 'fp64' else 1e-6)
 
 
+@pytest.mark.parametrize('precision,tol', [('fp64', 1e-9), ('fp32', 2e-5)])
+@pytest.mark.parametrize('S', [300, 640, 1100])
+def test_forward_backward_dense_with_more_than_256_states(precision, tol, S):
+    """The reference's helper takes any S (VBx.py:146-175): a dense Dirichlet transition matrix on more states than the
+    register-resident kernel holds goes through fb_dense_big_kernel (M in HBM) -- against the oracle's forward_backward
+    (round 3 dispatched 256 < S <= 1024 to the 256-state kernel and silently dropped the states above 256; S > 1024 was
+    refused)."""
+    import vbx_amd
+    r = np.random.default_rng(S)
+    T = 40
+    tr = r.dirichlet(np.full(S, 0.3), size=S)
+    ip = r.dirichlet(np.full(S, 1.0))
+    lls = 3.0 * r.standard_normal((T, S)) - 40.0 * r.random((T, 1))
+    post, tll, lfw, lbw = vbx_amd.forward_backward(lls, tr, ip, precision=precision)
+    ref = _orc().forward_backward(lls, tr, ip)
+    assert post.shape == (T, S)
+    np.testing.assert_allclose(post, ref[0], rtol=0, atol=tol)
+    np.testing.assert_allclose(tll, ref[1], rtol=1e-11 if precision == 'fp64' else 1e-6)
+    np.testing.assert_allclose(lfw, ref[2], rtol=0, atol=(1e-9 if precision == 'fp64' else 2e-5) * np.abs(ref[2]).max())
+    np.testing.assert_allclose(lbw, ref[3], rtol=0, atol=(1e-9 if precision == 'fp64' else 2e-5) * max(1.0, np.abs(ref[3]).max()))
+    np.testing.assert_allclose(post.sum(1), 1.0, atol=1e-6)
+
+
 # ------------------------------------------------------------------------------------ VBx()
 def run_case(c, precision):
     import vbx_amd

@@ -9,8 +9,8 @@ import sys
 import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NAME = 'void vbx::chunk_post_kernel<float, 32, false>(vbx::BatchView<float>)'
-REPLAY = 'void vbx::chunk_post_kernel<float, 32, true>(vbx::BatchView<float>)'
+NAME = 'void vbx::chunk_post_kernel<float, 32, false, true>(vbx::BatchView<float>)'
+REPLAY = 'void vbx::chunk_post_kernel<float, 32, true, false>(vbx::BatchView<float>)'
 OTHER = 'void vbx::scan2_kernel<float, 32>(vbx::BatchView<float>, int)'
 
 
@@ -49,7 +49,7 @@ def test_kernel_stats_and_pmc_tools(tmp_path):
     assert doc['iteration_hbm_bytes'] == k['hbm_bytes_per_launch'] + doc['kernels']['scan2']['hbm_bytes_per_launch']
     stats = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'rocpd_stats.py'), fetch], check=True,
                            capture_output=True, text=True).stdout
-    row = [line for line in stats.splitlines() if line.startswith('chunk_post_kernel<float, 32, false>')][0].split()
+    row = [line for line in stats.splitlines() if line.startswith('chunk_post_kernel<float, 32, false')][0].split()
     assert row[-6:-1] == ['4', '800.0', '200.00', '200.00', '200.00']          # calls, total, avg, min, max (us)
     txt = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'pmc_counters.py'), sq], check=True,
                          capture_output=True, text=True).stdout
@@ -72,9 +72,13 @@ def test_chunk_kernels_keep_their_register_and_lds_budget():
         name, rest = line[:58].strip(), line[58:].split()
         if len(rest) == 6:
             rows[name] = dict(zip(('vgpr', 'agpr', 'spill', 'scratch', 'occ', 'lds'), map(int, rest)))
-    post, loglik = rows['chunk_post_kernel<float, 32, false>'], rows['chunk_loglik_kernel<float, 32>']
+    post, loglik = rows['chunk_post_kernel<float, 32, false, false>'], rows['chunk_loglik_kernel<float, 32, false>']
     assert post['spill'] == 0 and post['scratch'] == 0 and post['occ'] >= 4 and post['lds'] <= 40 * 1024, post
     assert loglik['spill'] == 0 and loglik['scratch'] == 0 and loglik['occ'] >= 8 and loglik['lds'] <= 20 * 1024, loglik
+    # the instances with the GEMMs on f16 operand pairs (vbx_split.hpp)
+    post, loglik = rows['chunk_post_kernel<float, 32, false, true>'], rows['chunk_loglik_kernel<float, 32, true>']
+    assert post['spill'] == 0 and post['scratch'] == 0 and post['occ'] >= 4 and post['lds'] <= 40 * 1024, post
+    assert loglik['spill'] == 0 and loglik['scratch'] == 0 and loglik['occ'] >= 7 and loglik['lds'] <= 20 * 1024, loglik
     for name, r in rows.items():
         if 'double' not in name and ', 16' not in name:
             assert r['scratch'] == 0, (name, r)

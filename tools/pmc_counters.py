@@ -15,8 +15,9 @@ def short(name):
     m = re.search(r'vbx::(\w+?)(?:_kernel)?<([^>]*)>', name)
     if not m:
         return name[:40]
-    # the gamma write-out is an instance of chunk_post_kernel (<R, SP, true>) but not part of an iteration
-    return 'chunk_post_replay' if m.group(1) == 'chunk_post' and m.group(2).rstrip().endswith('true') else m.group(1)
+    # the gamma write-out is an instance of chunk_post_kernel (<R, SP, REPLAY = true, SPLIT>) but not part of an iteration
+    args = [a.strip() for a in m.group(2).split(',')]
+    return 'chunk_post_replay' if m.group(1) == 'chunk_post' and len(args) >= 3 and args[2] == 'true' else m.group(1)
 
 
 def main(path, out=None):

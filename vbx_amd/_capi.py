@@ -15,6 +15,8 @@ PREC_FP32, PREC_FP64 = 0, 1
 FB_AUTO, FB_SEQUENTIAL, FB_CHUNKED = 0, 1, 2
 OPT_FB_ALGO, OPT_CHECK_EVERY, OPT_PROFILE, OPT_CHUNK_FRAMES, OPT_FUSE, OPT_SCAN_GROUP = 1, 2, 3, 4, 5, 6
 OPT_TWO_LEVEL_FROM, OPT_STREAMS, OPT_SPLIT_TILES, OPT_SCAN_GROUP2, OPT_THREE_LEVEL_FROM = 8, 10, 11, 12, 13
+OPT_GEMM = 14                # how the fp32 path multiplies: GEMM_EXACT (f32 MFMA) | GEMM_SPLIT (f16 operand pairs, vbx_split.hpp)
+GEMM_EXACT, GEMM_SPLIT = 0, 1
 K_NAMES = ['prep', 'mstep_acc', 'mstep_fin', 'loglik', 'fb', 'fb_aux', 'post', 'iter_fin', 'chunk_loglik',
            'chunk_post']
 MAX_SPEAKERS = 1024
@@ -30,6 +32,7 @@ ABI_SYMBOLS = [
     'vbx_scores_destroy',
     'vbx_xvectors_project', 'vbx_xvectors_get', 'vbx_xvectors_destroy', 'vbx_cos_similarity_resident',
     'vbx_batch_set_recording_resident', 'vbx_batch_get_labels', 'vbx_batch_set_recording_shared',
+    'vbx_batch_gemm_in_effect',
 ]
 
 
@@ -78,6 +81,7 @@ def load():
     lib.vbx_batch_last_run_ms.argtypes = [vp, C.POINTER(dbl), C.POINTER(C.c_int)]
     lib.vbx_batch_kernel_times.argtypes = [vp, vp, vp]
     lib.vbx_batch_streams.argtypes = [vp]
+    lib.vbx_batch_gemm_in_effect.argtypes = [vp]
     lib.vbx_run.argtypes = [vp, vp, vp]
     lib.vbx_forward_backward.argtypes = [vp, i64, i32, vp, vp, vp, dbl, C.c_int, C.c_int, vp, C.POINTER(dbl),
                                          vp, vp, vp]
@@ -123,8 +127,11 @@ def _f64(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
 
 
+SPLIT_NAMES = ('fp32-split', 'fp32s', 'f32-split')       # fp32 storage, the two GEMMs on f16 operand pairs (VBX_OPT_GEMM)
+
+
 def precision_code(precision) -> int:
-    if precision in (PREC_FP32, 'fp32', 'f32', 'float32', np.float32):
+    if precision in (PREC_FP32, 'fp32', 'f32', 'float32', np.float32) or precision in SPLIT_NAMES:
         return PREC_FP32
     if precision in (PREC_FP64, 'fp64', 'f64', 'float64', np.float64):
         return PREC_FP64
@@ -371,6 +378,11 @@ class Batch:
         split = os.environ.get('VBX_AMD_SPLIT_TILES')     # 1 / 2: half-tile re-runs on / off (0: the library's choice)
         if split is not None:
             self.set_option(OPT_SPLIT_TILES, int(split))
+        gemm = os.environ.get('VBX_AMD_GEMM')             # 'exact' | 'split' (VBX_OPT_GEMM)
+        if isinstance(precision, str) and precision in SPLIT_NAMES:
+            gemm = 'split'
+        if gemm:
+            self.set_option(OPT_GEMM, {'exact': GEMM_EXACT, 'split': GEMM_SPLIT}[gemm])
         fuse = os.environ.get('VBX_AMD_FUSE')             # '0' keeps every stage in its own kernel
         if fuse is not None:
             self.set_option(OPT_FUSE, int(fuse))
@@ -452,6 +464,12 @@ class Batch:
     def streams(self) -> int:
         """HIP streams (sub-batches) this batch runs on (VBX_OPT_STREAMS in effect)."""
         return int(self._lib.vbx_batch_streams(self._h))
+
+    @property
+    def gemm(self) -> str:
+        """'split' when the iterations of the last run multiplied with f16 operand pairs (VBX_OPT_GEMM in effect), else
+        'exact'."""
+        return 'split' if int(self._lib.vbx_batch_gemm_in_effect(self._h)) == GEMM_SPLIT else 'exact'
 
     def kernel_times(self):
         ms = np.zeros(len(K_NAMES))

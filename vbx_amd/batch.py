@@ -166,8 +166,8 @@ def VBx_sweep(X, Phi, points, maxIters=10, epsilon=1e-4, precision=None, device=
     return [_as_tuple(r, return_model) for r in raw]
 
 
-def _as_tuple(res, return_model):
-    if res['warned']:
+def _as_tuple(res, return_model, warn=True):
+    if res['warned'] and warn:
         print('WARNING: Value of auxiliary function has decreased!')       # VBx.py:123-124
     out = (res['gamma'], res['pi'], [[np.float64(e)] for e in res['Li']])
     if return_model:
@@ -182,12 +182,16 @@ def VBx_batch_distributed(recordings, maxIters=10, epsilon=1e-4, precision=None,
     Every rank passes the same list; rank r computes the recordings assigned to it (LPT on T x S) on its own GPU.  There
     is no collective on the data path; what happens to the RESULTS afterwards is the caller's choice:
 
-      gather=True / 'root'   one ``gather_object`` to rank 0, which returns the complete list; every other rank returns
-                             its own results and ``None`` for the rest (the responsibilities are the bulk: 8 T S bytes per
-                             recording -- 2.4 MB at T = 10 000, S = 30, 19 MB per rank and 154 MB at rank 0 for BASELINE
-                             config 4 -- so they travel once, to the rank that writes them out)
-      gather='all'           ``all_gather_object``: every rank returns the complete list (world x as many bytes)
+      gather=True / 'all'    ``all_gather_object``: every rank returns the complete list (the behaviour ``True`` has always
+                             had; world x the bytes of the responsibilities: 8 T S per recording -- 2.4 MB at T = 10 000,
+                             S = 30, 154 MB per rank for BASELINE config 4)
+      gather='root'          one ``gather_object`` to rank 0, which returns the complete list; every other rank returns
+                             its own results and ``None`` for the rest -- the responsibilities travel once, to the rank
+                             that writes them out (what ``vbx_amd.vbhmm`` and ``bench.py`` want)
       gather=False           nothing is exchanged: every rank returns its own results, ``None`` elsewhere
+
+    The reference's 'auxiliary function has decreased' warning (VBx.py:123-124) is printed by the rank that ran the
+    recording, once.
 
     ``run_shard(items, maxIters, epsilon)`` defaults to the HIP path; the CPU test-suite injects the oracle here."""
     import torch.distributed as dist
@@ -206,7 +210,7 @@ def VBx_batch_distributed(recordings, maxIters=10, epsilon=1e-4, precision=None,
         raise ValueError(f"gather={gather!r}: expected True / 'root', 'all' or False")
     merged = dict(local)
     if gather and world > 1:
-        if gather == 'all':
+        if gather in (True, 'all'):
             parts = [None] * world
             dist.all_gather_object(parts, local)
         else:
@@ -214,4 +218,4 @@ def VBx_batch_distributed(recordings, maxIters=10, epsilon=1e-4, precision=None,
             dist.gather_object(local, parts, dst=0)
         for p in parts or []:
             merged.update(p)
-    return [(_as_tuple(merged[b], return_model) if b in merged else None) for b in range(len(items))]
+    return [(_as_tuple(merged[b], return_model, warn=b in local) if b in merged else None) for b in range(len(items))]

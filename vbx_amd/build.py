@@ -13,14 +13,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.environ.get('VBX_AMD_LIB') or os.path.join(CSRC, 'libvbx_hip.so')   # (VBX_AMD_LIB: an experiment build, tools/build_variants.sh)
 SOURCES = ['vbx_capi.hip']
-HEADERS = ['vbx_device.hpp', 'vbx_kernels.hpp', 'vbx_scan.hpp', 'vbx_scan_wide.hpp', 'vbx_fb_dense.hpp', 'vbx_operator.hpp', 'vbx_chunk_loglik.hpp', 'vbx_chunk_post.hpp', 'vbx_linkage.hpp', 'vbx_ahc.hpp', 'vbx_frontend.hpp', os.path.join('..', '..', 'include', 'vbx_hip.h')]
+HEADERS = ['vbx_device.hpp', 'vbx_kernels.hpp', 'vbx_scan.hpp', 'vbx_scan_wide.hpp', 'vbx_fb_dense.hpp', 'vbx_operator.hpp', 'vbx_split.hpp', 'vbx_chunk_loglik.hpp', 'vbx_chunk_post.hpp', 'vbx_linkage.hpp', 'vbx_ahc.hpp', 'vbx_frontend.hpp', os.path.join('..', '..', 'include', 'vbx_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-Wno-pass-failed']
 
 
 # the sources that decide what the kernels of an EM iteration do and move: profiles/*_pmc_traffic.json carries their
 # hash, and bench.py only quotes a PMC figure whose hash matches the tree it runs from
 ITERATION_SOURCES = ['vbx_capi.hip', 'vbx_device.hpp', 'vbx_kernels.hpp', 'vbx_scan.hpp', 'vbx_operator.hpp',
-                     'vbx_chunk_loglik.hpp', 'vbx_chunk_post.hpp']
+                     'vbx_split.hpp', 'vbx_chunk_loglik.hpp', 'vbx_chunk_post.hpp']
 
 
 def iteration_source_hash() -> str:

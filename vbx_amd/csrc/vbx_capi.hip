@@ -132,6 +132,11 @@ struct vbx_batch {
     // options
     int fb_algo = VBX_FB_AUTO, check_every = 4, chunk_frames = 0, fuse = 2;
     int split_tiles = 0;                          // option: 0 auto, 1 on, 2 off (VBX_OPT_SPLIT_TILES)
+    int gemm = VBX_GEMM_EXACT;                    // option VBX_OPT_GEMM: how the fp32 path multiplies (vbx_split.hpp)
+    bool split_now = false;                       // in effect for the launches being issued: f16 operand pairs
+    std::vector<char> split_dirty;                // recording -> its rho has changed since its f16 copies were made
+    void *d_rho_a = nullptr, *d_rho_b = nullptr, *d_alpha_frag = nullptr;
+    int *d_rho_e = nullptr, *d_rho_amax = nullptr, *d_alpha_e = nullptr;
     int64_t profile = 0;                          // bit k: bracket launches of kernel class k with HIP events
     bool mpart_valid = false;                     // mpart/npart hold gamma^T rho of the current gamma (fused path)
     bool gamma_stale = false;                     // fused iterations have run since gamma was last written (run_end replays)
@@ -218,6 +223,9 @@ struct vbx_batch {
         v.sop2 = (R*)d_sop2; v.sopexp2 = d_sopexp2; v.sup2_rec = d_sup2_rec; v.sup2_idx = d_sup2_idx;
         v.sgroup2 = sgroup2; v.nsup2_total = nsup2_total;
         v.gamma0 = fused_now ? (R*)d_gamma0 : nullptr; v.pi_prev = d_pi_prev;
+        const bool sp = split_now && fused_now;
+        v.rho_a = sp ? (const _Float16*)d_rho_a : nullptr; v.rho_b = sp ? (const _Float16*)d_rho_b : nullptr;
+        v.rho_e = sp ? d_rho_e : nullptr; v.alpha_frag = sp ? (_Float16*)d_alpha_frag : nullptr; v.alpha_e = sp ? d_alpha_e : nullptr;
         return v;
     }
 };
@@ -245,6 +253,12 @@ struct LaunchScope {   // brackets one kernel launch with events when profiling 
         if (ep) (void)hipEventRecord(ep->b, b->ctx->stream);
     }
 };
+
+// (debugging aid: VBX_AMD_SPLIT_MASK = 1 / 2 keeps the split GEMM to chunk_loglik / chunk_post only)
+static int split_debug_mask() {
+    static const int m = [] { const char* e = std::getenv("VBX_AMD_SPLIT_MASK"); return e ? atoi(e) : 3; }();
+    return m;
+}
 
 #define NT_SWITCH(nt_, BODY)                                   \
     switch (nt_) {                                             \
@@ -302,8 +316,15 @@ static int small_kernel_threads(const vbx_batch* b, int from_tiles) {
 
 // chunk_post over the tiles of the batch; REPLAY: the instance that only writes the responsibilities
 template <typename R, int SP, bool REPLAY> void launch_chunk_post(vbx_batch* b, const BatchView<R>& v) {
-    if constexpr (ChunkPostCfg<R, SP>::kFits)
+    if constexpr (ChunkPostCfg<R, SP>::kFits) {
+        if constexpr (std::is_same<R, float>::value && !REPLAY) {
+            if (v.rho_b && (split_debug_mask() & 2)) {       // gamma^T rho on the f16 matrix cores (vbx_split.hpp)
+                hipLaunchKernelGGL((chunk_post_kernel<R, SP, false, true>), dim3(b->nblocks_chunk), dim3(256), 0, b->ctx->stream, v);
+                return;
+            }
+        }
         hipLaunchKernelGGL((chunk_post_kernel<R, SP, REPLAY>), dim3(b->nblocks_chunk), dim3(256), 0, b->ctx->stream, v);
+    }
 }
 
 template <typename R, int SP> void launch_scan(vbx_batch* b, const BatchView<R>& v, bool fused_post, bool fused_loglik) {
@@ -312,7 +333,14 @@ template <typename R, int SP> void launch_scan(vbx_batch* b, const BatchView<R>&
     if constexpr (ChunkLoglikCfg<R, SP>::kFits) {
         if (fused_loglik) {      // log-likelihoods and the chunk operators in one pass over rho
             LaunchScope ls(b, VBX_K_CHUNK_LOGLIK);
-            hipLaunchKernelGGL((chunk_loglik_kernel<R, SP>), dim3(b->nblocks_chunk), dim3(256), 0, st, v);
+            bool launched = false;
+            if constexpr (std::is_same<R, float>::value) {
+                if (v.rho_a && (split_debug_mask() & 1)) {   // rho alpha^T on the f16 matrix cores (vbx_split.hpp)
+                    hipLaunchKernelGGL((chunk_loglik_kernel<R, SP, true>), dim3(b->nblocks_chunk), dim3(256), 0, st, v);
+                    launched = true;
+                }
+            }
+            if (!launched) hipLaunchKernelGGL((chunk_loglik_kernel<R, SP>), dim3(b->nblocks_chunk), dim3(256), 0, st, v);
             have_op = true;
         }
     }
@@ -427,8 +455,15 @@ template <typename R> void launch_post(vbx_batch* b, double eps) {
     }
 }
 
+// Can this batch multiply with f16 operand pairs (VBX_OPT_GEMM = split)?  fp32, both fused per-chunk kernels.
+static bool split_available(const vbx_batch* b) {
+    return b->gemm == VBX_GEMM_SPLIT && b->precision == VBX_PREC_FP32 && b->Dp <= kSplitMaxDp &&
+           fused_available<float>(b) && fused_loglik_available<float>(b);
+}
+
 template <typename R> void launch_iteration(vbx_batch* b, double eps) {
     b->fused_now = fused_available<R>(b);
+    b->split_now = b->d_rho_a != nullptr && split_available(b);
     // the previous iteration of this run (if any) is finished by the launch that starts this one; the last one of a run
     // by run_end
     const int fin_mode = b->fin_pending ? 3 : 1;
@@ -466,8 +501,22 @@ void launch_prep(vbx_batch* b, const RecDesc& rd) {
                        b->D, b->Dp);
 }
 
-// A block of at least `bytes` bytes: the smallest spare one that fits (and is at most twice too large), else a new one.
+// (debugging aid: VBX_AMD_POISON=1 fills every block handed out with 0xFF bytes -- NaNs in every floating-point type -- so
+//  that a read of memory nobody wrote shows up in the results instead of depending on what the block held before)
+static int ctx_alloc_raw(vbx_ctx* ctx, void** p, size_t bytes);
 int ctx_alloc(vbx_ctx* ctx, void** p, size_t bytes) {
+    static const bool poison = [] { const char* e = std::getenv("VBX_AMD_POISON"); return e && e[0] == '1'; }();
+    const int rc = ctx_alloc_raw(ctx, p, bytes);
+    if (rc == VBX_OK && poison) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipMemset(*p, 0xFF, std::max<size_t>(bytes, 16)));
+        HIPCHK(ctx, hipDeviceSynchronize());
+    }
+    return rc;
+}
+
+// A block of at least `bytes` bytes: the smallest spare one that fits (and is at most twice too large), else a new one.
+static int ctx_alloc_raw(vbx_ctx* ctx, void** p, size_t bytes) {
     std::lock_guard<std::mutex> lock(ctx->alloc_mutex);
     bytes = std::max<size_t>(bytes, 16);
     if (ctx->recycle) {
@@ -791,7 +840,8 @@ static int leaf_destroy(vbx_batch* b) {
                     b->d_xstage, b->d_ip, b->d_fw_scale, b->d_bw_scale, b->d_op, b->d_fbound, b->d_gbound,
                     b->d_opexp, b->d_tllpart, b->d_sfw, b->d_dump, b->d_sop, b->d_sopexp, b->d_sup_rec, b->d_sup_idx,
                     b->d_sop2, b->d_sopexp2, b->d_sup2_rec, b->d_sup2_idx,
-                    b->d_gamma0, b->d_pi_prev, b->d_oph, b->d_ophexp, b->d_cop, b->d_lppow, b->d_tile_order};
+                    b->d_gamma0, b->d_pi_prev, b->d_oph, b->d_ophexp, b->d_cop, b->d_lppow, b->d_tile_order,
+                    b->d_rho_a, b->d_rho_b, b->d_alpha_frag, b->d_rho_e, b->d_rho_amax, b->d_alpha_e};
     (void)hipStreamSynchronize(b->ctx->stream);               // nothing of this batch may still be running when its
     for (void* p : ptrs) ctx_free(b->ctx, p);                 // blocks go back to the spare list
     if (b->ev_start) (void)hipEventDestroy(b->ev_start);
@@ -833,6 +883,7 @@ static int leaf_create(vbx_ctx* ctx, int n_rec, const int64_t* T, const int32_t*
     b->max_iters = max_iters;
     b->recs.resize(n_rec);
     b->is_set.assign(n_rec, 0);
+    b->split_dirty.assign(n_rec, 1);
     std::vector<int> tile_rec, tile_t0;
     long long row = 0;
     long long maxT = 0;
@@ -842,7 +893,8 @@ static int leaf_create(vbx_ctx* ctx, int n_rec, const int64_t* T, const int32_t*
         rd.row0 = rd.rho_row0 = row;
         rd.T = (int)T[i];
         rd.S = S[i];
-        rd.tile0 = (int)tile_rec.size();
+        rd.tile0 = rd.rho_tile0 = (int)tile_rec.size();
+        rd.rho_rec = i;
         rd.ntiles = (rd.T + kTileFrames - 1) / kTileFrames;
         for (int tl = 0; tl < rd.ntiles; ++tl) {
             tile_rec.push_back(i);
@@ -960,6 +1012,10 @@ static int leaf_set_option(vbx_batch* b, int option, int64_t value) {
         case VBX_OPT_CHUNK_FRAMES:
             if (value < 0) FAIL(b->ctx, VBX_ERR_INVALID, "chunk_frames must be >= 0");
             b->chunk_frames = (int)value;
+            return VBX_OK;
+        case VBX_OPT_GEMM:
+            if (value != VBX_GEMM_EXACT && value != VBX_GEMM_SPLIT) FAIL(b->ctx, VBX_ERR_INVALID, "VBX_OPT_GEMM takes VBX_GEMM_EXACT or VBX_GEMM_SPLIT");
+            b->gemm = (int)value;
             return VBX_OK;
         default: FAIL(b->ctx, VBX_ERR_INVALID, "unknown option %d", option);
     }
@@ -1154,12 +1210,17 @@ static void own_rho(vbx_batch* b, int rec) {
         if (i != rec && b->share_src[i] == rec) {
             b->share_src[i] = i;
             b->recs[i].rho_row0 = b->recs[i].row0;
+            b->recs[i].rho_tile0 = b->recs[i].tile0;
+            b->recs[i].rho_rec = i;
             b->is_set[i] = 0;
             b->order_dirty = true;
         }
     if (b->share_src[rec] != rec) b->order_dirty = true;
     b->share_src[rec] = rec;
     b->recs[rec].rho_row0 = b->recs[rec].row0;
+    b->recs[rec].rho_tile0 = b->recs[rec].tile0;
+    b->recs[rec].rho_rec = rec;
+    b->split_dirty[rec] = 1;                                  // (every caller is about to give `rec` new x-vectors)
 }
 
 static int leaf_set_recording(vbx_batch* b, int rec, const void* X, int x_dtype, const double* Phi, const double* pi0,
@@ -1206,6 +1267,10 @@ static int leaf_set_recording_shared(vbx_batch* b, int rec, int src, const doubl
     if ((alpha0 == nullptr) != (invL0 == nullptr)) { alpha0 = nullptr; invL0 = nullptr; }
     if (!(loopProb >= 0.0 && loopProb <= 1.0)) FAIL(ctx, VBX_ERR_INVALID, "loopProb=%g outside [0,1]", loopProb);
     if (!(Fa > 0.0) || !(Fb > 0.0)) FAIL(ctx, VBX_ERR_INVALID, "Fa and Fb must be positive");
+    // (a source that reads the rows of `rec` itself would be unset by own_rho below and leave `rec` pointing at rows that
+    //  hold nothing: round-3 advisor finding)
+    if (b->share_src[src] == rec)
+        FAIL(ctx, VBX_ERR_STATE, "recording %d reads the x-vectors of recording %d: it cannot be that recording's source", src, rec);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     own_rho(b, rec);                                          // (whoever shared with `rec` must be set again)
     const int owner = b->share_src[src];                      // a source that shares itself: its owner
@@ -1214,6 +1279,8 @@ static int leaf_set_recording_shared(vbx_batch* b, int rec, int src, const doubl
     rd.Fa = Fa;
     rd.Fb = Fb;
     rd.rho_row0 = b->recs[owner].row0;
+    rd.rho_tile0 = b->recs[owner].tile0;
+    rd.rho_rec = owner;
     b->share_src[rec] = owner;
     b->order_dirty = true;
     // the rows of rho this recording leaves unused lie behind another recording's: the last chunk of that one reads a whole
@@ -1230,6 +1297,43 @@ static int leaf_set_recording_shared(vbx_batch* b, int rec, int src, const doubl
     return VBX_OK;
 }
 
+// VBX_OPT_GEMM = split: the f16 copies of rho (vbx_split.hpp) of every recording whose x-vectors have changed since they
+// were made -- largest magnitude, power-of-two scale, then the two fragment-ordered copies; the recordings that share a
+// rho read their owner's tiles and scale (RecDesc::rho_tile0 / rho_rec).
+static int prepare_split(vbx_batch* b) {
+    if (!split_available(b)) return VBX_OK;
+    vbx_ctx* ctx = b->ctx;
+    if (!b->d_rho_a) {
+        const size_t tile_bytes = (size_t)kTileFrames * b->Dp * 4;
+        int rc = dmalloc_bytes(ctx, &b->d_rho_a, (size_t)b->ntiles_total * tile_bytes);
+        if (rc == VBX_OK) rc = dmalloc_bytes(ctx, &b->d_rho_b, (size_t)b->ntiles_total * tile_bytes);
+        if (rc == VBX_OK) rc = dmalloc_bytes(ctx, &b->d_alpha_frag, (size_t)2 * b->n_rec * b->Sp * b->Dp * 4);
+        if (rc == VBX_OK) rc = dmalloc(ctx, &b->d_rho_e, (size_t)b->n_rec);
+        if (rc == VBX_OK) rc = dmalloc(ctx, &b->d_rho_amax, (size_t)b->n_rec);
+        if (rc == VBX_OK) rc = dmalloc(ctx, &b->d_alpha_e, (size_t)2 * b->n_rec * b->Sp);
+        if (rc != VBX_OK) return rc;
+        HIPCHK(ctx, hipMemsetAsync(b->d_alpha_frag, 0, (size_t)2 * b->n_rec * b->Sp * b->Dp * 4, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(b->d_alpha_e, 0, sizeof(int) * 2 * b->n_rec * b->Sp, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(b->d_rho_e, 0, sizeof(int) * b->n_rec, ctx->stream));
+        b->split_dirty.assign(b->n_rec, 1);
+    }
+    const size_t tile_halfs = (size_t)kTileFrames * b->Dp * 2;
+    for (int i = 0; i < b->n_rec; ++i) {
+        if (b->share_src[i] != i || !b->split_dirty[i]) continue;
+        const RecDesc& rd = b->recs[i];
+        const float* rho = (const float*)b->d_rho + rd.row0 * b->Dp;
+        HIPCHK(ctx, hipMemsetAsync(b->d_rho_amax + i, 0, sizeof(int), ctx->stream));
+        LaunchScope ls(b, VBX_K_PREP);
+        hipLaunchKernelGGL(rho_absmax_kernel, dim3(rd.ntiles), dim3(256), 0, ctx->stream, rho, rd.T, b->Dp, b->d_rho_amax + i);
+        hipLaunchKernelGGL(rho_split_kernel, dim3(rd.ntiles), dim3(256), 0, ctx->stream, rho, rd.T, b->Dp,
+                           (const int*)(b->d_rho_amax + i), b->d_rho_e + i, (_Float16*)b->d_rho_a + (size_t)rd.tile0 * tile_halfs,
+                           (_Float16*)b->d_rho_b + (size_t)rd.tile0 * tile_halfs);
+        b->split_dirty[i] = 0;
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return VBX_OK;
+}
+
 // One run = begin (checks, tables, start event) -> max_iters x { launch one iteration; now and then look at the
 // convergence flags } -> end (stop event, wait, timings).  Split so that a stream group can interleave its kids.
 static int run_begin(vbx_batch* b, int max_iters) {
@@ -1241,6 +1345,8 @@ static int run_begin(vbx_batch* b, int max_iters) {
     int rc = choose_fb_algo(b, false);
     if (rc != VBX_OK) return rc;
     rc = upload_recs(b);
+    if (rc != VBX_OK) return rc;
+    rc = prepare_split(b);
     if (rc != VBX_OK) return rc;
     std::fill(b->k_ms, b->k_ms + VBX_K_COUNT, 0.0);
     std::fill(b->k_launches, b->k_launches + VBX_K_COUNT, 0);
@@ -1695,6 +1801,12 @@ int vbx_batch_last_run_ms(vbx_batch* b, double* total_ms, int* iters_launched) {
 
 int vbx_batch_streams(const vbx_batch* b) { return !b ? 0 : b->kids.empty() ? 1 : (int)b->kids.size(); }
 
+int vbx_batch_gemm_in_effect(const vbx_batch* b) {
+    if (!b) return VBX_GEMM_EXACT;
+    const vbx_batch* leaf = b->kids.empty() ? b : b->kids[0];
+    return leaf->split_now ? VBX_GEMM_SPLIT : VBX_GEMM_EXACT;
+}
+
 int vbx_batch_kernel_times(vbx_batch* b, double* ms, int64_t* launches) {
     if (!b) return VBX_ERR_INVALID;
     if (b->kids.empty()) return leaf_kernel_times(b, ms, launches);
@@ -1858,7 +1970,8 @@ template <typename R>
 int fb_dense_impl(vbx_ctx* ctx, int64_t T, int32_t S, const double* lls, const double* tr, const double* ip, double* gamma,
                   double* tll, double* lfw, double* lbw) {
     int Sp = 16;
-    while (Sp < S) Sp *= 2;
+    while (Sp < S && Sp < 256) Sp *= 2;
+    if (S > 256) Sp = round_up(S, 64);                               // fb_dense_big_kernel: M in HBM, any S
     const size_t cells = (size_t)T * Sp;
     std::vector<R> bm(cells, (R)0), m0((size_t)Sp * Sp, (R)0), m1((size_t)Sp * Sp, (R)0), v0(Sp, (R)0);
     std::vector<double> mr((size_t)T);
@@ -1902,7 +2015,11 @@ int fb_dense_impl(vbx_ctx* ctx, int64_t T, int32_t S, const double* lls, const d
             case 32: VBX_FB_DENSE(32); break;
             case 64: VBX_FB_DENSE(64); break;
             case 128: VBX_FB_DENSE(128); break;
-            default: VBX_FB_DENSE(256); break;
+            case 256: VBX_FB_DENSE(256); break;
+            default:      // more than 256 states (the register-resident kernel would drop them: round-3 advisor finding)
+                hipLaunchKernelGGL((fb_dense_big_kernel<R>), dim3(2), dim3(1024), 0, st, d_m0, d_m1, d_b, d_v0, d_ah, d_bh,
+                                   d_fs, d_bs, (int)T, (int)S, Sp);
+                break;
         }
 #undef VBX_FB_DENSE
         e = hipGetLastError();
@@ -1946,7 +2063,7 @@ int vbx_forward_backward_dense(vbx_ctx* ctx, int64_t T, int32_t S, const double*
                                int precision, double* gamma, double* tll, double* lfw, double* lbw) {
     if (!ctx) return VBX_ERR_INVALID;
     if (!lls || !tr || !ip || T <= 0 || S <= 0) FAIL(ctx, VBX_ERR_INVALID, "vbx_forward_backward_dense: bad argument");
-    if (S > VBX_MAX_SPEAKERS) FAIL(ctx, VBX_ERR_UNSUPPORTED, "S=%d exceeds VBX_MAX_SPEAKERS=%d", S, VBX_MAX_SPEAKERS);
+    if (S > vbx::kFbDenseBigMax) FAIL(ctx, VBX_ERR_UNSUPPORTED, "forward_backward (dense): S=%d exceeds %d states", S, vbx::kFbDenseBigMax);
     if (precision != VBX_PREC_FP32 && precision != VBX_PREC_FP64) FAIL(ctx, VBX_ERR_INVALID, "unknown precision %d", precision);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     return precision == VBX_PREC_FP64 ? fb_dense_impl<double>(ctx, T, S, lls, tr, ip, gamma, tll, lfw, lbw)
@@ -2455,3 +2572,31 @@ extern "C" int vbx_debug_clocks(long long* out, int n_words) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(vbx::g_phase_clocks), (size_t)n_words * sizeof(long long));
 }
 #endif
+
+// debugging aid (not part of the ABI): copy one of a plain batch's per-tile arrays to the host
+//   which = 0 mpart [tiles][Sp][Dp] R, 1 npart [tiles][Sp] R, 2 epart [tiles][Sp] f64, 3 tllpart [tiles] f64, 4 gamma0 [n_rec][Sp] R
+extern "C" long long vbx_debug_fetch(vbx_batch* b, int which, void* out, long long cap_bytes) {
+    if (!b || !b->kids.empty()) return -1;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    const size_t nt = (size_t)b->ntiles_total, sp = (size_t)b->Sp, dp = (size_t)b->Dp, rs = b->rsize;
+    const void* src = nullptr;
+    size_t bytes = 0;
+    switch (which) {
+        case 0: src = b->d_mpart; bytes = nt * sp * dp * rs; break;
+        case 1: src = b->d_npart; bytes = nt * sp * rs; break;
+        case 2: src = b->d_epart; bytes = nt * sp * 8; break;
+        case 3: src = b->d_tllpart; bytes = nt * 8; break;
+        case 4: src = b->d_gamma0; bytes = (size_t)b->n_rec * sp * rs; break;
+#ifdef VBX_DEBUG_INPUTS
+        case 5:
+            bytes = std::min<size_t>(nt, vbx::kDbgTiles) * 8 * 8;
+            if ((long long)bytes > cap_bytes) return -(long long)bytes;
+            return hipMemcpyFromSymbol(out, HIP_SYMBOL(vbx::g_dbg_inputs), bytes) == hipSuccess ? (long long)bytes : -1;
+#endif
+        default: return -1;
+    }
+    if (!src || (long long)bytes > cap_bytes) return -(long long)bytes;
+    if (hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (long long)bytes;
+}

@@ -2,6 +2,7 @@
 // pass over rho (the other per-chunk kernel, chunk_post, is in vbx_chunk_post.hpp).
 #pragma once
 #include "vbx_operator.hpp"
+#include "vbx_split.hpp"
 
 namespace vbx {
 
@@ -21,8 +22,14 @@ template <typename R, int SP> struct ChunkLoglikCfg {
     static constexpr bool kFits = kBytes <= 160 * 1024;
 };
 
-template <typename R, int SP>
-__global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)sizeof(R) <= 256 ? 4 : 2)) void chunk_loglik_kernel(BatchView<R> bt) {
+#ifndef VBX_SPLIT_LOGLIK_WAVES
+#define VBX_SPLIT_LOGLIK_WAVES 7
+#endif
+// SPLIT (fp32 only): the product on v_mfma_f32_16x16x32_f16 with f16 operand pairs (vbx_split.hpp) -- rho from its
+// fragment-ordered copy rho_a, alpha from the fragments fin_kernel wrote.
+template <typename R, int SP, bool SPLIT = false>
+__global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? (SPLIT && SP == 32 ? VBX_SPLIT_LOGLIK_WAVES : 8) : SP * (int)sizeof(R) <= 256 ? 4 : 2)) void chunk_loglik_kernel(BatchView<R> bt) {
+    static_assert(!SPLIT || sizeof(R) == 4, "the split GEMM is a mode of the fp32 path");
     using M = Mfma16<R>;
     using acc_t = typename M::acc_t;
     using R4 = typename Vec<R>::v4;
@@ -73,6 +80,57 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)si
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[m][n] = acc_t{0, 0, 0, 0};
+        R cscale[NT];                                  // what turns an accumulator into rho . alpha (1, or 2^-(e_rho + e_alpha))
+#pragma unroll
+        for (int n = 0; n < NT; ++n) cscale[n] = (R)1;
+        if constexpr (SPLIT) {
+            // ---- f16 pairs: per K-block of 32 dims a wave loads its four A fragments (2 M-tiles x {hi, lo}: one
+            // contiguous KB per load instruction) and multiplies them with the NT x {hi, lo} B fragments of the block,
+            // staged in LDS in fragment order (lane-linear 16-byte reads); three MFMAs per product (vbx_split.hpp)
+            const int KK = Dp >> 5;
+            const int rtile = tile - rd.tile0 + rd.rho_tile0;
+            const h8* __restrict__ ra = reinterpret_cast<const h8*>(bt.rho_a) + (long long)rtile * (kTileFrames * Dp / 4)
+                                        + (long long)(2 * wave) * KK * 128 + lane;
+            const h8* __restrict__ af = reinterpret_cast<const h8*>(bt.alpha_frag)
+                                        + ((long long)par * bt.n_rec + rec) * (SP * Dp / 4);
+            h8* const afl = reinterpret_cast<h8*>(lds);    // [n][kk of the slice: 4][hi | lo][lane]
+            const int e_rho = bt.rho_e[rd.rho_rec];
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                cscale[n] = scale2((R)1, -(e_rho + bt.alpha_e[(long long)par * bt.vec_stride + (long long)rec * SP + 16 * n + i]));
+            h8 a[2][2][2];                                 // [buffer][M-tile][hi | lo]
+            auto load_a = [&](int buf, int kk) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    a[buf][m][0] = ra[((long long)m * KK + kk) * 128];
+                    a[buf][m][1] = ra[((long long)m * KK + kk) * 128 + 64];
+                }
+            };
+            load_a(0, 0);
+#pragma unroll 1
+            for (int kk0 = 0; kk0 < KK; kk0 += 4) {
+                const int nk = min(4, KK - kk0);
+                if (kk0 > 0) __syncthreads();
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    for (int q = tid; q < nk * 128; q += 256) afl[n * 512 + q] = af[((long long)n * KK + kk0) * 128 + q];
+                __syncthreads();
+#pragma unroll
+                for (int kl = 0; kl < 4; ++kl) {
+                    if (kl < nk) {
+                        const int kk = kk0 + kl;
+                        if (kk + 1 < KK) load_a((kl + 1) & 1, kk + 1);
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) {
+                            const h8 bh = afl[(n * 4 + kl) * 128 + lane], bl = afl[(n * 4 + kl) * 128 + 64 + lane];
+#pragma unroll
+                            for (int m = 0; m < 2; ++m)
+                                acc[m][n] = mfma_split(a[kl & 1][m][0], a[kl & 1][m][1], bh, bl, acc[m][n]);
+                        }
+                    }
+                }
+            }
+        } else {
         // rows past the end of the recording are clamped (their results are never stored)
         const int rowA0 = min(f0 + i, rd.T - 1), rowA1 = min(f0 + 16 + i, rd.T - 1);
         constexpr int QB = 2;                          // K blocks of 16 whose rho fragments are loaded together
@@ -128,6 +186,7 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)si
                 if (q0 + QB < nq) load_a(q0 + QB);
             }
         }
+        }
         VBX_STAMP();
         __syncthreads();                               // every wave is done with the alpha slice: b may overwrite it
         const R Fa = (R)rd.Fa;
@@ -150,7 +209,7 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)si
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
                         const int s = 16 * n + i;
-                        v[n] = (s < rd.S) ? Fa * (acc[m][n][r] + biasv[n]) : neg_inf<R>();
+                        v[n] = (s < rd.S) ? Fa * (SPLIT ? acc[m][n][r] * cscale[n] + biasv[n] : acc[m][n][r] + biasv[n]) : neg_inf<R>();
                         mx = vmax(mx, v[n]);
                     }
                     mx = allreduce_max<16>(mx);
@@ -290,8 +349,8 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? 8 : SP * (int)si
                 R sig = 0;
 #pragma unroll
                 for (int mt = 0; mt < NT; ++mt) sig += (acc[mt][0] + acc[mt][1]) + (acc[mt][2] + acc[mt][3]);
-                sig += __shfl_xor(sig, 16, 64);
-                sig += __shfl_xor(sig, 32, 64);
+                sig = add_xor<16>(sig);
+                sig = add_xor<32>(sig);
                 const int ew = eW[ci];
                 const bool ok = ew > kNoMass / 2 && sig > (R)0;
                 const int e = ok ? rescale_exponent(sig) : 0;

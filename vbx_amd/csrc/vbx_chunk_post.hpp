@@ -47,6 +47,7 @@
 #pragma once
 #include <type_traits>
 #include "vbx_scan.hpp"
+#include "vbx_split.hpp"
 
 // 0: the four chains of a split tile on four waves (A/B builds)
 #ifndef VBX_POST_PACKED
@@ -55,6 +56,10 @@
 
 namespace vbx {
 
+#ifdef VBX_DEBUG_INPUTS
+constexpr int kDbgTiles = 16384;
+__device__ double g_dbg_inputs[kDbgTiles * 8];     // per tile: checksums of what chunk_post read (debugging aid)
+#endif
 #ifdef VBX_PHASE_CLOCKS
 constexpr int kClockTiles = 8192;
 __device__ long long g_phase_clocks[kClockTiles * 16];
@@ -67,9 +72,11 @@ template <typename R, int SP> struct ChunkPostCfg {
                                   : kBytes <= 80 * 1024 ? 2 : 1;
 };
 
-// REPLAY: write gamma only (see above).
-template <typename R, int SP, bool REPLAY>
+// REPLAY: write gamma only (see above).  SPLIT (fp32 only): gamma^T rho on v_mfma_f32_16x16x32_f16 with f16 operand pairs
+// (vbx_split.hpp) -- rho from its fragment-ordered copy rho_b, gamma split where it is computed.
+template <typename R, int SP, bool REPLAY, bool SPLIT = false>
 __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post_kernel(BatchView<R> bt) {
+    static_assert(!SPLIT || (sizeof(R) == 4 && !REPLAY), "the split GEMM is a mode of the fp32 iteration");
     using M = Mfma16<R>;
     using acc_t = typename M::acc_t;
     using R2 = typename Vec<R>::v2;
@@ -89,6 +96,7 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
     __shared__ __attribute__((aligned(16))) R aprev0[SP];
     __shared__ double ent_w[4][SP];
     __shared__ double red[16];
+    __shared__ R nsum_w[SPLIT ? 4 : 1][SP];            // SPLIT: sum of gamma per wave and speaker (taken from registers)
 
     const int tile = tile_of_block(bt, blockIdx.x);
     if (tile < 0 || (!REPLAY && bt.tile_done[tile])) return;
@@ -172,6 +180,34 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
         }
         __syncthreads();
         VBX_STAMP();
+#ifdef VBX_DEBUG_INPUTS
+        if (!REPLAY && tile < kDbgTiles) {
+            double* d = g_dbg_inputs + (long long)tile * 8;
+            double sb = 0;                                    // boundary vector of this wave (fbound for 0 / 2, gbound for 1 / 3)
+            for (int r = 0; r < NREG; ++r) sb += (double)bnd_v[r] * (1 + so + r);
+            sb = allreduce_sum<16>(sb);
+            double so_ = 0, se = 0;
+            if (split && wave >= 2) {
+                for (int r = 0; r < NREG; ++r) {
+                    se += (double)ope[r] * (1 + so + r);
+                    for (int ii = 0; ii < QS; ++ii) so_ += (double)(wave == 2 ? opf[ii][r] : opb[r][ii]) * (1 + ii + 3 * r + 7 * lane);
+                }
+                so_ = allreduce_sum<64>(so_);
+                se = allreduce_sum<16>(se);
+            }
+            double sbt = 0;
+            for (int q = tid; q < LAT; q += 256) sbt += (double)bl[q] * (1 + (q & 1023));
+            sbt = block_sum(sbt, red);
+            double sc = 0;
+            for (int r = 0; r < NREG; ++r) sc += (double)c_l[so + r] * (1 + so + r);
+            sc = allreduce_sum<16>(sc);
+            if (lane == 0) {
+                if (wave == 1) d[0] = sb;                       // gbound as the backward wave holds it
+                (void)sbt; (void)sc;
+            }
+            __syncthreads();
+        }
+#endif
 
         // ---- re-run: wave 0 forward, wave 1 backward (VBx.py:167-171 in the linear domain) ----------------------
         // A lone wavefront on a dependent instruction stream pays ~8-10 cycles per instruction, so the loops are
@@ -290,8 +326,8 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
                 }
 #pragma unroll
                 for (int r = 0; r < NREG; ++r) {
-                    a[r] += __shfl_xor(a[r], 16, 64);
-                    a[r] += __shfl_xor(a[r], 32, 64);
+                    a[r] = add_xor<16>(a[r]);
+                    a[r] = add_xor<32>(a[r]);
                     if (so + r >= n_spk) a[r] = 0;               // padded speakers carry no mass
                 }
             }
@@ -315,8 +351,8 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
                     R tot = 0;
 #pragma unroll
                     for (int ii = 0; ii < QS; ++ii) tot += opb[r][ii] * mv_w[1][g4 * QS + ii];
-                    tot += __shfl_xor(tot, 16, 64);
-                    tot += __shfl_xor(tot, 32, 64);
+                    tot = add_xor<16>(tot);
+                    tot = add_xor<32>(tot);
                     x[r] = tot;
                     tj[r] = (tot > (R)0 && ope[r] > kNoMass / 2) ? ope[r] + exponent_of(tot) : kNever;
                     top = max(top, tj[r]);
@@ -333,6 +369,13 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
         }
         if (packed) {
             __syncthreads();
+#ifdef VBX_DEBUG_INPUTS
+            if (!REPLAY && tile < kDbgTiles && tid == 0) {
+                double sx = 0;
+                for (int q = 0; q < SP; ++q) sx += (double)mv_w[1][q] * (1 + q);
+                g_dbg_inputs[(long long)tile * 8 + 4] = sx;      // the backward vector at the cut as wave 3 left it
+            }
+#endif
             if (wave == 0 && hl == 1) load_pack<NREG>(a, mv_w[0] + so);      // rows 2-3: the second half starts from a_(H-1)
             if (wave == 1 && hl == 0) load_pack<NREG>(x, mv_w[1] + so);      // rows 0-1: the first half starts from x_(H-1)
         }
@@ -432,11 +475,51 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
 #pragma unroll
             for (int u = 0; u < QK; ++u) dst[u] = *reinterpret_cast<const R2*>(src + 4 * (qi * QK + u) * Dp + lane_off);
         };
-        if (!REPLAY && wave * 32 < Dp) load_quarter(bq[0], wave, 0);
+        // SPLIT: the B operand comes from rho_b, [slab][h][kk][hi | lo][lane] in 16-byte fragments (vbx_split.hpp): per
+        // k-step of 32 frames a wave fetches the four fragments of its slab, one contiguous KB per load instruction
+        h8 bs[2][2][2];                                          // [buffer][h][hi | lo]
+        const h8* __restrict__ rb = nullptr;
+        if constexpr (SPLIT) {
+            const RecDesc& rdd = bt.recs[rec];
+            rb = reinterpret_cast<const h8*>(bt.rho_b) + (long long)(tile - rdd.tile0 + rdd.rho_tile0) * (kTileFrames * Dp / 4) + lane;
+        }
+        auto load_kstep = [&](int buf, int slab, int kk) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                bs[buf][h][0] = rb[((long long)(2 * slab + h) * 4 + kk) * 128];
+                bs[buf][h][1] = rb[((long long)(2 * slab + h) * 4 + kk) * 128 + 64];
+            }
+        };
+        if constexpr (SPLIT) {
+            if (wave * 32 < Dp) load_kstep(0, wave, 0);
+        } else {
+            if (!REPLAY && wave * 32 < Dp) load_quarter(bq[0], wave, 0);
+        }
         VBX_STAMP();
         __syncthreads();
         VBX_STAMP();
 
+#ifdef VBX_DEBUG_INPUTS
+        if (!REPLAY && tile < kDbgTiles) {
+            // checksums of what pass 1 is about to read (after the barrier above), per producer:
+            //   a rows: r1[0:32), bl[32:64), r1[64:96), bl[96:128)  (forward, before / after the crossing of each half)
+            //   x rows: bl[0:32), r1[32:64), bl[64:96), r1[96:128)
+            double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;
+            for (int q = tid; q < LAT; q += 256) {
+                const int f = q / SP;
+                const bool low = (f & 32) == 0;
+                const double w = 1 + (q % 977);
+                if (low) s0 += (double)r1[q] * w;            // a before the crossing
+                else (f < 64 ? s3 : s1) += (double)r1[q] * w;   // x before the crossing: first half | second half
+                if (low) s2 += (double)bl[q] * w;            // x after the crossing
+            }
+            if (tid < kTileFrames) { s4 = (double)sfl[tid] * (1 + tid); s5 = (double)qfl[tid] * (1 + tid); }
+            s0 = block_sum(s0, red); s1 = block_sum(s1, red); s2 = block_sum(s2, red); s3 = block_sum(s3, red);
+            s4 = block_sum(s4, red); s5 = block_sum(s5, red);
+            if (tid == 0) { double* d = g_dbg_inputs + (long long)tile * 8; d[1] = s0; d[2] = s1; d[3] = s3; d[5] = s2; d[6] = s4; d[7] = s5; }
+            __syncthreads();
+        }
+#endif
         // ---- posteriors and the "entered" statistic                               (VBx.py:101-103,174) --
         //   gamma_t = a_t x_t / sum;   entered_j += gamma_t[j] s_{t-1} / (lp a_{t-1}[j] + c_j s_{t-1}),  t >= 1
         // rows are brought to scale 1 first (a/s sums to 1, x/q >= 1 elementwise): no product can underflow.
@@ -511,8 +594,8 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
 #pragma unroll
             for (int r = 0; r < NREG; ++r) {
                 double e = (double)ent[r];                     // <= 8 terms per lane in working precision
-                e += __shfl_xor(e, 16, 64);
-                e += __shfl_xor(e, 32, 64);
+                e = add_xor<16>(e);
+                e = add_xor<32>(e);
                 if (g4 == 0) ent_w[wave][so + r] = e;
             }
             double mpartial = 0.0;                             // this chunk's share of the total log-likelihood (VBx.py:173)
@@ -532,10 +615,36 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
                 bt.epart[(long long)tile * SP + tid] = tid < n_spk ? e : 0.0;
             }
             if (tid == 0) bt.tllpart[tile] = mpartial;
+            if constexpr (SPLIT) {
+                // The eight frames of this thread, f = 16 it + 4 wave + g4, are the k-slots (kk = wave, g = g4, e = it) of
+                // rho_b's order, and its NREG states the rows i16 of the NREG M-tiles: the thread's gamma 2^14 IS lane
+                // (16 g4 + i16)'s A fragment of k-step `wave`, one 16-byte store per M-tile and half.
+                static_assert(NIT == 8, "one A fragment = eight frames");
+                h8* const gfr = reinterpret_cast<h8*>(bl);         // [M-tile][k-step][hi | lo][lane]
+#pragma unroll
+                for (int r = 0; r < NREG; ++r) {
+                    h8 hi, lo;
+                    R nloc = 0;
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        _Float16 a, b;
+                        split_f16(gam[it][r] * (R)(1 << kSplitTop), a, b);
+                        hi[it] = a;
+                        lo[it] = b;
+                        nloc += gam[it][r];
+                    }
+                    gfr[(r * 4 + wave) * 128 + lane] = hi;
+                    gfr[(r * 4 + wave) * 128 + 64 + lane] = lo;
+                    nloc = add_xor<16>(nloc);
+                    nloc = add_xor<32>(nloc);
+                    if (g4 == 0) nsum_w[wave][so + r] = nloc;
+                }
+            } else {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int f = 16 * it + 4 * wave + g4;
                 store_pack<NREG>(bl + f * SP + so, gam[it]);       // A operand of the accumulation below (0 past the end)
+            }
             }
             // iter_fin needs the responsibilities of frame 0 (VBx.py:102)
             if (chunk0 && wave == 0 && g4 == 0) store_pack<NREG>(bt.gamma0 + (long long)rec * SP + so, gam[0]);
@@ -546,6 +655,40 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
         // ---- next M-step: C[s][d] = sum_t gamma[t][s] rho[t][d] on MFMA 16x16x4        (VBx.py:96) --
         // M index i of tile mu <-> speaker NT*i + mu (one vector LDS read feeds every tile);
         // N index j of half h <-> feature 32*slab + 2j + h (one 8/16-byte global load feeds both).
+        if constexpr (SPLIT) {
+            if (tid < SP) bt.npart[(long long)tile * SP + tid] = (nsum_w[0][tid] + nsum_w[1][tid]) + (nsum_w[2][tid] + nsum_w[3][tid]);
+            const h8* const gfr = reinterpret_cast<const h8*>(bl);
+            const R descale = scale2((R)1, -(kSplitTop + bt.rho_e[bt.recs[rec].rho_rec]));
+            for (int slab = wave; slab * 32 < Dp; slab += 4) {
+                acc_t acc[NT][2];
+#pragma unroll
+                for (int mu = 0; mu < NT; ++mu) {
+                    acc[mu][0] = acc_t{0, 0, 0, 0};
+                    acc[mu][1] = acc_t{0, 0, 0, 0};
+                }
+                if (slab != wave) load_kstep(0, slab, 0);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    if (kk < 3) load_kstep((kk + 1) & 1, slab, kk + 1);
+#pragma unroll
+                    for (int mu = 0; mu < NT; ++mu) {
+                        const h8 ah = gfr[(mu * 4 + kk) * 128 + lane], al = gfr[(mu * 4 + kk) * 128 + 64 + lane];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) acc[mu][h] = mfma_split(ah, al, bs[kk & 1][h][0], bs[kk & 1][h][1], acc[mu][h]);
+                    }
+                }
+                R* __restrict__ part = bt.mpart + (long long)tile * SP * Dp;
+#pragma unroll
+                for (int mu = 0; mu < NT; ++mu) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int s = NT * M::row(lane, r) + mu;
+                        *reinterpret_cast<R2*>(part + (long long)s * Dp + 32 * slab + 2 * i16) =
+                            R2{acc[mu][0][r] * descale, acc[mu][1][r] * descale};
+                    }
+                }
+            }
+        } else
         for (int slab = wave; slab * 32 < Dp; slab += 4) {
             acc_t acc[NT][2];
             R nsum[NT];
@@ -590,8 +733,8 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
 #pragma unroll
                 for (int mu = 0; mu < NT; ++mu) {
                     R v = nsum[mu];
-                    v += __shfl_xor(v, 16, 64);
-                    v += __shfl_xor(v, 32, 64);
+                    v = add_xor<16>(v);
+                    v = add_xor<32>(v);
                     if (g4 == 0) bt.npart[(long long)tile * SP + NT * i16 + mu] = v;
                 }
             }

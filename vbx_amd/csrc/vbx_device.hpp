@@ -136,6 +136,22 @@ template <int CTRL> __device__ __forceinline__ int dpp_mov(int v) {
     return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
 }
 
+// v + (the value lane ^ STAGE holds), STAGE = 16 or 32, on the VALU (v_permlane16/32_swap).  NOT __shfl_xor: that is a
+// ds_bpermute_b32, an LDS-queue instruction, and on gfx950 (ROCm 7.2) a bpermute whose ADDRESS register the compiler
+// re-uses in the very next VALU instruction returned another lane's value now and then once the LDS queue of the CU was
+// kept full by other workgroups' 16-byte reads -- round 4: the vector at the cut of chunk_post, wrong in ~3 of 1400 tiles,
+// only from the second round of workgroups on, only beside the f16-MFMA instances (tools/r04_inputs.py).
+template <int STAGE, typename T> __device__ __forceinline__ T add_xor(T v) {
+    T a, b;
+    cross_rows<STAGE>(v, a, b);
+    return a + b;
+}
+template <int STAGE> __device__ __forceinline__ int max_xor(int v) {
+    int a, b;
+    cross_rows<STAGE>(v, a, b);
+    return a > b ? a : b;
+}
+
 // value held by one lane, as a wave-uniform scalar (v_readlane_b32 -> SGPR)
 __device__ __forceinline__ float read_lane(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
@@ -269,6 +285,32 @@ __device__ __forceinline__ double block_sum(double v, double* lds /* >= 16 doubl
     double tot = 0.0;
     for (int w = 0; w < nw; ++w) tot += lds[w];
     return tot;
+}
+
+// ---------------------------------------------------------------------------------------
+// f16 operand pairs of the split GEMMs (vbx_split.hpp)
+// ---------------------------------------------------------------------------------------
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+using f4 = Vec<float>::v4;
+
+constexpr int kSplitTop = 14;          // scaled operands: largest magnitude in [2^13, 2^14)
+constexpr int kSplitMaxDp = 1024;      // fin_kernel keeps a speaker's alpha row in LDS while it looks for the scale
+
+// exponent e such that amax 2^e lies in [2^13, 2^14); 0 for amax = 0 (or not finite)
+__device__ __forceinline__ int split_exponent(float amax) {
+    if (!(amax > 0.0f) || !(amax < INFINITY)) return 0;
+    return max(-100, min(100, kSplitTop - __builtin_amdgcn_frexp_expf(amax)));
+}
+
+__device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+
+// offsets in halfs inside one recording's alpha fragments [Sp / 16][Dp / 32][hi | lo][64 lanes][8]
+__device__ __forceinline__ long long alpha_frag_offset(int s, int d, int hl, int Dp) {
+    const int n = s >> 4, j = s & 15, kk = d >> 5, g = (d & 31) >> 3, e = d & 7;
+    return ((((long long)n * (Dp >> 5) + kk) * 2 + hl) * 64 + 16 * g + j) * 8 + e;
 }
 
 }  // namespace vbx

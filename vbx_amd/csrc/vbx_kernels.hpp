@@ -27,6 +27,8 @@ struct RecDesc {
     int has_model;    // alpha/invL supplied by the caller: skip the first M-step (VBx.py:94)
     int sup0;         // first group operator of this recording (two- / three-level boundary walk)
     int sup20;        // first level-2 group operator of this recording (three-level walk)
+    int rho_tile0;    // first tile of its rho in the fragment-ordered f16 copies (split GEMMs): tile0, or the owner's
+    int rho_rec;      // the recording that owns that rho (index of its scale exponent, BatchView::rho_e)
     double lp, Fa, Fb;
     double gsum;      // sum_t G_t (VBx.py:87)
 };
@@ -113,6 +115,13 @@ template <typename R> struct BatchView {
     // two halves of a tile on separate waves (half the dependent chain).  op / opexp / fbound / gbound always
     // have room for two chunks per tile.
     int spt;
+    // split GEMMs (vbx_split.hpp; fp32 batches with VBX_OPT_GEMM = split): rho as f16 pairs in MFMA fragment order, the
+    // model's alpha likewise (fin_kernel), and their power-of-two scales.  All null when the mode is off.
+    const _Float16* rho_a;     // [tiles][kTileFrames x Dp x 2]  A operand of rho alpha^T   (chunk_loglik)
+    const _Float16* rho_b;     // [tiles][kTileFrames x Dp x 2]  B operand of gamma^T rho   (chunk_post)
+    const int* rho_e;          // [n_rec]  the copies hold rho 2^rho_e (indexed by RecDesc::rho_rec)
+    _Float16* alpha_frag;      // [2][n_rec][Sp x Dp x 2]  alpha 2^alpha_e of the two model copies, B operand of rho alpha^T
+    int* alpha_e;              // [2][n_rec][Sp]
 };
 
 // the tile a workgroup of a per-chunk kernel works on (-1: none)
@@ -229,8 +238,8 @@ __global__ __launch_bounds__(64) void mstep_acc_kernel(BatchView<R> bt) {
 #pragma unroll
         for (int mu = 0; mu < NT; ++mu) {
             R v = nsum[mu];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
+            v = add_xor<16>(v);
+            v = add_xor<32>(v);
             if (g == 0) bt.npart[(long long)tile * Sp + s0 + 16 * mu + i] = v;
         }
     }
@@ -258,6 +267,8 @@ __global__ __launch_bounds__(1024) void fin_kernel(BatchView<R> bt, int mode) {
     __shared__ double lds[16];
     __shared__ double sh[1024];
     __shared__ int done_sh;
+    __shared__ float arow[kSplitMaxDp];                     // split GEMMs: the speaker's alpha row (f32, as stored)
+    __shared__ float amax_sh[16];
     const int rec = blockIdx.x, Sp = bt.Sp, Dp = bt.Dp;
     const RecState st_in = bt.state[rec];
     const RecDesc rd = bt.recs[rec];
@@ -346,6 +357,7 @@ __global__ __launch_bounds__(1024) void fin_kernel(BatchView<R> bt, int mode) {
     }
     const long long sd = (long long)(k & 1) * bt.model_stride + ((long long)rec * Sp + s) * Dp;
     double bsum = 0.0, esum = 0.0;
+    float amax = 0.0f;                                      // (split GEMMs: the largest |alpha| of this speaker)
     // thread = (feature d, slice of the tile range: 2 slices, 8 in a block of 1024 threads -- a recording of T = 200 000
     // has 1563 partials per speaker, twenty dependent rounds of loads on two slices); loads are clamped instead of
     // predicated so that all of a round are in flight per thread
@@ -388,8 +400,30 @@ __global__ __launch_bounds__(1024) void fin_kernel(BatchView<R> bt, int mode) {
             }
             bsum += (il + al * al) * phi;
             if (s < rd.S && d < bt.D) esum += log(il) - il - al * al + 1.0;
+            if (bt.alpha_frag) {
+                arow[d] = (float)al;
+                amax = fmaxf(amax, fabsf((float)al));
+            }
         }
         __syncthreads();
+    }
+    if (bt.alpha_frag) {
+        // alpha of this speaker as f16 pairs in the fragment order of chunk_loglik's B operand (vbx_split.hpp), scaled by
+        // the power of two that puts its largest magnitude into [2^13, 2^14)
+        amax = allreduce_max<64>(amax);
+        if ((threadIdx.x & 63) == 0) amax_sh[threadIdx.x >> 6] = amax;
+        __syncthreads();
+        float m = 0.0f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, amax_sh[w]);
+        const int e2 = split_exponent(m);
+        _Float16* __restrict__ fr = bt.alpha_frag + ((long long)(k & 1) * bt.n_rec + rec) * Sp * Dp * 2;
+        for (int d = threadIdx.x; d < Dp; d += blockDim.x) {
+            _Float16 hi, lo;
+            split_f16(__builtin_amdgcn_ldexpf(arow[d], e2), hi, lo);
+            fr[alpha_frag_offset(s, d, 0, Dp)] = hi;
+            fr[alpha_frag_offset(s, d, 1, Dp)] = lo;
+        }
+        if (threadIdx.x == 0) bt.alpha_e[(long long)(k & 1) * bt.vec_stride + (long long)rec * Sp + s] = e2;
     }
     bsum = block_sum(bsum, lds);
     esum = block_sum(esum, lds);

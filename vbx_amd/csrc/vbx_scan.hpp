@@ -406,8 +406,8 @@ __global__ __launch_bounds__(256) void scan_compose_kernel(BatchView<R> bt, int 
                     tj[mt][r] = (pv[mt][r] > (R)0 && e > kNoMass / 2) ? e + exponent_of(pv[mt][r]) : kNever;
                     top = max(top, tj[mt][r]);
                 }
-            top = max(top, __shfl_xor(top, 16, 64));
-            top = max(top, __shfl_xor(top, 32, 64));
+            top = max_xor<16>(top);
+            top = max_xor<32>(top);
             alive = top > -(1 << 27) && eP > kNoMass / 2;
 #pragma unroll
             for (int mt = 0; mt < NT; ++mt)
@@ -431,8 +431,8 @@ __global__ __launch_bounds__(256) void scan_compose_kernel(BatchView<R> bt, int 
             R sig = 0;
 #pragma unroll
             for (int mt = 0; mt < NT; ++mt) sig += (acc[mt][0] + acc[mt][1]) + (acc[mt][2] + acc[mt][3]);
-            sig += __shfl_xor(sig, 16, 64);
-            sig += __shfl_xor(sig, 32, 64);
+            sig = add_xor<16>(sig);
+            sig = add_xor<32>(sig);
             if (alive && sig > (R)0) {
                 const int e = rescale_exponent(sig);
 #pragma unroll

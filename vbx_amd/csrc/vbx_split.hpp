@@ -1,0 +1,103 @@
+// vbx_split.hpp -- the two GEMM-shaped contractions of an iteration (rho alpha^T, VBx.py:97; gamma^T rho, VBx.py:96) on
+// the f16 matrix cores with error-compensated operands ("split" mode of the fp32 path, VBX_OPT_GEMM).
+//
+// v_mfma_f32_16x16x4_f32 is exact f32 but runs at the f32 VECTOR rate (64 FLOP / clk / SIMD: 32 cycles per instruction,
+// 1/16 of the f16 / bf16 matrix rate) and does not overlap with vector instructions on a SIMD (DESIGN section 17,
+// tools/valu_probe.hip): 27-30 % of the SIMD cycles of both per-chunk kernels.  Here every f32 operand x is carried as
+// two f16 values,
+//     x 2^e = hi + lo,   hi = f16(x 2^e),   lo = f16(x 2^e - hi)
+// (22 significant bits; e an exact power-of-two scale chosen per recording / per speaker so that the largest magnitude
+// sits in [2^13, 2^14): hi never overflows and lo stays a normal f16 number for everything within 2^-17 of the largest),
+// and a product is three v_mfma_f32_16x16x32_f16 with f32 accumulation,
+//     a b ~ hi_a lo_b + lo_a hi_b + hi_a hi_b      (the dropped lo lo term is 2^-22 of the product)
+// i.e. 3 x 16 cycles per K = 32 against 8 x 32: a fifth of the matrix cycles, and they run on the matrix cores proper.
+// The operands that do not change over the iterations are split ONCE: rho lives in HBM a second and a third time as f16
+// pairs in MFMA fragment order -- 4 bytes per element like the f32 copy, so the kernels' traffic is unchanged:
+//     rho_a  A operand of rho alpha^T (rows = frames, k = feature dims)      chunk_loglik
+//     rho_b  B operand of gamma^T rho (k = frames, columns = feature dims)   chunk_post
+// alpha is split by fin_kernel when it writes the model (per-speaker scale), gamma by chunk_post where it is computed
+// (scale 2^14: gamma <= 1).
+//
+// Fragment order (one v_mfma_f32_16x16x32_f16 operand = 8 halfs per lane = one 16-byte load; lane = 16 g + i):
+//   A: row i, k-slots (g, e), e = 0..7        B: column i, k-slots (g, e)
+// Which k a slot (kk, g, e) stands for is free as long as A and B agree (the sum over k is order-free):
+//   rho_a / alpha : feature dim  d = 32 kk + 8 g + e
+//   rho_b / gamma : frame        f = 16 e + 4 kk + g      (the eight frames one thread of chunk_post's posterior pass owns
+//                                                          are its own operand: no transposition, one 16-byte LDS store)
+#pragma once
+#include "vbx_scan.hpp"
+
+namespace vbx {
+
+__device__ __forceinline__ f4 mfma_h(h8 a, h8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+// (small terms first)
+__device__ __forceinline__ f4 mfma_split(h8 ah, h8 al, h8 bh, h8 bl, f4 c) {
+    c = mfma_h(ah, bl, c);
+    c = mfma_h(al, bh, c);
+    return mfma_h(ah, bh, c);
+}
+
+// largest |rho| of a recording -> amax[0] (bits of a non-negative float order like integers); grid = tiles of the recording
+__global__ __launch_bounds__(256) void rho_absmax_kernel(const float* __restrict__ rho, int T, int Dp, int* __restrict__ amax) {
+    const long long n = (long long)min(kTileFrames, T - (int)blockIdx.x * kTileFrames) * Dp;
+    const float* __restrict__ src = rho + (long long)blockIdx.x * kTileFrames * Dp;
+    float m = 0.0f;
+    for (long long q = threadIdx.x; q < n; q += 256) m = fmaxf(m, fabsf(src[q]));
+    m = allreduce_max<64>(m);
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(amax, __builtin_bit_cast(int, m));
+}
+
+// rho (f32, [T][Dp]) of one recording -> its tiles of rho_a and rho_b; grid = tiles of the recording, block = 256.
+// A tile of either is kTileFrames x Dp x 2 halfs; frames past the end of the recording are zero.
+//   rho_a tile: [m-tile 0..7][kk 0..Dp/32-1][hi | lo][lane][8]   frame 16 mt + i, dim 32 kk + 8 g + e
+//   rho_b tile: [slab 0..Dp/32-1][h 0..1][kk 0..3][hi | lo][lane][8]   dim 32 slab + 2 i + h, frame 16 e + 4 kk + g
+// (the column relabelling of rho_b -- dims 2 i and 2 i + 1 in the two N-tiles of a slab -- gives chunk_post 8-byte stores)
+__global__ __launch_bounds__(256) void rho_split_kernel(const float* __restrict__ rho, int T, int Dp, const int* __restrict__ amax,
+                                                        int* __restrict__ rho_e, _Float16* __restrict__ rho_a,
+                                                        _Float16* __restrict__ rho_b) {
+    const int e2 = split_exponent(__builtin_bit_cast(float, *amax));
+    if (blockIdx.x == 0 && threadIdx.x == 0) *rho_e = e2;
+    const int t0 = blockIdx.x * kTileFrames, KK = Dp >> 5;
+    const long long tile_halfs = (long long)kTileFrames * Dp * 2;
+    _Float16* __restrict__ ta = rho_a + blockIdx.x * tile_halfs;
+    _Float16* __restrict__ tb = rho_b + blockIdx.x * tile_halfs;
+    const int nitems = 8 * KK * 64;                    // (m-tile, kk, lane) resp. (slab, h, kk, lane): the same count
+    for (int it = threadIdx.x; it < nitems; it += 256) {
+        const int lane = it & 63, i = lane & 15, g = lane >> 4;
+        {
+            const int kk = (it >> 6) % KK, mt = (it >> 6) / KK;
+            const int f = t0 + 16 * mt + i;
+            h8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = f < T ? scale2(rho[(long long)f * Dp + 32 * kk + 8 * g + e], e2) : 0.0f;
+                _Float16 a, b;
+                split_f16(v, a, b);
+                hi[e] = a;
+                lo[e] = b;
+            }
+            h8* dst = reinterpret_cast<h8*>(ta) + ((long long)(mt * KK + kk) * 2) * 64 + lane;
+            dst[0] = hi;
+            dst[64] = lo;
+        }
+        {
+            const int kk = (it >> 6) & 3, sh = (it >> 8);          // sh = 2 slab + h
+            const int d = 32 * (sh >> 1) + 2 * i + (sh & 1);
+            h8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int f = t0 + 16 * e + 4 * kk + g;
+                const float v = f < T ? scale2(rho[(long long)f * Dp + d], e2) : 0.0f;
+                _Float16 a, b;
+                split_f16(v, a, b);
+                hi[e] = a;
+                lo[e] = b;
+            }
+            h8* dst = reinterpret_cast<h8*>(tb) + ((long long)(sh * 4 + kk) * 2) * 64 + lane;
+            dst[0] = hi;
+            dst[64] = lo;
+        }
+    }
+}
+
+}  // namespace vbx
