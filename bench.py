@@ -25,13 +25,18 @@ Also on the same JSON line:
   roofline                  dominant kernel: algorithmic bytes / HIP-event time vs the 8 TB/s HBM peak
   roofline_whole_iteration  the five launches of an iteration together, against the survey's byte count (SURVEY 8d:
                             one kernel per stage) and against the fused design's compulsory bytes
+  f32_split                 the same batch with the two GEMMs on f16 operand pairs (VBX_OPT_GEMM = split: v_mfma_f32_16x16x32_f16,
+                            fp32 storage and accumulation; vbx_amd/csrc/vbx_split.hpp), with its own roofline.  `value` stays the
+                            exact-f32 line (--gemm exact) unless --gemm split is asked for
   f64                       the same batch on the fp64 path (what vbhmm.py gets: its inputs are float64), with its own roofline
   configs                   BASELINE.json configs[1], [2], [4]: C2 (T=10k, S=10), C3 (T=50k, S=30), C5 (T=200k, S=50, loopProb
                             0.9, the nine-point Fa/Fb sweep as one batch on a shared rho, and with private copies), fp32 and
                             fp64: ms per iteration, dominant kernel, algorithmic bytes, fraction of the HBM peak
   single_recording          latency-bound rate of ONE recording (batch=1) on one GPU
-  cpu_baseline              the NumPy/SciPy restatement of the reference (oracle/vbx_oracle.py, kind "port": the GPU
-                            box has no /root/reference) on the host cores, bounded sample (rank 0, N=1 only)
+  cpu_baseline              the reference's own VBx() -- oracle/_ref/VBx_reference.py, the file oracle/build_ref.py copies
+                            from /root/reference at build time (kind "reference"; git-ignored, it travels with the snapshot) --
+                            or, where that file is missing, the NumPy/SciPy restatement oracle/vbx_oracle.py (kind "port"),
+                            on the host cores, bounded sample (rank 0, N=1 only)
 """
 from __future__ import annotations
 
@@ -89,9 +94,50 @@ def pmc_traffic(kernel, workload):
     return (None, f'refused: {stale} was measured on other kernel sources than {now}' if stale else 'no PMC profile of this workload on file', None)
 
 
-def algo_bytes(kernel, T, R, S, esize):
+def sq_issue(kernel, workload):
+    """Issue-side picture of ``kernel`` from the committed SQ pass (tools/pmc_counters.py -> profiles/*_sq_issue.json):
+    fractions of all SIMD cycles of a launch in which a matrix instruction executes (SQ_VALU_MFMA_BUSY_CYCLES) and in which
+    a vector instruction issues (SQ_ACTIVE_INST_VALU x 4 cycles), and what is left.  Same rules as pmc_traffic: the file
+    must be of this workload and of these kernel sources.  -> dict or None"""
+    import glob
+    from vbx_amd.build import iteration_source_hash
+    now = iteration_source_hash()
+    for path in sorted(glob.glob(os.path.join(REPO, 'profiles', '*_sq_issue.json'))):
+        try:
+            doc = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if doc.get('workload') != workload or kernel not in doc.get('kernels', {}) or doc.get('iteration_source_sha16') != now:
+            continue
+        k = doc['kernels'][kernel]
+        return {'mfma_busy': k['mfma_busy'], 'valu_issue': k['valu_issue'], 'idle': max(0.0, 1.0 - k['mfma_busy'] - k['valu_issue']),
+                'source': os.path.relpath(path, REPO)}
+    return None
+
+
+HBM_COPY_GBS = 6290.0           # MI355X_MICROARCH.md: 6.29 TB/s measured with a float4 copy (79 % of the spec)
+
+
+def classify_bound(issue, traffic_bytes, avg_us):
+    """What a kernel is bound by, from the counters and not from the design's intention:
+      'simd-issue'  the SIMDs issue matrix or vector instructions in >= 70 % of their cycles
+      'hbm'         the bytes it really moves (PMC) go at >= 70 % of what a plain copy reaches on this chip
+      'latency'     neither: exposed waits (dependent chains, launches too small to fill the chip)
+      'unprofiled'  no SQ / PMC pass of this workload on these kernel sources is on file"""
+    if issue is None and traffic_bytes is None:
+        return 'unprofiled'
+    if issue is not None and issue['mfma_busy'] + issue['valu_issue'] >= 0.70:
+        return 'simd-issue'
+    if traffic_bytes is not None and traffic_bytes / (avg_us * 1e-6) / 1e9 >= 0.70 * HBM_COPY_GBS:
+        return 'hbm'
+    return 'latency'
+
+
+def algo_bytes(kernel, T, R, S, esize, n_rec=1, rho_copies=None):
+    """Algorithmic HBM bytes of one launch over ``n_rec`` recordings of which ``rho_copies`` (default: all) have a rho of
+    their own -- a sweep over one recording reads ONE rho (vbx_batch_set_recording_shared)."""
     pr, ps = ALGO_PASSES[kernel]
-    return esize * (pr * T * R + ps * T * S)
+    return esize * (pr * T * R * (n_rec if rho_copies is None else rho_copies) + ps * T * S * n_rec)
 
 
 def make_batch(ctx, n_rec, T, S, D, precision, seed0, max_iters, streams=None):
@@ -132,26 +178,47 @@ def make_sweep_batch(ctx, T, S, D, precision, max_iters, shared, loop_prob=0.9, 
     return batch
 
 
+def reference_module():
+    """The reference's own VBx.py as oracle/build_ref.py left it in oracle/_ref/ (None where that has not run)."""
+    path = os.path.join(REPO, 'oracle', '_ref', 'VBx_reference.py')
+    if not os.path.exists(path):
+        return None
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('_vbx_reference', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def cpu_baseline(T, S, D, iters, precision='fp32'):
-    """oracle (kind="port"): same algorithm and third-party calls as the reference's VBx.py (pinned to the reference's
-    outputs at this very size by tests/test_oracle_golden.py).  Timed on one core; its first two iterations also
-    serve BASELINE.json's second metric: max |gamma - gamma_NumPy| of the GPU path on the same recording and
-    initialisation (two iterations: further on, fp32 and fp64 EM trajectories drift apart by themselves until they
+    """The reference's VBx() itself (kind "reference": oracle/_ref/VBx_reference.py, copied from /root/reference by
+    oracle/build_ref.py at build time) or, without it, the oracle (kind "port": same algorithm and third-party calls, pinned
+    to the reference's outputs at this very size by tests/test_oracle_golden.py).  Timed on one core; its first two
+    iterations also serve BASELINE.json's second metric: max |gamma - gamma_NumPy| of the GPU path on the same recording
+    and initialisation (two iterations: further on, fp32 and fp64 EM trajectories drift apart by themselves until they
     meet again at convergence; tests/test_gpu_configs.py compares converged runs with the reference)."""
     import contextlib
     import io
-    from oracle import vbx_oracle
+    ref = reference_module()
+    if ref is not None:
+        vbx_oracle = ref
+        kind = 'reference'
+    else:
+        from oracle import vbx_oracle
+        kind = 'port'
     from vbx_amd.synth import make_recording
     X, Phi, _ = make_recording(T, S, D=D, seed=0, kappa=0.05)
     g = np.random.default_rng(10_000).gamma(1.0, size=(T, S))
     g /= g.sum(1, keepdims=True)
     kw = dict(loopProb=0.99, Fa=0.3, Fb=17.0, pi=S, gamma=g, epsilon=-1e300)
     t0 = time.perf_counter()
-    vbx_oracle.VBx(X, Phi, maxIters=iters, **kw)
+    with contextlib.redirect_stdout(io.StringIO()):
+        vbx_oracle.VBx(X, Phi, maxIters=iters, **kw)
     dt = time.perf_counter() - t0
-    out = {'value': iters / dt, 'unit': 'EM iterations/s', 'cores': 1, 'kind': 'port',
-           'sample': f'{iters} iterations of one recording T={T} S={S} R={D} (float64, NumPy+SciPy logsumexp, '
-                     f'{dt:.1f} s on {os.cpu_count()} visible cores; the path is single-threaded)'}
+    out = {'value': iters / dt, 'unit': 'EM iterations/s', 'cores': 1, 'kind': kind,
+           'sample': f'{iters} iterations of one recording T={T} S={S} R={D} ('
+                     + ('the unmodified VBx/VBx.py::VBx of the reference' if kind == 'reference' else 'oracle/vbx_oracle.py')
+                     + f', float64, NumPy+SciPy logsumexp, {dt:.1f} s on {os.cpu_count()} visible cores; the path is single-threaded)'}
     import vbx_amd
     with contextlib.redirect_stdout(io.StringIO()):
         g_ref, pi_ref, L_ref = vbx_oracle.VBx(X, Phi, maxIters=2, **kw)
@@ -183,6 +250,13 @@ def main():
     ap.add_argument('--S', type=int, default=30)
     ap.add_argument('--D', type=int, default=128)
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'fp64'])
+    ap.add_argument('--gemm', default='exact', choices=['exact', 'split'],
+                    help='how the fp32 HEADLINE multiplies: exact = v_mfma_f32_16x16x4_f32; split = f16 operand pairs on the '
+                         'matrix cores (VBX_OPT_GEMM).  The other one is measured as a sub-record either way')
+    ap.add_argument('--no-split', action='store_true', help='skip the sub-record of the other GEMM mode')
+    ap.add_argument('--total-recordings', type=int, default=None,
+                    help='strong scaling: this many recordings over ALL ranks (BASELINE configs[3] as stated: 64 over 8 GPUs = 8 '
+                         'per GPU); --batch is then total / gpus and "scaling" says strong')
     ap.add_argument('--min-seconds', type=float, default=0.5, help='timed region: blocks of K steps until this much time')
     ap.add_argument('--max-blocks', type=int, default=200)
     ap.add_argument('--cpu-iters', type=int, default=20, help='oracle iterations for cpu_baseline (0 = skip)')
@@ -221,6 +295,13 @@ def main():
     info = ctx.device_info()
     esize = 4 if args.precision == 'fp32' else 8
     K, W = args.steps, args.warmup
+    if args.total_recordings is not None:
+        if args.total_recordings % world:
+            raise SystemExit(f'--total-recordings {args.total_recordings} is not a multiple of {world} ranks')
+        args.batch = args.total_recordings // world
+    # the precision string the library takes for the headline and for the other GEMM mode of the fp32 path
+    head_prec = 'fp32-split' if (args.precision == 'fp32' and args.gemm == 'split') else args.precision
+    other_prec = None if args.precision != 'fp32' else ('fp32' if args.gemm == 'split' else 'fp32-split')
 
     def barrier():
         if dist is not None:
@@ -282,14 +363,23 @@ def main():
         probe.close()
         return per_kernel, dom, probe_ms / (K * blocks), blocks
 
-    def roofline_of(per_kernel, dom, n_rec, T, S, D, es, workload):
-        """``roofline`` of the dominant HBM-side kernel: algorithmic bytes of one launch / its HIP-event duration."""
-        dom_bytes = n_rec * algo_bytes(dom, T, D, S, es)
-        achieved = dom_bytes / (per_kernel[dom]['avg_us'] * 1e-6) / 1e9
+    def roofline_of(per_kernel, dom, n_rec, T, S, D, es, workload, rho_copies=None):
+        """``roofline`` of the dominant HBM-side kernel: algorithmic bytes of one launch / its HIP-event duration, the bytes it
+        really moved (PMC) and what its SIMDs did meanwhile (SQ) where a profile of this workload on these kernel sources is
+        on file, and ``bound`` as those counters say (classify_bound).  ``achieved`` / ``frac`` are always against the HBM
+        peak: the algorithm is on the bandwidth side of the roofline whatever a kernel's present limit is."""
+        dom_bytes = algo_bytes(dom, T, D, S, es, n_rec, rho_copies)
+        avg_us = per_kernel[dom]['avg_us']
+        achieved = dom_bytes / (avg_us * 1e-6) / 1e9
         traffic = pmc_traffic(dom, workload)
-        return {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic[0], 'traffic_source': traffic[1],
-                'algorithmic_bytes_per_launch': dom_bytes, 'avg_launch_us': per_kernel[dom]['avg_us']}, traffic
+        issue = sq_issue(dom, workload)
+        out = {'bound': classify_bound(issue, traffic[0], avg_us), 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+               'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic[0], 'traffic_source': traffic[1],
+               'algorithmic_bytes_per_launch': dom_bytes, 'avg_launch_us': avg_us, 'simd_issue': issue}
+        if traffic[0] is not None:
+            out['traffic_GBs'] = traffic[0] / (avg_us * 1e-6) / 1e9
+            out['traffic_frac_of_copy_rate'] = out['traffic_GBs'] / HBM_COPY_GBS
+        return out, traffic
 
     # upper bound on the iterations a batch will be asked for (the ELBO history lives on the device)
     budget = W + K * (args.max_blocks + 2) + 16
@@ -298,22 +388,25 @@ def main():
         return make_batch(ctx, args.batch, args.T, args.S, args.D, precision, seed0=rank * args.batch,
                           max_iters=max_iters, streams=streams)
 
-    per_kernel, dom, probe_ms_per_step, probe_blocks = kernel_probe(lambda mi, st: headline(args.precision, mi, st),
+    per_kernel, dom, probe_ms_per_step, probe_blocks = kernel_probe(lambda mi, st: headline(head_prec, mi, st),
                                                                      args.min_seconds / 2, args.max_blocks)
 
     # ---- the timed region: the library's default configuration, no per-kernel events
-    batch = headline(args.precision, budget, args.streams)
+    batch = headline(head_prec, budget, args.streams)
     streams = batch.streams
     batch.run(W, -np.inf)
     times = timed_blocks(batch, args.min_seconds, args.max_blocks)
     res0 = batch.result(0, want_model=False)
+    gemm_ran = batch.gemm
     batch.close()
     med = statistics.median(times)
+    if args.precision == 'fp32':
+        assert gemm_ran == args.gemm, f'--gemm {args.gemm} but the library multiplied {gemm_ran}'
 
     # ---- the other configurations of BASELINE.json, each with its own kernel-level figure (rank 0 measures what fits one
     # GPU by itself; the multi-GPU metric is the batch above).  value = recording-iterations/s like the headline.
-    def one_config(name, make, n_rec, T, S, precision, note, min_seconds):
-        es = 4 if precision == 'fp32' else 8
+    def one_config(name, make, n_rec, T, S, precision, note, min_seconds, rho_copies=None):
+        es = 8 if precision == 'fp64' else 4
         pk, dk, _, _ = kernel_probe(make, min_seconds / 2, 16)
         b = make(W + K * 18 + 16, None)
         b.run(W, -np.inf)
@@ -331,14 +424,15 @@ def main():
         workload = {'batch': n_rec, 'T': T, 'S': S, 'D': args.D, 'precision': precision}
         if name.startswith('C5'):
             workload['sweep'] = name.split('_')[-1]
-        roof, _ = roofline_of(pk, dk, n_rec, T, S, args.D, es, workload)
-        fused = n_rec * (8 * T * args.D + 8 * T * S) * es / 4
+        roof, _ = roofline_of(pk, dk, n_rec, T, S, args.D, es, workload, rho_copies)
+        fused = ((n_rec if rho_copies is None else rho_copies) * 8 * T * args.D + n_rec * 8 * T * S) * es / 4
         return {'workload': note, 'precision': precision, 'recordings': n_rec, 'T': T, 'S': S, 'streams': nstreams,
                 'ms_per_iteration': 1e3 * dt / K, 'value': n_rec * K / dt, 'unit': 'recording-EM-iterations/s',
                 'blocks_of_K_steps': len(ts), 'seconds': sum(ts),
                 'dominant_kernel': dk, 'avg_us': roof['avg_launch_us'], 'algorithmic_bytes': roof['algorithmic_bytes_per_launch'],
                 'frac': roof['frac'], 'achieved_GBs': roof['achieved'], 'traffic': roof['traffic'],
-                'traffic_source': roof['traffic_source'],
+                'traffic_source': roof['traffic_source'], 'bound': roof['bound'], 'simd_issue': roof['simd_issue'],
+                'rho_copies_read': n_rec if rho_copies is None else rho_copies,
                 'iteration_compulsory_bytes': fused, 'iteration_frac_of_hbm_peak': fused / (dt / K) / 1e9 / HBM_PEAK_GBS,
                 'kernels_avg_us': {k: round(v['avg_us'], 2) for k, v in pk.items()}, 'elbo_last': elbo}
 
@@ -355,20 +449,62 @@ def main():
                 return b
             return make
         short = args.min_seconds / 4
-        for prec in ('fp32', 'fp64'):
+        # configs[0]: the reference's example recording, ONE reference-style call with host arrays in and out (allocation,
+        # H2D of X, the loop with the reference's own stopping rule, the gamma write-out, D2H) -- call-level, PCIe inclusive
+        gpath = os.path.join(REPO, 'tests', 'golden', 'es2005a.npz')
+        if os.path.exists(gpath):
+            import vbx_amd
+            g = dict(np.load(gpath))
+            kw = dict(pi=int(g['qinit'].shape[1]), gamma=g['qinit'], loopProb=float(g['loopProb']), Fa=float(g['Fa']), Fb=float(g['Fb']))
+            n_ref = len(g['Li40'])
+            for prec in ('fp64', 'fp32', 'fp32-split'):
+                X = g['fea'] if prec == 'fp64' else g['fea'].astype(np.float32)
+                call = dict(maxIters=40, epsilon=1e-6) if prec == 'fp64' else dict(maxIters=n_ref, epsilon=-1e300)
+                ts = []
+                for _ in range(12):
+                    t0 = time.perf_counter()
+                    q, sp, L = vbx_amd.VBx(X, g['Phi'], precision=prec, **kw, **call)
+                    ts.append(time.perf_counter() - t0)
+                dt = statistics.median(ts[2:])
+                configs[f'C1_ES2005a_{prec}'] = {
+                    'workload': 'configs[0]: exp/ES2005a x-vectors (T=1025, S=31 AHC clusters, R=128), VBx() as vbhmm.py:154-158 '
+                                'calls it; fp64 under the reference\'s own stopping rule (maxIters=40, epsilon=1e-6), fp32 over the '
+                                'same 13 iterations', 'precision': prec, 'iterations': len(L), 'reference_iterations': n_ref,
+                    'ms_per_call': 1e3 * dt, 'value': len(L) / dt, 'unit': 'EM iterations/s (call-level: host arrays in and out)',
+                    'gamma_max_abs_diff_vs_reference': float(np.abs(q - g['gamma40']).max()),
+                    'elbo_rel_diff_vs_reference': float(abs(L[-1][0] - g['Li40'][-1]) / abs(g['Li40'][-1])),
+                    'calls_timed': len(ts) - 2, 'note': 'median of 10 calls after 2 warm-up calls'}
+        # configs[3] AS STATED: 64 recordings over 8 GPUs = 8 per GPU (the headline line holds 64 per GPU: weak scaling)
+        for prec in ('fp32', 'fp32-split', 'fp64'):
+            configs[f'C4_as_stated_8_per_gpu_{prec}'] = one_config(
+                'C4', lambda mi, st, prec=prec: make_batch(ctx, 8, args.T, args.S, args.D, prec, 0, mi, st), 8, args.T, args.S, prec,
+                'configs[3] as stated: 64 recordings over 8 GPUs = 8 recordings of T=10 000, S=30 on THIS GPU '
+                '(python bench.py --gpus 8 --total-recordings 64 runs exactly that split)', short)
+        for prec in ('fp32', 'fp32-split', 'fp64'):
             configs[f'C2_T10k_S10_{prec}'] = one_config('C2', single(10000, 10, prec, 0.99), 1, 10000, 10, prec,
                                                          'configs[1]: one recording, T=10 000, S=10, Fa=0.3 Fb=17 loopProb=0.99', short)
             configs[f'C3_T50k_S30_{prec}'] = one_config('C3', single(50000, 30, prec, 0.99), 1, 50000, 30, prec,
                                                          'configs[2]: one recording, T=50 000, S=30 (two-level boundary walk)', short)
             for mode in ('shared', 'private'):
-                if mode == 'private' and prec == 'fp64':
+                if mode == 'private' and prec != 'fp32':
                     continue
                 configs[f'C5_T200k_S50_sweep9_{prec}_{mode}'] = one_config(
                     f'C5_{mode}', lambda mi, st, prec=prec, mode=mode: make_sweep_batch(ctx, 200000, 50, args.D, prec, mi, mode == 'shared'),
                     len(SWEEP_POINTS), 200000, 50, prec,
                     'configs[4]: T=200 000, S=50, loopProb=0.9, the nine (Fa, Fb) points of the recipes as ONE batch, '
                     + ('one rho shared by all points (vbx_batch_set_recording_shared)' if mode == 'shared'
-                       else 'every point with a private copy of the x-vectors (round 2)'), short)
+                       else 'every point with a private copy of the x-vectors (round 2)'), short,
+                    rho_copies=1 if mode == 'shared' else None)
+
+    other = None
+    if other_prec is not None and not args.no_split:
+        pko, dko, mso, _ = kernel_probe(lambda mi, st: headline(other_prec, mi, st), args.min_seconds / 4, args.max_blocks)
+        bo = headline(other_prec, budget, args.streams)
+        bo.run(W, -np.inf)
+        to = timed_blocks(bo, args.min_seconds / 2, args.max_blocks)
+        assert bo.gemm == ('split' if other_prec == 'fp32-split' else 'exact')
+        bo.close()
+        other = (to, pko, dko, mso)
 
     f64 = None
     if not args.no_f64 and args.precision == 'fp32':
@@ -396,7 +532,7 @@ def main():
 
     if rank == 0:
         total_units = world * args.batch * K
-        workload = {'batch': args.batch, 'T': args.T, 'S': args.S, 'D': args.D, 'precision': args.precision}
+        workload = {'batch': args.batch, 'T': args.T, 'S': args.S, 'D': args.D, 'precision': head_prec}
         roof, traffic = roofline_of(per_kernel, dom, args.batch, args.T, args.S, args.D, esize, workload)   # (profiled with --streams 1)
         roof['measured'] = (f'HIP events over {probe_blocks} block(s) of K steps (after W warm-up steps) of the same batch on ONE '
                             f'stream (VBX_OPT_STREAMS=1, {probe_ms_per_step:.4f} ms per step): a kernel-level figure needs the '
@@ -410,9 +546,10 @@ def main():
             'warmup': W,
             'ms_per_step': 1e3 * med / K,
             'higher_is_better': True,
-            'scaling': 'weak',
+            'scaling': 'strong' if args.total_recordings is not None else 'weak',
             'vs_baseline': None,
             'dtype': 'f32' if args.precision == 'fp32' else 'f64',
+            'gemm': (args.gemm if args.precision == 'fp32' else 'exact'),
             'data': 'synthetic',
             'config': {'workload': f'batch of {args.batch} recordings per GPU, each T={args.T} x-vectors, '
                                    f'R={args.D}, S={args.S} (BASELINE configs[3] batch; headline shape), '
@@ -447,6 +584,21 @@ def main():
             whole['pmc_bytes_per_step'] = traffic[2]['iteration_hbm_bytes']
             whole['pmc_over_fused_compulsory'] = traffic[2]['iteration_hbm_bytes'] / fused_bytes
         out['roofline_whole_iteration'] = whole
+        if other:
+            to, pko, dko, mso = other
+            mo = statistics.median(to)
+            roofo, _ = roofline_of(pko, dko, args.batch, args.T, args.S, args.D, 4, dict(workload, precision=other_prec))
+            key = 'f32_split' if other_prec == 'fp32-split' else 'f32_exact'
+            out[key] = {'value': total_units / mo, 'unit': 'recording-EM-iterations/s', 'ms_per_step': 1e3 * mo / K,
+                        'blocks_of_K_steps': len(to), 'roofline': roofo, 'one_stream_ms_per_step': mso,
+                        'kernels_avg_us': {k: round(v['avg_us'], 2) for k, v in pko.items()},
+                        'speedup_over_headline': med / mo,
+                        'note': ('same batch, fp32 storage and accumulation, the two GEMMs (rho alpha^T, gamma^T rho) on '
+                                 'v_mfma_f32_16x16x32_f16 with error-compensated f16 operand pairs (VBX_OPT_GEMM = split, '
+                                 'vbx_amd/csrc/vbx_split.hpp); parity against the reference under the bounds of the exact path: '
+                                 'tests/test_gpu_split.py, tests/test_gpu_configs.py [fp32-split], profiles/*config_parity.json')
+                                if other_prec == 'fp32-split' else
+                                'same batch with the exact f32 GEMMs (v_mfma_f32_16x16x4_f32)'}
         if f64:
             t64, pk64, dk64, ms64 = f64
             m64 = statistics.median(t64)
@@ -467,7 +619,7 @@ def main():
         if single_rec:
             out['single_recording'] = single_rec
         if world == 1 and args.cpu_iters > 0:
-            cb = cpu_baseline(args.T, args.S, args.D, args.cpu_iters, args.precision)
+            cb = cpu_baseline(args.T, args.S, args.D, args.cpu_iters, head_prec)
             out['cpu_baseline'] = cb
             if single_rec:
                 out['single_recording']['speedup_vs_cpu_baseline'] = single_rec['value'] / cb['value']

@@ -61,7 +61,7 @@ extern "C" {
                                    2*mask: only the kernel classes whose bit (1 << VBX_K_*) is set in mask */
 #define VBX_OPT_CHUNK_FRAMES 4  /* frames per scan chunk for VBX_FB_CHUNKED (0 = auto)         */
 #define VBX_OPT_SCAN_GROUP 6    /* chunks per group of the two-level boundary walk: 0 auto (sqrt(chunks / 5) once a
-                                   recording has >= 160 chunks, or >= 32 in a batch of <= 4), 1 flat chain, >= 2 explicit */
+                                   recording has >= 160 chunks, or >= 32 in a batch of <= 16), 1 flat chain, >= 2 explicit */
 #define VBX_OPT_SCAN_GROUP2 12   /* groups per level-2 group of the THREE-level walk: 0 auto (from 300 chunks per recording --
                                    T = 38 400 -- both group sizes become (chunks / 8)^(1/3) + 1), 1 off, >= 2 explicit (on top of
                                    the VBX_OPT_SCAN_GROUP in effect)                                                     */

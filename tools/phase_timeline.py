@@ -14,10 +14,10 @@ from vbx_amd import _capi  # noqa: E402
 from vbx_amd.synth import make_recording  # noqa: E402
 
 
-def main(nrec=64, T=10000, S=30, out='gpurun_out/phase_timeline.npy'):
+def main(nrec=64, T=10000, S=30, precision='fp32', out='gpurun_out/phase_timeline.npy'):
     ctx = _capi.Context(0)
     lib = _capi.load()
-    batch = _capi.Batch(ctx, [T] * nrec, [S] * nrec, 128, precision='fp32', max_iters=6)
+    batch = _capi.Batch(ctx, [T] * nrec, [S] * nrec, 128, precision=precision, max_iters=6)
     batch.set_option(_capi.OPT_STREAMS, 1)           # tile numbers index the stamp table: one stream group
     X, Phi, _ = make_recording(T, S, seed=1, kappa=0.05)
     g0 = np.random.default_rng(2).gamma(1.0, size=(T, S))
@@ -57,5 +57,5 @@ def main(nrec=64, T=10000, S=30, out='gpurun_out/phase_timeline.npy'):
 
 
 if __name__ == '__main__':
-    a = [int(v) for v in sys.argv[1:4]]          # [recordings T S]
-    main(*a) if a else main()
+    a = [int(v) for v in sys.argv[1:4]]          # [recordings T S [precision]]
+    main(*a, *sys.argv[4:5]) if a else main()

@@ -1,11 +1,17 @@
 #!/usr/bin/env python
 """Per-kernel averages of every PMC counter in a rocprofv3 rocpd database (``--pmc A B C ...`` pass).
 
-    python tools/pmc_counters.py <results.db> [out.txt]
+    python tools/pmc_counters.py <results.db> [out.txt [issue.json key=value ...]]
+
+With ``issue.json`` and the workload (the key=value words tools/profile_target.py prints) the pass is also condensed into
+the file bench.py reads for ``roofline.simd_issue``: per kernel the fractions of all SIMD cycles of a launch with a matrix
+instruction executing / a vector instruction issuing, stamped with the hash of the kernel sources like the PMC traffic files.
 
 Second half of the launches of each kernel only (the first ones include first-touch effects).  Ratios between SQ
 counters of one pass (e.g. SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES) are what they are good for; MI355X_MICROARCH.md
 ("rocprofv3 PMC slots") lists the units."""
+import json
+import os
 import re
 import sqlite3
 import sys
@@ -20,7 +26,7 @@ def short(name):
     return 'chunk_post_replay' if m.group(1) == 'chunk_post' and len(args) >= 3 and args[2] == 'true' else m.group(1)
 
 
-def main(path, out=None):
+def main(path, out=None, issue_out=None, *kv):
     db = sqlite3.connect(path)
     rows = db.execute('select name, counter_name, counter_value from pmc_events').fetchall()
     agg = {}
@@ -48,6 +54,7 @@ def main(path, out=None):
         lines.append('')
         lines.append('# kernel: MFMA-busy SIMD-cycles per launch, launch duration (us, under the profiler), MFMA utilisation of the')
         lines.append('# chip (busy / (1024 SIMDs x duration x 2.4 GHz)), issue activity of the resident waves (ACTIVE_INST_ANY / WAVE_CYCLES)')
+        issue = {}
         for k, d in sorted(agg.items()):
             v = d.get('SQ_VALU_MFMA_BUSY_CYCLES', [])
             launches = len(dur.get(k, [])) or 1
@@ -69,7 +76,20 @@ def main(path, out=None):
                 valu = (sum(va) / len(va)) * rows_per_launch * 4.0
                 vutil = valu / (1024 * us * 2400.0) if us > 0 else float('nan')
                 line += f'   valu_issue_simd_cycles {valu:14.0f}   valu_util {vutil:7.4f}   valu+mfma {vutil + util:7.4f}'
+                issue[k] = {'mfma_busy': util, 'valu_issue': vutil, 'duration_us_under_profiler': us, 'launches_profiled': launches}
             lines.append(line)
+        if issue_out and issue:
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            from vbx_amd.build import iteration_source_hash
+            workload = {}
+            for item in kv:
+                key, val = item.split('=', 1)
+                workload[key] = int(val) if val.lstrip('-').isdigit() else val
+            with open(issue_out, 'w') as fh:
+                json.dump({'workload': workload, 'kernels': issue, 'iteration_source_sha16': iteration_source_hash(),
+                           'source': 'rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU ... (one pass); mfma_busy = busy '
+                                     'cycles / (1024 SIMDs x duration x 2.4 GHz), valu_issue = 4 x SQ_ACTIVE_INST_VALU / the same'},
+                          fh, indent=1, sort_keys=True)
     text = '\n'.join(lines) + '\n'
     if out:
         open(out, 'w').write(text)
@@ -77,4 +97,4 @@ def main(path, out=None):
 
 
 if __name__ == '__main__':
-    main(*sys.argv[1:3])
+    main(*sys.argv[1:])

@@ -613,7 +613,7 @@ int choose_fb_algo(vbx_batch* b, bool step_api_logs) {
     // two-level walk over the chunk boundaries once the flat chain gets long
     int group = 1;
     if (chunked && b->Sp <= 64) {            // (the wide scan walks the flat chain)
-        // a handful of recordings: the walk is exposed (nothing else to fill the GPU with), and groups of four cut its
+        // up to 16 recordings: the walk is exposed (nothing else to fill the GPU with), and groups of four cut its
         // dependent chain from K to K/4 + 4 + 4 steps (T = 10 000, one recording: 28 -> 19 us per iteration); many
         // recordings: the three launches of the two-level walk cost more than they save until the chain is long
         // Group size: a composition step (S x S times S x S) costs about four walk steps, so the chain
@@ -622,7 +622,9 @@ int choose_fb_algo(vbx_batch* b, bool step_api_logs) {
         // 185/216/253 us; T = 50 000 (K = 391): g = 8/12/16/24 -> 35/37/41/51 us.
         const int g_auto = std::max(4, (int)std::lround(std::sqrt((double)maxchunks / 5.0)));
         if (b->scan_group >= 2) group = b->scan_group;
-        else if (b->scan_group == 0 && (maxchunks >= b->two_level_from || (b->n_rec <= 4 && maxchunks >= 32)))
+        // (round 4, 8 / 16 / 24 / 32 / 64 recordings of T = 10 000 on one stream, groups of 4 against the flat chain: walk
+        //  25.3 -> 20.5 / 21.6 / 22.5 / 25.4 / 32.5 us, iteration 73.7 -> 69.1, 95.7 -> 90.0, then no gain: up to 16 recordings)
+        else if (b->scan_group == 0 && (maxchunks >= b->two_level_from || (b->n_rec <= 16 && maxchunks >= 32)))
             group = g_auto;
     }
     // Third level: with products worth ~4 walk steps the chain 4 (g - 1) + 4 (g2 - 1) + K / (g g2) + g2 + g is shortest

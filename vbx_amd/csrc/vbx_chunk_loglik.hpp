@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? (SPLIT && SP == 
         else epilogue(std::false_type{});
     }
     VBX_STAMP();
-    __syncthreads();
+    lds_barrier();                 // (phase 2 reads the LDS copy of b; the stores of b and of the row maxima drain meanwhile)
     VBX_STAMP();
 
     // ---- phase 2: transfer operators, one column per group of PH lanes (vbx_operator.hpp) ------------------------------
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? (SPLIT && SP == 
             using M = Mfma16<R>;
             R* const Fl = lds;
             R* const Wt = lds + SP * SP;
-            __syncthreads();                               // every column is built: b is dead
+            lds_barrier();                               // every column is built: b is dead
             const bool holds_p2 = builder && (kSideBySide ? my_half == 1 : true);
             const bool holds_p1 = builder && my_half == 0;
             if (holds_p2) {
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? (SPLIT && SP == 
                     if (part == 0) eF[colbase + k * CS] = expo[kSideBySide ? 0 : 1][k];
                 }
             }
-            __syncthreads();
+            lds_barrier();
             if (holds_p1) {
 #pragma unroll
                 for (int k = 0; k < NC; ++k) {
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? (SPLIT && SP == 
                     if (part == 0) eW[col] = alive ? expo[0][k] + top : kNoMass;
                 }
             }
-            __syncthreads();
+            lds_barrier();
             if (wave < NT) {
                 using acc_t = typename M::acc_t;
                 const int ci = 16 * wave + i;              // my column of P (i = lane & 15, g = lane >> 4)

@@ -98,7 +98,12 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
     __shared__ double red[16];
     __shared__ R nsum_w[SPLIT ? 4 : 1][SP];            // SPLIT: sum of gamma per wave and speaker (taken from registers)
 
-    const int tile = tile_of_block(bt, blockIdx.x);
+    // (without a table the tiles are taken from the last one down: chunk_loglik has just written b and the half-tile operators
+    //  front to back, so the ones written last -- still in the memory-side cache -- are read first; VBX_POST_REVERSE=0: A/B)
+#ifndef VBX_POST_REVERSE
+#define VBX_POST_REVERSE 1
+#endif
+    const int tile = (VBX_POST_REVERSE && !REPLAY && !bt.tile_order) ? bt.ntiles_total - 1 - (int)blockIdx.x : tile_of_block(bt, blockIdx.x);
     if (tile < 0 || (!REPLAY && bt.tile_done[tile])) return;
     VBX_CLOCKS_DECL();
     // (the wave index as a scalar: roles, frame ranges and loop bounds of the re-run stay in SGPRs)
@@ -477,7 +482,7 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
         };
         // SPLIT: the B operand comes from rho_b, [slab][h][kk][hi | lo][lane] in 16-byte fragments (vbx_split.hpp): per
         // k-step of 32 frames a wave fetches the four fragments of its slab, one contiguous KB per load instruction
-        h8 bs[2][2][2];                                          // [buffer][h][hi | lo]
+        h8 bs[4][2][2];                                          // [k-step][h][hi | lo]: a wave's whole slab (64 registers)
         const h8* __restrict__ rb = nullptr;
         if constexpr (SPLIT) {
             const RecDesc& rdd = bt.recs[rec];
@@ -648,8 +653,18 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
             }
             // iter_fin needs the responsibilities of frame 0 (VBx.py:102)
             if (chunk0 && wave == 0 && g4 == 0) store_pack<NREG>(bt.gamma0 + (long long)rec * SP + so, gam[0]);
+            if constexpr (SPLIT) {
+                // the other three k-steps of the wave's slab go into flight together, now that the registers of the posterior
+                // pass are free: ONE exposed round trip in the accumulation instead of three (phase stamps, 64 recordings:
+                // the accumulation phase was 11.6 k of a workgroup's 41 k cycles, all of it waiting for these loads one
+                // k-step at a time)
+                if (wave * 32 < Dp) {
+#pragma unroll
+                    for (int kk = 1; kk < 4; ++kk) load_kstep(kk, wave, kk);
+                }
+            }
         }
-        __syncthreads();
+        lds_barrier();                 // (gamma and the sums meet in LDS; the partial sums stored above and the loads in flight need no wait)
         VBX_STAMP();
 
         // ---- next M-step: C[s][d] = sum_t gamma[t][s] rho[t][d] on MFMA 16x16x4        (VBx.py:96) --
@@ -666,15 +681,17 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
                     acc[mu][0] = acc_t{0, 0, 0, 0};
                     acc[mu][1] = acc_t{0, 0, 0, 0};
                 }
-                if (slab != wave) load_kstep(0, slab, 0);
+                if (slab != wave) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) load_kstep(kk, slab, kk);
+                }
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    if (kk < 3) load_kstep((kk + 1) & 1, slab, kk + 1);
 #pragma unroll
                     for (int mu = 0; mu < NT; ++mu) {
                         const h8 ah = gfr[(mu * 4 + kk) * 128 + lane], al = gfr[(mu * 4 + kk) * 128 + 64 + lane];
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) acc[mu][h] = mfma_split(ah, al, bs[kk & 1][h][0], bs[kk & 1][h][1], acc[mu][h]);
+                        for (int h = 0; h < 2; ++h) acc[mu][h] = mfma_split(ah, al, bs[kk][h][0], bs[kk][h][1], acc[mu][h]);
                     }
                 }
                 R* __restrict__ part = bt.mpart + (long long)tile * SP * Dp;

@@ -275,6 +275,17 @@ struct ScaledProduct {
     }
 };
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope release / acquire over ALL address
+// spaces: with a global store behind it the compiler must emit s_waitcnt vmcnt(0) before the s_barrier -- and vmcnt counts
+// loads too, so every global load a wave has in flight for a LATER phase is waited for at the barrier (chunk_post: the rho
+// fragments requested ahead of the accumulation; chunk_loglik: the stores of b draining into HBM while the operators are
+// built from the LDS copy).  Where the phases on either side of a barrier exchange data through LDS only, this is the one to use.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // Block-wide sum of one double per thread through LDS (blockDim.x multiple of 64, <= 1024).
 __device__ __forceinline__ double block_sum(double v, double* lds /* >= 16 doubles */) {
     v = allreduce_sum<64>(v);
