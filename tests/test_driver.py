@@ -377,12 +377,13 @@ def test_device_stages_against_what_the_reference_driver_computed(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('kind', ['cosine', 'ties', 'es2005a'])
-def test_device_linkage_is_the_host_linkage_bit_for_bit(kind):
-    """vbx_scores_linkage_average (nearest-neighbour chain walked by one workgroup on the score matrix in HBM) against
-    vbx_linkage_average on the condensed matrix the device hands out (itself SciPy's linkage bit for bit, see below):
-    same merges, same numbering, same distances to the last bit -- random cosine similarities, similarities with
-    massive exact ties (few distinct integer-valued x-vectors), the example recording."""
+def test_device_linkage_is_the_host_linkage_bit_for_bit(kind, monkeypatch):
+    """vbx_scores_linkage_average in its CHAIN form (VBX_AMD_LINKAGE_DEVICE=chain: the nearest-neighbour chain walked by one
+    workgroup on the score matrix in HBM) against vbx_linkage_average on the condensed matrix the device hands out (itself
+    SciPy's linkage bit for bit, see below): same merges, same numbering, same distances to the last bit -- random cosine
+    similarities, similarities with massive exact ties (few distinct integer-valued x-vectors), the example recording."""
     from vbx_amd import _capi
+    monkeypatch.setenv('VBX_AMD_LINKAGE_DEVICE', 'chain')
     ctx = _capi.default_context()
     rng = np.random.default_rng(11)
     xs = []
@@ -404,6 +405,66 @@ def test_device_linkage_is_the_host_linkage_bit_for_bit(kind):
         want = _capi.linkage_average(cond)
         assert got.shape == want.shape and np.array_equal(got, want), (kind, n, np.argwhere(got != want)[:3])
         assert np.array_equal(np.signbit(got), np.signbit(want))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['cosine', 'clustered', 'ties', 'es2005a'])
+def test_device_linkage_in_rounds_of_reciprocal_pairs(kind, monkeypatch):
+    """The default device linkage from 1024 clusters on: ALL reciprocal nearest-neighbour pairs merged per round by the whole
+    chip (vbx_ahc.hpp, rnn_*), the chain finishing the last few hundred clusters.  Average linkage is reducible, so the
+    merges are the chain's; only the order in which a cluster's updates meet differs.  Against the chain form (= the host
+    routine = SciPy, bit for bit):
+      * distinct distances (cosine, clustered speakers, the example recording): the SAME tree -- identical children and
+        sizes in every row of Z -- and heights within 16 ulp (measured: 8); identical flat clusters at any threshold;
+      * massive exact ties: a valid average-linkage dendrogram of the input (every height = the mean pairwise distance of
+        the two merged clusters), and identical flat clusters at thresholds that do not fall on a tied height."""
+    from vbx_amd import _capi
+    ctx = _capi.default_context()
+    rng = np.random.default_rng(17)
+    xs = []
+    if kind == 'cosine':
+        xs = [rng.standard_normal((n, 16)) for n in (1024, 1500, 4097, 9001)]
+    elif kind == 'clustered':
+        for n, k in ((3000, 6), (10000, 9)):                                        # speakers: tight groups, like real x-vectors
+            centres = rng.standard_normal((k, 32))
+            xs.append(centres[rng.integers(0, k, n)] + 0.35 * rng.standard_normal((n, 32)))
+    elif kind == 'ties':
+        for n in (1200, 2500):
+            base = rng.integers(-1, 2, size=(6, 8)).astype(float) + 0.5
+            xs.append(base[rng.integers(0, 6, n)])
+    else:
+        xv = np.load(GOLD)['xvecs'].astype(np.float64)
+        xs = [xv, np.concatenate([xv, xv[::-1] * 1.0001 + 1e-3 * rng.standard_normal(xv.shape)])]    # 1025, 2050
+    for x in xs:
+        n = len(x)
+        monkeypatch.setenv('VBX_AMD_LINKAGE_DEVICE', 'rounds')
+        sc = _capi.Scores.cos_similarity(ctx, x)
+        cond = sc.get_condensed(n, -1.0)
+        got = sc.linkage_average(n)
+        sc.close()
+        monkeypatch.setenv('VBX_AMD_LINKAGE_DEVICE', 'chain')
+        sc = _capi.Scores.cos_similarity(ctx, x)
+        want = sc.linkage_average(n)
+        sc.close()
+        assert got.shape == want.shape == (n - 1, 4)
+        assert np.all(np.diff(got[:, 2]) >= 0) and np.array_equal(got[:, 3][-1:], [n])
+        if kind != 'ties':
+            assert np.array_equal(got[:, [0, 1, 3]], want[:, [0, 1, 3]]), (kind, n, np.argwhere(got[:, [0, 1, 3]] != want[:, [0, 1, 3]])[:3])
+            ulp = np.spacing(np.abs(want[:, 2]))
+            # (a height is a chain of weighted means whose association order differs between the two forms: measured <= 8 ulp)
+            # (... of the height, or of the distances it is a mean of where positive and negative ones cancel: |d| <= 1)
+            assert np.all(np.abs(got[:, 2] - want[:, 2]) <= np.maximum(16 * ulp, 1e-15)), (kind, n, np.max(np.abs(got[:, 2] - want[:, 2]) / ulp))
+            cuts = np.quantile(want[:, 2], [0.2, 0.5, 0.8, 0.95, 0.99])
+        else:
+            if n <= 1500:
+                _upgma_check(cond, got)
+            levels = np.unique(np.round(want[:, 2], 9))
+            cuts = (levels[:-1] + levels[1:]) / 2                                    # between two tied heights
+            cuts = cuts[:: max(1, len(cuts) // 6)]
+        for t in cuts:
+            a, b = _capi.fcluster_distance(got, float(t)), _capi.fcluster_distance(want, float(t))
+            # the same partition (cluster numbers follow the tree walk, which ties may order differently)
+            assert len(set(zip(a.tolist(), b.tolist()))) == len(set(a.tolist())) == len(set(b.tolist())), (kind, n, t)
 
 
 def _upgma_check(y, Z):

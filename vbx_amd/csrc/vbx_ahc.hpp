@@ -205,6 +205,30 @@ __global__ __launch_bounds__(256) void linkage_prepare_kernel(double* __restrict
 
 struct ChainMergeDev { int a, b; double d; };          // same layout as vbx::ChainMerge of the host code
 
+// (value, index) arg-min over the 64 lanes of a wavefront, the lowest index winning ties; every lane gets the result.
+// DPP row operations and permlane swaps -- not __shfl_xor, i.e. ds_bpermute_b32 (vbx_device.hpp, add_xor).
+__device__ __forceinline__ void argmin_pair(double& m, int& mi, double ov, int oi) {
+    if (ov < m || (ov == m && oi < mi)) { m = ov; mi = oi; }
+}
+__device__ __forceinline__ void argmin_allreduce64(double& m, int& mi) {
+    argmin_pair(m, mi, dpp_mov<0xB1>(m), dpp_mov<0xB1>(mi));
+    argmin_pair(m, mi, dpp_mov<0x4E>(m), dpp_mov<0x4E>(mi));
+    argmin_pair(m, mi, dpp_mov<0x141>(m), dpp_mov<0x141>(mi));
+    argmin_pair(m, mi, dpp_mov<0x140>(m), dpp_mov<0x140>(mi));
+    {
+        double ma, mb;
+        int ia, ib;
+        cross_rows<16>(m, ma, mb);
+        cross_rows<16>(mi, ia, ib);
+        m = ma; mi = ia;
+        argmin_pair(m, mi, mb, ib);
+        cross_rows<32>(m, ma, mb);
+        cross_rows<32>(mi, ia, ib);
+        m = ma; mi = ia;
+        argmin_pair(m, mi, mb, ib);
+    }
+}
+
 // (n_a d_a + n_b d_b) / (n_a + n_b) with every operation rounded on its own, as SciPy and the host code compute it
 // (hipcc contracts a * b + c into a fused multiply-add by default, also through __dmul_rn / __dadd_rn)
 __device__ __forceinline__ double average_update(double fa, double da, double fb, double db, double fs) {
@@ -287,12 +311,7 @@ __global__ __launch_bounds__(1024) void nn_chain_kernel(double* __restrict__ D, 
                     if (w < m) { m = w; mi = i; }
                 }
             }
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const double ov = __shfl_xor(m, off, 64);
-                const int oi = __shfl_xor(mi, off, 64);
-                if (ov < m || (ov == m && oi < mi)) { m = ov; mi = oi; }
-            }
+            argmin_allreduce64(m, mi);
             if (lane == 0) { wmin[wave] = m; widx[wave] = mi; }
             __syncthreads();
             if (tid == 0) {
@@ -387,12 +406,8 @@ __global__ __launch_bounds__(1024) void linkage_compact_index_kernel(int n, cons
     for (int base = 0; base < n; base += 1024) {
         const int i = base + tid;
         const int live = (i < n && size[i] > 0) ? 1 : 0;
-        int incl = live;                                     // inclusive prefix sum inside the wave
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int v = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += v;
-        }
+        // inclusive prefix count inside the wave from the ballot (no shuffles: vbx_device.hpp, add_xor)
+        const int incl = __popcll(__ballot(live) & ((2ull << lane) - 1ull));
         if (lane == 63) wsum[wave] = incl;
         __syncthreads();
         int before = carry;
@@ -420,6 +435,163 @@ __global__ __launch_bounds__(256) void linkage_compact_matrix_kernel(const doubl
     const double* __restrict__ src = D1 + (long long)old_of_new[r] * n1;
     double* __restrict__ dst = D2 + (long long)r * n2;
     for (int c = threadIdx.x; c < n2; c += 256) dst[c] = src[old_of_new[c]];
+}
+
+// ---- rounds of reciprocal nearest neighbours: the whole chip on one recording ---------------------------------------------
+// Average linkage is reducible: two clusters that are each other's nearest neighbour stay so whatever else is merged, so
+// ALL reciprocal pairs of the current matrix can be merged at once (the nearest-neighbour chain finds the same pairs one
+// after the other).  A round =
+//   rnn_rowmin   one workgroup per live row: nearest live neighbour, the lowest index among equals
+//   rnn_pairs    one workgroup: the reciprocal pairs (a < b, nn[a] == b, nn[b] == a) in index order -> the merge list;
+//                with lowest-index ties the globally smallest pair is always reciprocal, so every round merges something
+//   rnn_rows     one workgroup per pair: row b <- (n_a row a + n_b row b) / (n_a + n_b)   (b keeps the merged cluster)
+//   rnn_cols     one workgroup per live row x, merged rows included: D[x][b] <- (n_a D[x][a] + n_b D[x][b]) / (n_a + n_b) for
+//                every pair -- the same operations on the same numbers as row b got, so row b and column b agree bit for
+//                bit wherever x is not itself a merged row; between two merged rows the two orders of association differ
+//                in the last bits, and
+//   rnn_canon    makes the row of the smaller index the one value of both entries (the matrix stays exactly symmetric:
+//                the nearest-neighbour relation the next round reads must be the same from both sides)
+//   rnn_sizes    a dies, b takes both sizes.
+// Same update formula, operation for operation, as the chain (average_update); only the ORDER in which a cluster's merges
+// meet differs from the chain's, i.e. heights agree to a few ulp and the tree is the same wherever distances are distinct
+// (tests/test_driver.py).  One recording of 10 000 x-vectors: a few dozen rounds instead of 30 000 dependent row scans.
+struct RnnPair { int a, b, na, nb; };
+
+__global__ __launch_bounds__(256) void rnn_rowmin_kernel(const double* __restrict__ D, int n, const int* __restrict__ size,
+                                                          int* __restrict__ nn, double* __restrict__ nnd) {
+    __shared__ double wm[4];
+    __shared__ int wi[4];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    if (size[i] == 0) {
+        if (tid == 0) nn[i] = -1;
+        return;
+    }
+    const double inf = (double)INFINITY;
+    const double* __restrict__ row = D + (long long)i * n;
+    double m = inf;
+    int mi = 0x7fffffff;
+    constexpr int U = 8;
+    for (int j0 = tid; j0 < n; j0 += U * 256) {
+        double v[U];
+        int live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = min(j0 + u * 256, n - 1);
+            v[u] = row[j];
+            live[u] = size[j];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * 256;
+            const double w = (j < n && live[u] > 0) ? v[u] : inf;          // (the diagonal holds +inf)
+            if (w < m) { m = w; mi = j; }                                    // (ascending j per thread: the lowest index stays)
+        }
+    }
+    argmin_allreduce64(m, mi);
+    if ((tid & 63) == 0) { wm[tid >> 6] = m; wi[tid >> 6] = mi; }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w) argmin_pair(m, mi, wm[w], wi[w]);
+        nn[i] = mi < n ? mi : -1;
+        nnd[i] = m;
+    }
+}
+
+// state[2] = merges so far, state[3] = pairs of this round; role[x] = 0 untouched, 1 dies (a), 2 merged row (b)
+__global__ __launch_bounds__(1024) void rnn_pairs_kernel(int n, const int* __restrict__ size, const int* __restrict__ orig,
+                                                         const int* __restrict__ nn, const double* __restrict__ nnd,
+                                                         RnnPair* __restrict__ pairs, int* __restrict__ role,
+                                                         ChainMergeDev* __restrict__ merges, int* __restrict__ state) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k0 = state[2];
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        int j = -1;
+        if (i < n && size[i] > 0) {
+            j = nn[i];
+            if (!(j > i && nn[j] == i)) j = -1;              // (the pair is recorded by its smaller index)
+        }
+        const int hit = j >= 0 ? 1 : 0;
+        // inclusive prefix count inside the wave from the ballot (no shuffles: vbx_device.hpp, add_xor)
+        const int incl = __popcll(__ballot(hit) & ((2ull << lane) - 1ull));
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int before = carry;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        if (i < n) role[i] = 0;
+        __syncthreads();                                     // (roles are cleared before any pair of this block sets one)
+        if (hit) {
+            const int p = before + incl - 1;
+            pairs[p] = RnnPair{i, j, size[i], size[j]};
+            merges[k0 + p] = ChainMergeDev{orig[i], orig[j], nnd[i]};
+        }
+        __syncthreads();
+        if (tid == 1023) carry = before + incl;
+        __syncthreads();
+    }
+    __syncthreads();
+    const int np = carry;
+    for (int p = tid; p < np; p += 1024) {                   // (after every role has been cleared)
+        role[pairs[p].a] = 1;
+        role[pairs[p].b] = 2;
+    }
+    if (tid == 0) {
+        state[3] = np;
+        state[2] = k0 + np;
+    }
+}
+
+// grid = pairs of the round
+__global__ __launch_bounds__(256) void rnn_rows_kernel(double* __restrict__ D, int n, const int* __restrict__ size,
+                                                        const RnnPair* __restrict__ pairs) {
+    const RnnPair pr = pairs[blockIdx.x];
+    const double fa = (double)pr.na, fb = (double)pr.nb, fs = (double)(pr.na + pr.nb);
+    const double* __restrict__ ra = D + (long long)pr.a * n;
+    double* __restrict__ rb = D + (long long)pr.b * n;
+    for (int k = threadIdx.x; k < n; k += 256) {
+        if (k == pr.a || k == pr.b || size[k] == 0) continue;
+        rb[k] = average_update(fa, ra[k], fb, rb[k], fs);
+    }
+}
+
+// grid = rows of the matrix (dead and dying rows leave at once)
+__global__ __launch_bounds__(256) void rnn_cols_kernel(double* __restrict__ D, int n, const int* __restrict__ size,
+                                                        const int* __restrict__ role, const RnnPair* __restrict__ pairs,
+                                                        const int* __restrict__ state) {
+    const int x = blockIdx.x;
+    if (size[x] == 0 || role[x] == 1) return;
+    const int np = state[3];
+    double* __restrict__ row = D + (long long)x * n;
+    for (int p = threadIdx.x; p < np; p += 256) {
+        const RnnPair pr = pairs[p];
+        if (pr.b == x) continue;                             // (its own pair: the diagonal)
+        row[pr.b] = average_update((double)pr.na, row[pr.a], (double)pr.nb, row[pr.b], (double)(pr.na + pr.nb));
+    }
+}
+
+// grid = pairs: the entries between two merged rows take the value the row of the smaller index holds
+__global__ __launch_bounds__(256) void rnn_canon_kernel(double* __restrict__ D, int n, const RnnPair* __restrict__ pairs,
+                                                         const int* __restrict__ state) {
+    const int np = state[3];
+    const int b = pairs[blockIdx.x].b;
+    for (int q = threadIdx.x; q < np; q += 256) {
+        const int b2 = pairs[q].b;
+        if (b2 > b) D[(long long)b2 * n + b] = D[(long long)b * n + b2];
+    }
+}
+
+__global__ __launch_bounds__(256) void rnn_sizes_kernel(int* __restrict__ size, const RnnPair* __restrict__ pairs,
+                                                         const int* __restrict__ state) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= state[3]) return;
+    const RnnPair pr = pairs[p];
+    size[pr.a] = 0;
+    size[pr.b] = pr.na + pr.nb;
 }
 
 }  // namespace vbx

@@ -2425,27 +2425,40 @@ int vbx_scores_linkage_average(vbx_scores* sc, int64_t T, double* Z) {
     if (T == 1) return VBX_OK;
     vbx_ctx* ctx = sc->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    // stages of n/4 merges with a compaction of the live rows and columns in between (vbx_ahc.hpp); below kStageMin
-    // clusters the rest runs in one stage (there a merge costs its four round trips, not the bytes of a row)
+    // Two ways over the matrix (vbx_ahc.hpp):
+    //   rounds  all reciprocal nearest-neighbour pairs of the current matrix merged at once, the whole chip on every pass
+    //           (VBX_AMD_LINKAGE_DEVICE=rounds, the default from kRoundsFrom clusters): a few dozen rounds for 10 000 x-vectors
+    //   chain   SciPy's nearest-neighbour chain on ONE persistent workgroup, bit for bit the host routine (=chain): it
+    //           finishes what the rounds leave (the last few hundred clusters, where a round is all launch latency) and is
+    //           the reference the rounds are tested against
+    // The chain runs in stages of n/4 merges with a compaction of the live rows and columns in between; below kStageMin
+    // clusters the rest runs in one stage (there a merge costs its four round trips, not the bytes of a row).
     static const long long kStageMin = [] { const char* e = getenv("VBX_AMD_LINKAGE_STAGE_MIN"); const long long v = e ? atoll(e) : 0; return v >= 64 ? v : 4096LL; }();
     static const bool staged = [] { const char* e = getenv("VBX_AMD_LINKAGE_STAGES"); return !(e && e[0] == '0'); }();
+    const char* dev_mode = getenv("VBX_AMD_LINKAGE_DEVICE");           // (read per call: tests compare the two in one process)
+    const bool rounds_on = !(dev_mode && std::strcmp(dev_mode, "chain") == 0);
+    static const long long kRoundsFrom = [] { const char* e = getenv("VBX_AMD_LINKAGE_ROUNDS_FROM"); const long long v = e ? atoll(e) : 0; return v >= 4 ? v : 1024LL; }();
+    static const long long kRoundsStop = [] { const char* e = getenv("VBX_AMD_LINKAGE_ROUNDS_STOP"); const long long v = e ? atoll(e) : 0; return v >= 2 ? v : 384LL; }();
     int *d_size = nullptr, *d_size2 = nullptr, *d_chain = nullptr, *d_orig = nullptr, *d_orig2 = nullptr, *d_old = nullptr,
-        *d_newidx = nullptr, *d_state = nullptr;
-    double* d_alt = nullptr;
+        *d_newidx = nullptr, *d_state = nullptr, *d_nn = nullptr, *d_role = nullptr;
+    double *d_alt = nullptr, *d_cmp = nullptr, *d_nnd = nullptr;
     vbx::ChainMergeDev* d_merges = nullptr;
-    const bool stages = staged && T >= 2 * kStageMin;
-    const long long n_alt = stages ? T - T / 4 : 0;
+    vbx::RnnPair* d_pairs = nullptr;
+    const bool rounds = rounds_on && T >= kRoundsFrom;
     int rc = dmalloc(ctx, &d_size, (size_t)T);
     if (rc == VBX_OK) rc = dmalloc(ctx, &d_chain, (size_t)T);
     if (rc == VBX_OK) rc = dmalloc(ctx, &d_orig, (size_t)T);
     if (rc == VBX_OK) rc = dmalloc(ctx, &d_state, (size_t)4);
     if (rc == VBX_OK) rc = dmalloc(ctx, &d_merges, (size_t)(T - 1));
-    if (rc == VBX_OK && stages) {
-        rc = dmalloc(ctx, &d_size2, (size_t)T);
-        if (rc == VBX_OK) rc = dmalloc(ctx, &d_orig2, (size_t)T);
-        if (rc == VBX_OK) rc = dmalloc(ctx, &d_old, (size_t)T);
-        if (rc == VBX_OK) rc = dmalloc(ctx, &d_newidx, (size_t)T);
-        if (rc == VBX_OK) rc = dmalloc(ctx, &d_alt, (size_t)(n_alt * n_alt));
+    if (rc == VBX_OK) rc = dmalloc(ctx, &d_size2, (size_t)T);
+    if (rc == VBX_OK) rc = dmalloc(ctx, &d_orig2, (size_t)T);
+    if (rc == VBX_OK) rc = dmalloc(ctx, &d_old, (size_t)T);
+    if (rc == VBX_OK) rc = dmalloc(ctx, &d_newidx, (size_t)T);
+    if (rc == VBX_OK && rounds) {
+        rc = dmalloc(ctx, &d_nn, (size_t)T);
+        if (rc == VBX_OK) rc = dmalloc(ctx, &d_nnd, (size_t)T);
+        if (rc == VBX_OK) rc = dmalloc(ctx, &d_role, (size_t)T);
+        if (rc == VBX_OK) rc = dmalloc(ctx, &d_pairs, (size_t)(T / 2 + 1));
     }
     std::vector<vbx::ChainMerge> merges((size_t)(T - 1));
     static_assert(sizeof(vbx::ChainMerge) == sizeof(vbx::ChainMergeDev), "merge record layout");
@@ -2461,33 +2474,73 @@ int vbx_scores_linkage_average(vbx_scores* sc, int64_t T, double* Z) {
         if (e == hipSuccess) e = hipStreamSynchronize(st);                 // (the host vectors go out of scope below)
         if (e == hipSuccess) {
             hipLaunchKernelGGL(vbx::linkage_prepare_kernel, dim3((unsigned)T), dim3(256), 0, st, sc->d_s, (long long)T);
-            double *cur = sc->d_s, *alt = d_alt;
+            double* cur = sc->d_s;
             int *size_c = d_size, *size_a = d_size2, *orig_c = d_orig, *orig_a = d_orig2;
             long long n_cur = T, done = 0;
-            while (done < T - 1) {
-                const long long remaining = T - 1 - done;
-                const long long m = (stages && n_cur >= 2 * kStageMin) ? std::min(remaining, n_cur / 4) : remaining;
-                hipLaunchKernelGGL(vbx::nn_chain_kernel, dim3(1), dim3(1024), 0, st, cur, (int)n_cur, size_c, d_chain, orig_c,
-                                   d_state, d_merges, (int)done, (int)(done + m));
-                done += m;
-                if (done < T - 1) {                                        // the live clusters move up, in order
-                    const long long n_new = n_cur - m;
-                    hipLaunchKernelGGL(vbx::linkage_compact_index_kernel, dim3(1), dim3(1024), 0, st, (int)n_cur, size_c, orig_c,
-                                       d_chain, d_state, size_a, orig_a, d_old, d_newidx);
-                    hipLaunchKernelGGL(vbx::linkage_compact_matrix_kernel, dim3((unsigned)n_new), dim3(256), 0, st, cur, (int)n_cur,
-                                       alt, (int)n_new, d_old);
-                    std::swap(cur, alt);
-                    std::swap(size_c, size_a);
-                    std::swap(orig_c, orig_a);
-                    n_cur = n_new;
+            auto compact_into = [&](double* dst, long long n_new) {       // the live clusters move up, in order
+                hipLaunchKernelGGL(vbx::linkage_compact_index_kernel, dim3(1), dim3(1024), 0, st, (int)n_cur, size_c, orig_c,
+                                   d_chain, d_state, size_a, orig_a, d_old, d_newidx);
+                hipLaunchKernelGGL(vbx::linkage_compact_matrix_kernel, dim3((unsigned)n_new), dim3(256), 0, st, cur, (int)n_cur,
+                                   dst, (int)n_new, d_old);
+                std::swap(size_c, size_a);
+                std::swap(orig_c, orig_a);
+                n_cur = n_new;
+            };
+            if (rounds) {
+                // rounds of reciprocal pairs on the matrix as it lies (dead rows and columns are skipped, not removed: a
+                // round reads n_live x n entries), until few clusters are left or a round hardly merges anything
+                int stalled = 0;
+                while (e == hipSuccess && T - done > kRoundsStop && stalled < 3) {
+                    const int n = (int)T;
+                    hipLaunchKernelGGL(vbx::rnn_rowmin_kernel, dim3((unsigned)n), dim3(256), 0, st, cur, n, size_c, d_nn, d_nnd);
+                    hipLaunchKernelGGL(vbx::rnn_pairs_kernel, dim3(1), dim3(1024), 0, st, n, size_c, orig_c, d_nn, d_nnd, d_pairs,
+                                       d_role, d_merges, d_state);
+                    int st_host[4] = {0, 0, 0, 0};
+                    e = hipMemcpyAsync(st_host, d_state, sizeof st_host, hipMemcpyDeviceToHost, st);
+                    if (e == hipSuccess) e = hipStreamSynchronize(st);
+                    if (e != hipSuccess) break;
+                    const int np = st_host[3];
+                    if (np <= 0) break;                                    // (cannot happen: the smallest pair is reciprocal)
+                    hipLaunchKernelGGL(vbx::rnn_rows_kernel, dim3((unsigned)np), dim3(256), 0, st, cur, n, size_c, d_pairs);
+                    hipLaunchKernelGGL(vbx::rnn_cols_kernel, dim3((unsigned)n), dim3(256), 0, st, cur, n, size_c, d_role, d_pairs, d_state);
+                    hipLaunchKernelGGL(vbx::rnn_canon_kernel, dim3((unsigned)np), dim3(256), 0, st, cur, n, d_pairs, d_state);
+                    hipLaunchKernelGGL(vbx::rnn_sizes_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, size_c, d_pairs, d_state);
+                    stalled = ((long long)np * 64 < T - done) ? stalled + 1 : 0;
+                    done = st_host[2];
+                }
+                if (e == hipSuccess && done < T - 1) {                     // what is left goes to the chain, compacted
+                    const long long n_new = T - done;
+                    rc = dmalloc(ctx, &d_cmp, (size_t)(n_new * n_new));
+                    if (rc == VBX_OK) {
+                        compact_into(d_cmp, n_new);
+                        cur = d_cmp;
+                    }
                 }
             }
-            e = hipGetLastError();
+            if (rc == VBX_OK && e == hipSuccess && done < T - 1) {
+                const bool stages = staged && n_cur >= 2 * kStageMin;
+                const long long n_alt = stages ? n_cur - n_cur / 4 : 0;
+                if (stages) rc = dmalloc(ctx, &d_alt, (size_t)(n_alt * n_alt));
+                double* alt = d_alt;
+                while (rc == VBX_OK && done < T - 1) {
+                    const long long remaining = T - 1 - done;
+                    const long long m = (stages && n_cur >= 2 * kStageMin) ? std::min(remaining, n_cur / 4) : remaining;
+                    hipLaunchKernelGGL(vbx::nn_chain_kernel, dim3(1), dim3(1024), 0, st, cur, (int)n_cur, size_c, d_chain, orig_c,
+                                       d_state, d_merges, (int)done, (int)(done + m));
+                    done += m;
+                    if (done < T - 1) {
+                        compact_into(alt, n_cur - m);
+                        std::swap(cur, alt);
+                    }
+                }
+            }
+            if (e == hipSuccess) e = hipGetLastError();
         }
-        if (e == hipSuccess) e = hipMemcpyAsync(merges.data(), d_merges, sizeof(vbx::ChainMerge) * merges.size(), hipMemcpyDeviceToHost, st);
+        if (rc == VBX_OK && e == hipSuccess) e = hipMemcpyAsync(merges.data(), d_merges, sizeof(vbx::ChainMerge) * merges.size(), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
     }
-    for (void* p : {(void*)d_size2, (void*)d_orig, (void*)d_orig2, (void*)d_old, (void*)d_newidx, (void*)d_state, (void*)d_alt})
+    for (void* p : {(void*)d_size2, (void*)d_orig, (void*)d_orig2, (void*)d_old, (void*)d_newidx, (void*)d_state, (void*)d_alt,
+                    (void*)d_cmp, (void*)d_nn, (void*)d_nnd, (void*)d_role, (void*)d_pairs})
         ctx_free(ctx, p);
     ctx_free(ctx, d_size);
     ctx_free(ctx, d_chain);
