@@ -249,7 +249,8 @@ def main():
     ap.add_argument('--T', type=int, default=10000)
     ap.add_argument('--S', type=int, default=30)
     ap.add_argument('--D', type=int, default=128)
-    ap.add_argument('--precision', default='fp32', choices=['fp32', 'fp64'])
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'fp64', 'fp32-split'],
+                    help="fp32-split = --precision fp32 --gemm split (the name the library and the profiles use)")
     ap.add_argument('--gemm', default='exact', choices=['exact', 'split'],
                     help='how the fp32 HEADLINE multiplies: exact = v_mfma_f32_16x16x4_f32; split = f16 operand pairs on the '
                          'matrix cores (VBX_OPT_GEMM).  The other one is measured as a sub-record either way')
@@ -266,6 +267,8 @@ def main():
     ap.add_argument('--streams', type=int, default=None, help='HIP streams per batch (default: the library\'s choice)')
     ap.add_argument('--dry-run', action='store_true', help='stop after the ranks are established (no GPU needed)')
     args = ap.parse_args()
+    if args.precision == 'fp32-split':
+        args.precision, args.gemm = 'fp32', 'split'
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         respawn_under_torchrun(args.gpus)              # (does not return)

@@ -1,0 +1,35 @@
+#!/bin/bash
+# The round's profiles in one gpurun call:   tools/profiles.sh <round tag, e.g. r04> [workload tags ...]
+# rocprofv3 kernel trace + PMC FETCH_SIZE / WRITE_SIZE + two SQ passes (tools/profile_bench.sh) of
+#   f32_s1 / split_s1 / f64_s1   the headline batch (64 x T=10 000 x S=30) on one stream: exact f32, f16 operand pairs, fp64
+#                                (with the kernel trace of bench.py itself beside each)
+#   c2*, c3*                     BASELINE configs[1], [2] (one recording each): fp32, split, fp64
+#   c4x8*                        configs[3] as stated: 8 recordings on this GPU
+#   c5_shared*                   configs[4]: the nine-point sweep on one rho
+# Summaries land in gpurun_out/prof_<round>_*/ and are copied into profiles/<round>_* (the files bench.py reads carry the
+# hash of the kernel sources: a later change of the kernels retires them).
+r=$1; shift
+want="$*"
+export SQ2="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES"
+export SQ_EXTRA="SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_INSTS_LDS"
+run() {  # tag, NO_BENCH flag, args...
+  tag=$1; nb=$2; shift 2
+  if [ -n "$want" ] && ! echo " $want " | grep -q " $tag "; then return; fi
+  NO_BENCH=$nb bash tools/profile_bench.sh ${r}_$tag "$@" > /dev/null 2>&1
+  d=gpurun_out/prof_${r}_$tag
+  for f in kernel_stats.txt pmc_traffic.json sq_counters.txt sq2_counters.txt sq_issue.json bench_py_kernel_stats.txt bench_py_line.json; do
+    [ -s $d/$f ] && cp $d/$f profiles/${r}_${tag}_$f
+  done
+  echo "== $tag"; grep -v rocclr $d/pmc_traffic.txt 2>/dev/null | grep -E "chunk_|fin|scan"; grep -E "chunk_|fin_|scan" $d/kernel_stats.txt | cut -c1-120
+}
+run f32_s1 "" --streams 1
+run split_s1 "" --precision fp32-split --streams 1
+run f64_s1 "" --precision fp64 --streams 1
+for p in fp32 fp32-split fp64; do
+  s=$(echo $p | sed -e 's/fp32-split/split/' -e 's/fp//')
+  run c2_$s 1 --batch 1 --T 10000 --S 10 --precision $p
+  run c3_$s 1 --batch 1 --T 50000 --S 30 --precision $p
+  run c4x8_$s 1 --batch 8 --T 10000 --S 30 --precision $p
+  run c5_shared_$s 1 --sweep shared --T 200000 --S 50 --precision $p
+done
+ls profiles | grep "^${r}_" | wc -l

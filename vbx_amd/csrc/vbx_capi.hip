@@ -2429,16 +2429,17 @@ int vbx_scores_linkage_average(vbx_scores* sc, int64_t T, double* Z) {
     //   rounds  all reciprocal nearest-neighbour pairs of the current matrix merged at once, the whole chip on every pass
     //           (VBX_AMD_LINKAGE_DEVICE=rounds, the default from kRoundsFrom clusters): a few dozen rounds for 10 000 x-vectors
     //   chain   SciPy's nearest-neighbour chain on ONE persistent workgroup, bit for bit the host routine (=chain): it
-    //           finishes what the rounds leave (the last few hundred clusters, where a round is all launch latency) and is
-    //           the reference the rounds are tested against
+    //           finishes what the rounds leave (the last kRoundsStop = 48 clusters, where a round is all launch latency: handing
+    //           over at 384 / 128 / 48 / 16 clusters measured 7.6 / 5.9 / 5.8 / 6.0 ms at T = 10 000 and 3.1 / 1.4 / 1.2 / 1.1 ms
+    //           at T = 1025) and is the reference the rounds are tested against
     // The chain runs in stages of n/4 merges with a compaction of the live rows and columns in between; below kStageMin
     // clusters the rest runs in one stage (there a merge costs its four round trips, not the bytes of a row).
     static const long long kStageMin = [] { const char* e = getenv("VBX_AMD_LINKAGE_STAGE_MIN"); const long long v = e ? atoll(e) : 0; return v >= 64 ? v : 4096LL; }();
     static const bool staged = [] { const char* e = getenv("VBX_AMD_LINKAGE_STAGES"); return !(e && e[0] == '0'); }();
     const char* dev_mode = getenv("VBX_AMD_LINKAGE_DEVICE");           // (read per call: tests compare the two in one process)
     const bool rounds_on = !(dev_mode && std::strcmp(dev_mode, "chain") == 0);
-    static const long long kRoundsFrom = [] { const char* e = getenv("VBX_AMD_LINKAGE_ROUNDS_FROM"); const long long v = e ? atoll(e) : 0; return v >= 4 ? v : 1024LL; }();
-    static const long long kRoundsStop = [] { const char* e = getenv("VBX_AMD_LINKAGE_ROUNDS_STOP"); const long long v = e ? atoll(e) : 0; return v >= 2 ? v : 384LL; }();
+    static const long long kRoundsFrom = [] { const char* e = getenv("VBX_AMD_LINKAGE_ROUNDS_FROM"); const long long v = e ? atoll(e) : 0; return v >= 4 ? v : 256LL; }();
+    static const long long kRoundsStop = [] { const char* e = getenv("VBX_AMD_LINKAGE_ROUNDS_STOP"); const long long v = e ? atoll(e) : 0; return v >= 2 ? v : 48LL; }();
     int *d_size = nullptr, *d_size2 = nullptr, *d_chain = nullptr, *d_orig = nullptr, *d_orig2 = nullptr, *d_old = nullptr,
         *d_newidx = nullptr, *d_state = nullptr, *d_nn = nullptr, *d_role = nullptr;
     double *d_alt = nullptr, *d_cmp = nullptr, *d_nnd = nullptr;

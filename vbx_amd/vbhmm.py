@@ -136,9 +136,10 @@ class DeviceStages:
         self.xv = self._capi.XVectors(self.ctx, x, models['mean1'], models['lda'], models['mean2'], models['plda_mu'],
                                       models['plda_tr'], lda_dim)
 
-    # The chain costs ~3 us per step on the device whatever T is (3 T steps), the host routine ~3 ns per matrix entry:
-    # the device wins from T ~ 3000 (measured: T = 1025 12 vs 3 ms, T = 4000 on par, T = 10 000 0.1 vs 0.6 s)
-    DEVICE_LINKAGE_FROM = int(os.environ.get('VBX_AMD_DEVICE_LINKAGE_FROM', '3000'))
+    # The device linkage merges all reciprocal nearest-neighbour pairs per round on the whole chip (round 4: 1.2 ms at
+    # T = 1025, 2.2 ms at 4000, 5.8 ms at 10 000, 19 ms at 20 000; the one-workgroup chain of rounds 2-3: 12 / 54 / 174 / 512 ms);
+    # the host routine needs ~3 ns per matrix entry plus the condensed matrix over PCIe (3 ms at T = 1025): the device from ~600
+    DEVICE_LINKAGE_FROM = int(os.environ.get('VBX_AMD_DEVICE_LINKAGE_FROM', '600'))
 
     def ahc(self, k, threshold):
         """-> (AHC labels of recording k, calibrated threshold)."""
@@ -146,7 +147,7 @@ class DeviceStages:
         try:
             thr, _ = sc.two_gmm_calib(20, want_llr=False)
             if self.T[k] >= self.DEVICE_LINKAGE_FROM and self._capi.linkage_variant() == 'scipy':
-                lin_mat = sc.linkage_average(self.T[k])                # (the device chain follows SciPy's arithmetic)
+                lin_mat = sc.linkage_average(self.T[k])                # (SciPy's update formula; the tree of the host routine)
             else:                                     # short recording: the host chain beats the device's step latency
                 lin_mat = self._capi.linkage_average(sc.get_condensed(self.T[k], -1.0)) if self.T[k] > 1 else np.empty((0, 4))
         finally:
