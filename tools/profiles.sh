@@ -6,7 +6,8 @@
 #   c2*, c3*                     BASELINE configs[1], [2] (one recording each): fp32, split, fp64
 #   c4x8*                        configs[3] as stated: 8 recordings on this GPU
 #   c5_shared*                   configs[4]: the nine-point sweep on one rho
-# Summaries land in gpurun_out/prof_<round>_*/ and are copied into profiles/<round>_* (the files bench.py reads carry the
+# Summaries land in gpurun_out/prof_<round>_*/ and are copied into profiles/<round>_* on the box and into
+# gpurun_out/profiles_<round>/ (what comes back: copy that directory's files into profiles/; the files bench.py reads carry the
 # hash of the kernel sources: a later change of the kernels retires them).
 r=$1; shift
 want="$*"
@@ -17,9 +18,11 @@ run() {  # tag, NO_BENCH flag, args...
   if [ -n "$want" ] && ! echo " $want " | grep -q " $tag "; then return; fi
   NO_BENCH=$nb bash tools/profile_bench.sh ${r}_$tag "$@" > /dev/null 2>&1
   d=gpurun_out/prof_${r}_$tag
+  mkdir -p gpurun_out/profiles_$r
   for f in kernel_stats.txt pmc_traffic.json sq_counters.txt sq2_counters.txt sq_issue.json bench_py_kernel_stats.txt bench_py_line.json; do
-    [ -s $d/$f ] && cp $d/$f profiles/${r}_${tag}_$f
+    [ -s $d/$f ] && cp $d/$f profiles/${r}_${tag}_$f && cp $d/$f gpurun_out/profiles_$r/${r}_${tag}_$f
   done
+  rm -rf $d/trace $d/fetch $d/write $d/sq $d/sq2 $d/bench      # (the rocprofv3 databases: gpurun_out/ travels back only below 64 MiB)
   echo "== $tag"; grep -v rocclr $d/pmc_traffic.txt 2>/dev/null | grep -E "chunk_|fin|scan"; grep -E "chunk_|fin_|scan" $d/kernel_stats.txt | cut -c1-120
 }
 run f32_s1 "" --streams 1
