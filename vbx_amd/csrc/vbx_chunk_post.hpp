@@ -700,8 +700,9 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int s = NT * M::row(lane, r) + mu;
-                        *reinterpret_cast<R2*>(part + (long long)s * Dp + 32 * slab + 2 * i16) =
-                            R2{acc[mu][0][r] * descale, acc[mu][1][r] * descale};
+                        if (s < n_spk)         // (rows of padded speakers are zero: neither stored nor read back, fin_kernel)
+                            *reinterpret_cast<R2*>(part + (long long)s * Dp + 32 * slab + 2 * i16) =
+                                R2{acc[mu][0][r] * descale, acc[mu][1][r] * descale};
                     }
                 }
             }
@@ -743,7 +744,8 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int s = NT * M::row(lane, r) + mu;
-                    *reinterpret_cast<R2*>(part + (long long)s * Dp + 32 * slab + 2 * i16) = R2{acc[mu][0][r], acc[mu][1][r]};
+                    if (s < n_spk)             // (rows of padded speakers are zero: neither stored nor read back, fin_kernel)
+                        *reinterpret_cast<R2*>(part + (long long)s * Dp + 32 * slab + 2 * i16) = R2{acc[mu][0][r], acc[mu][1][r]};
                 }
             }
             if (slab == 0) {

@@ -349,7 +349,10 @@ __global__ __launch_bounds__(1024) void fin_kernel(BatchView<R> bt, int mode) {
     }
     const double fafb = rd.Fa / rd.Fb;
     double N = 0.0;
-    if (!given) {
+    // (a padded speaker, s >= S, has no mass: its partial sums are zero and are neither stored by chunk_post nor read here --
+    //  at S = 50 in 64 columns that is 22 % of the largest stream of a long recording's iteration)
+    const bool has_mass = s < rd.S;
+    if (!given && has_mass) {
         double part = 0.0;
         for (int tl = threadIdx.x; tl < nu; tl += blockDim.x)
             part += (double)bt.npart[(long long)(u0 + tl) * Sp + s];
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(1024) void fin_kernel(BatchView<R> bt, int mode) {
         const int d = d0 + dl;
         const bool dok = d < Dp;
         double C = 0.0;
-        if (!given) {
+        if (!given && has_mass) {
             const int nt = nu, last = nt - 1;
             const R* __restrict__ mp = bt.mpart + ((long long)u0 * Sp + s) * Dp + (dok ? d : 0);
             const long long stride = (long long)Sp * Dp;
