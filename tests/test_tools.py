@@ -82,3 +82,25 @@ def test_chunk_kernels_keep_their_register_and_lds_budget():
     for name, r in rows.items():
         if 'double' not in name and ', 16' not in name:
             assert r['scratch'] == 0, (name, r)
+
+
+def test_device_code_holds_no_lds_permute_instructions(tmp_path):
+    """``ds_bpermute_b32`` (what ``__shfl_xor`` / ``__shfl_up`` compile to) returned another lane's value
+    now and then once the LDS queue of a CU was kept full by other workgroups.  Every cross-lane exchange of the device code
+    is a DPP operation, a ``v_permlane*_swap`` or a ballot since; this test disassembles the gfx950 code object of the built
+    library and makes sure no LDS-queue permute has come back (no GPU needed)."""
+    import shutil
+    import subprocess
+    objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+    from vbx_amd import build as hipbuild
+    if not os.path.exists(objdump) or not os.path.exists(hipbuild.LIB):
+        pytest.skip('llvm-objdump or the built library not available')
+    lib = str(tmp_path / 'libvbx_hip.so')
+    shutil.copy(hipbuild.LIB, lib)
+    subprocess.run([objdump, '--offloading', lib], cwd=str(tmp_path), check=True, capture_output=True)
+    objs = [f for f in os.listdir(tmp_path) if 'gfx950' in f]
+    assert objs, os.listdir(tmp_path)
+    asm = subprocess.run([objdump, '-d', str(tmp_path / objs[0])], check=True, capture_output=True, text=True).stdout
+    assert 'v_mfma_f32_16x16x32_f16' in asm and 'v_permlane32_swap' in asm          # (the disassembly is the device code)
+    bad = [ln for ln in asm.splitlines() if 'ds_bpermute' in ln or 'ds_permute' in ln]
+    assert not bad, bad[:5]

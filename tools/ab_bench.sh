@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of library builds in ONE call (boxes of the pool differ by several percent): usage  LIBS="a.so b.so" MODE=split REPS=2 tools/r04_ab.sh
+# A/B of library builds in ONE call (boxes of the pool differ by several percent): usage  LIBS="a.so b.so" MODE=split REPS=2 tools/ab_bench.sh
 cd "$GRAFT_REPO_ROOT" || exit 1
 export VBX_AMD_NO_REBUILD=1
 for rep in $(seq 1 ${REPS:-2}); do

@@ -25,7 +25,7 @@ python tools/rocpd_stats.py $out/trace/trace_results.db $out/kernel_stats.txt > 
 [ -z "$NO_BENCH" ] && python tools/rocpd_stats.py $out/bench/bench_results.db $out/bench_py_kernel_stats.txt > /dev/null
 python tools/pmc_counters.py $out/sq/sq_results.db $out/sq_counters.txt > /dev/null
 [ -n "$SQ2" ] && python tools/pmc_counters.py $out/sq2/sq2_results.db $out/sq2_counters.txt $out/sq_issue.json $(grep '^workload ' $out/trace.log | cut -d' ' -f2-) > /dev/null
-[ -z "$NO_BENCH" ] && tail -1 $out/bench.log > $out/bench_py_line.json
+[ -z "$NO_BENCH" ] && grep "^{" $out/bench.log | tail -1 > $out/bench_py_line.json
 # HBM bytes per launch, stamped with the workload profile_target.py printed and the commit the library was built from
 python tools/pmc_traffic.py $out/fetch/fetch_results.db $out/write/write_results.db $out/pmc_traffic.json $(grep '^workload ' $out/trace.log | cut -d' ' -f2-) > $out/pmc_traffic.txt 2>&1
 cat $out/kernel_stats.txt

@@ -1511,7 +1511,7 @@ static int auto_streams(int n_rec, long long tiles) {
         const int k = std::atoi(env);
         if (k >= 1) return std::min(k, std::min(n_rec, 8));
     }
-    // measured on 64 recordings of T = 10 000: 1 / 2 / 3 / 4 streams = 341 / 321 / 312 / 334 us per
+    // measured on 64 recordings of T = 10 000 (NOTES.md, rounds 1-2): 1 / 2 / 3 / 4 streams = 341 / 321 / 312 / 334 us per
     // iteration (three is the robust optimum: the fourth stream brought nothing in any queue configuration tried)
     // -- and only when every stream still has several rounds of workgroups per launch (a chunk = one workgroup)
     return (n_rec >= 24 && tiles >= 1536) ? 3 : (n_rec >= 12 && tiles >= 768) ? 2 : 1;

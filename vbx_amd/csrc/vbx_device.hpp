@@ -140,7 +140,7 @@ template <int CTRL> __device__ __forceinline__ int dpp_mov(int v) {
 // ds_bpermute_b32, an LDS-queue instruction, and on gfx950 (ROCm 7.2) a bpermute whose ADDRESS register the compiler
 // re-uses in the very next VALU instruction returned another lane's value now and then once the LDS queue of the CU was
 // kept full by other workgroups' 16-byte reads -- round 4: the vector at the cut of chunk_post, wrong in ~3 of 1400 tiles,
-// only from the second round of workgroups on, only beside the f16-MFMA instances (tools/r04_inputs.py).
+// only from the second round of workgroups on, only beside the f16-MFMA instances (tools/chunk_inputs_probe.py).
 template <int STAGE, typename T> __device__ __forceinline__ T add_xor(T v) {
     T a, b;
     cross_rows<STAGE>(v, a, b);

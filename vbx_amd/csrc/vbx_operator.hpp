@@ -23,7 +23,7 @@ namespace vbx {
 // A thread builds NC columns at once -- colbase, colbase + SP / NC, ... -- on the same NR states: the rows of b and c are
 // fetched once for all of them and the NC recursions are independent instruction streams.  NC = 1 is what runs: two
 // columns per thread (on twice the lanes per column, the same thread count) measured 4-7 % slower on every shape
-// (vbx_chunk_loglik.hpp).
+// (vbx_chunk_loglik.hpp; NOTES.md, round 3).
 // -> x[k][NR] (column sums in [0.5, 1)), expo[k] (the column is x * 2^expo; -(1 << 24) for an all-zero column, which must
 // never win an exponent maximum).
 template <typename R, int SP, int PH, int NC>

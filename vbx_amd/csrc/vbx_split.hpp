@@ -2,7 +2,7 @@
 // the f16 matrix cores with error-compensated operands ("split" mode of the fp32 path, VBX_OPT_GEMM).
 //
 // v_mfma_f32_16x16x4_f32 is exact f32 but runs at the f32 VECTOR rate (64 FLOP / clk / SIMD: 32 cycles per instruction,
-// 1/16 of the f16 / bf16 matrix rate) and does not overlap with vector instructions on a SIMD (DESIGN section 17,
+// 1/16 of the f16 / bf16 matrix rate) and does not overlap with vector instructions on a SIMD (NOTES.md round 3,
 // tools/valu_probe.hip): 27-30 % of the SIMD cycles of both per-chunk kernels.  Here every f32 operand x is carried as
 // two f16 values,
 //     x 2^e = hi + lo,   hi = f16(x 2^e),   lo = f16(x 2^e - hi)
@@ -30,8 +30,14 @@
 namespace vbx {
 
 __device__ __forceinline__ f4 mfma_h(h8 a, h8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-// (small terms first)
+// (small terms first; VBX_SPLIT_LOLO=1 adds the lo lo term, 2^-22 of a product at most: A/B builds)
+#ifndef VBX_SPLIT_LOLO
+#define VBX_SPLIT_LOLO 0
+#endif
 __device__ __forceinline__ f4 mfma_split(h8 ah, h8 al, h8 bh, h8 bl, f4 c) {
+#if VBX_SPLIT_LOLO
+    c = mfma_h(al, bl, c);
+#endif
     c = mfma_h(ah, bl, c);
     c = mfma_h(al, bh, c);
     return mfma_h(ah, bh, c);

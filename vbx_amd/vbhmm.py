@@ -402,7 +402,7 @@ def build_parser():
                    help='smoothing of the hard AHC labels into the initial soft assignments')
     p.add_argument('--output-2nd', required=False, type=bool, default=False,
                    help='Output also second most likely speaker of VB-HMM')
-    p.add_argument('--precision', default='fp64', choices=['fp64', 'fp32'],
+    p.add_argument('--precision', default='fp64', choices=['fp64', 'fp32', 'fp32-split'],
                    help='arithmetic of the VB-HMM kernels (fp64 = the reference\'s dtype and iteration counts)')
     p.add_argument('--timing', action='store_true', help='print a JSON line with the stage timings of this rank')
     return p
