@@ -483,6 +483,11 @@ def main():
                 'C4', lambda mi, st, prec=prec: make_batch(ctx, 8, args.T, args.S, args.D, prec, 0, mi, st), 8, args.T, args.S, prec,
                 'configs[3] as stated: 64 recordings over 8 GPUs = 8 recordings of T=10 000, S=30 on THIS GPU '
                 '(python bench.py --gpus 8 --total-recordings 64 runs exactly that split)', short)
+        # 64 < S <= 256 runs the chunked scan with operators in HBM, not the fused kernels: what an AHC
+        # result of ~100 clusters on a long file costs (vbhmm.py:150-158)
+        for prec in ('fp32', 'fp64'):
+            configs[f'S128_T10k_{prec}'] = one_config('S128', single(10000, 128, prec, 0.99), 1, 10000, 128, prec,
+                                                       'one recording, T=10 000, S=128: the wide chunked scan (64 < S <= 256), unfused kernels', short)
         for prec in ('fp32', 'fp32-split', 'fp64'):
             configs[f'C2_T10k_S10_{prec}'] = one_config('C2', single(10000, 10, prec, 0.99), 1, 10000, 10, prec,
                                                          'configs[1]: one recording, T=10 000, S=10, Fa=0.3 Fb=17 loopProb=0.99', short)

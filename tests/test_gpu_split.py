@@ -178,3 +178,23 @@ def test_split_is_declined_where_the_fused_kernels_do_not_run(ctx):
     batch.run(1, -np.inf)
     assert batch.gemm == 'exact'
     batch.close()
+
+
+@pytest.mark.parametrize('precision', ['fp32-split', 'fp32'])
+def test_a_recording_does_not_depend_on_its_batch_at_scale(ctx, precision):
+    """More workgroups than the chip holds at once (3 x 469 chunks at four per CU, so that workgroups in every phase share
+    a CU): a recording's result must not depend on what else is in its batch, nor on the run.  This is the test that the
+    wrong sums of DESIGN section 6 fail (a packed-f32 operand form that misreads src1 beside matrix instructions: ~3 of 1400
+    chunks, only from the second round of workgroups on): three points on one shared rho with the same hyper-parameters must
+    agree with each other and with a single-recording run, bit for bit, after two iterations -- twice."""
+    from vbx_amd.synth import make_recording
+    T, S = 60000, 30
+    X, Phi, _ = make_recording(T, S, seed=3, kappa=0.05)
+    g0 = _soft(T, S, 4)
+    rec = (X, Phi, g0, 0.9, 0.3, 17.0)
+    (alone,), _ = _run(ctx, [rec], 2, precision)
+    for _rep in range(2):
+        shared, _ = _run(ctx, [rec, rec, rec], 2, precision, shared_from=0)
+        for k, r in enumerate(shared):
+            for key in ('gamma', 'pi', 'Li', 'alpha', 'invL'):
+                assert np.array_equal(r[key], alone[key]), (precision, _rep, k, key, float(np.abs(np.asarray(r[key]) - np.asarray(alone[key])).max()))

@@ -5,7 +5,7 @@ export VBX_AMD_NO_REBUILD=1
 for rep in $(seq 1 ${REPS:-2}); do
   for lib in $LIBS; do
     if [ "$lib" = default ]; then unset VBX_AMD_LIB; else export VBX_AMD_LIB=$PWD/$lib; fi
-    VBX_AMD_GEMM=${MODE:-split} timeout 300 python bench.py --no-configs --no-f64 --cpu-iters 0 ${BENCH_ARGS} > gpurun_out/r04_ab.json 2> gpurun_out/r04_ab.err
+    timeout 300 python bench.py --gemm ${MODE:-split} --no-split --no-configs --no-f64 --cpu-iters 0 ${BENCH_ARGS} > gpurun_out/r04_ab.json 2> gpurun_out/r04_ab.err
     python - <<PY
 import json
 d=json.loads(open('gpurun_out/r04_ab.json').read().strip().splitlines()[-1])

@@ -4,6 +4,6 @@
 cd "$(dirname "$0")/../vbx_amd/csrc" || exit 1
 for spec in "$@"; do
   tag="${spec%%:*}"; flags="${spec#*:}"
-  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-pass-failed $flags -o libvbx_hip_$tag.so vbx_capi.hip && echo "built $tag ($flags)" ) &
+  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-pass-failed -mllvm -slp-vectorize-hor=false $flags -o libvbx_hip_$tag.so vbx_capi.hip && echo "built $tag ($flags)" ) &
 done
 wait

@@ -12,9 +12,13 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.environ.get('VBX_AMD_LIB') or os.path.join(CSRC, 'libvbx_hip.so')   # (VBX_AMD_LIB: an experiment build, tools/build_variants.sh)
+OBJDUMP = '/opt/rocm/lib/llvm/bin/llvm-objdump'
 SOURCES = ['vbx_capi.hip']
 HEADERS = ['vbx_device.hpp', 'vbx_kernels.hpp', 'vbx_scan.hpp', 'vbx_scan_wide.hpp', 'vbx_fb_dense.hpp', 'vbx_operator.hpp', 'vbx_split.hpp', 'vbx_chunk_loglik.hpp', 'vbx_chunk_post.hpp', 'vbx_linkage.hpp', 'vbx_ahc.hpp', 'vbx_frontend.hpp', os.path.join('..', '..', 'include', 'vbx_hip.h')]
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-Wno-pass-failed']
+# -slp-vectorize-hor=false: the compiler's vectorised sums end in "v_pk_add_f32 d, p, p op_sel:[0,1]" (x + y of a register
+# pair), one of the packed-f32 forms that misread src1 on gfx950 under matrix-instruction load (audit_isa() below,
+# DESIGN section 6); with horizontal reductions left scalar none of them is generated, and audit_isa() makes sure
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-Wno-pass-failed', '-mllvm', '-slp-vectorize-hor=false']
 
 
 # the sources that decide what the kernels of an EM iteration do and move: profiles/*_pmc_traffic.json carries their
@@ -69,8 +73,54 @@ def build(force: bool = False, verbose: bool = False) -> str:
             if os.path.exists(tmp):
                 os.remove(tmp)
             raise RuntimeError('hipcc failed:\n' + res.stdout + res.stderr)
+        if os.path.exists(OBJDUMP) and not os.environ.get('VBX_AMD_SKIP_ISA_AUDIT'):
+            bad = audit_isa(disassemble(tmp))
+            if bad:
+                os.remove(tmp)
+                raise RuntimeError('the compiled device code holds packed-f32 instructions that misread src1 on gfx950 '
+                                   '(DESIGN section 6); restructure the source they come from:\n  ' + '\n  '.join(bad[:20]))
         os.replace(tmp, LIB)
     return LIB
+
+
+def disassemble(lib: str | None = None) -> str:
+    """The gfx950 code object of a built library as text (llvm-objdump; no GPU needed)."""
+    import tempfile
+    lib = lib or LIB
+    with tempfile.TemporaryDirectory() as tmp:
+        copy = os.path.join(tmp, 'lib.so')
+        shutil.copy(lib, copy)
+        subprocess.run([OBJDUMP, '--offloading', copy], cwd=tmp, check=True, capture_output=True)
+        objs = [f for f in os.listdir(tmp) if 'gfx950' in f]
+        if not objs:
+            raise RuntimeError(f'no gfx950 code object in {lib}')
+        return subprocess.run([OBJDUMP, '-d', os.path.join(tmp, objs[0])], check=True, capture_output=True, text=True).stdout
+
+
+def audit_isa(asm: str) -> list[str]:
+    """Instructions the device code must not contain, as 'kernel: instruction' strings.
+
+    Packed-f32 instructions whose LOW half takes src1 from the HIGH register of its pair -- the op_sel bit of src1:
+    ``v_pk_fma_f32 ... op_sel:[x,1,x]``, ``v_pk_mul_f32 / v_pk_add_f32 ... op_sel:[x,1]``.  On gfx950 that half reads src1
+    as ZERO in lanes 48-63 now and then (1e-5 ... 3e-4 of the executions) while another wavefront of the SIMD runs matrix
+    instructions; the selects of src0 and src2 and every op_sel_hi form are not affected (tools/hazard/pk_opsel_probe.hip,
+    profiles/r04_hazard/).  The compiler emits the form for the last step of a vectorised sum (x + y of a register pair:
+    avoided with -slp-vectorize-hor=false) and for a multiplier it broadcasts from the odd element of a loaded vector
+    (chunk_post's product at the cut in round 3).
+    """
+    import re
+    bad, kernel = [], '?'
+    sel = re.compile(r'op_sel:\[([01]),([01])')
+    for line in asm.splitlines():
+        if line.endswith('>:'):
+            kernel = line.split('<', 1)[-1][:-2]
+            continue
+        code = line.split('//')[0].strip()
+        if code.startswith('v_pk_') and '_f32' in code.split()[0]:
+            m = sel.search(code)
+            if m and m.group(2) == '1':
+                bad.append(f'{kernel}: {code}')
+    return bad
 
 
 if __name__ == '__main__':

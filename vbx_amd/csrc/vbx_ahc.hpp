@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void linkage_prepare_kernel(double* __restrict
 struct ChainMergeDev { int a, b; double d; };          // same layout as vbx::ChainMerge of the host code
 
 // (value, index) arg-min over the 64 lanes of a wavefront, the lowest index winning ties; every lane gets the result.
-// DPP row operations and permlane swaps -- not __shfl_xor, i.e. ds_bpermute_b32 (vbx_device.hpp, add_xor).
+// DPP row operations and permlane swaps (cheaper than __shfl_xor's ds_bpermute_b32 round trip: vbx_device.hpp, add_xor).
 __device__ __forceinline__ void argmin_pair(double& m, int& mi, double ov, int oi) {
     if (ov < m || (ov == m && oi < mi)) { m = ov; mi = oi; }
 }

@@ -2630,7 +2630,8 @@ extern "C" int vbx_debug_clocks(long long* out, int n_words) {
 #endif
 
 // debugging aid (not part of the ABI): copy one of a plain batch's per-tile arrays to the host
-//   which = 0 mpart [tiles][Sp][Dp] R, 1 npart [tiles][Sp] R, 2 epart [tiles][Sp] f64, 3 tllpart [tiles] f64, 4 gamma0 [n_rec][Sp] R
+//   which = 0 mpart [tiles][Sp][Dp] R, 1 npart [tiles][Sp] R, 2 epart [tiles][Sp] f64, 3 tllpart [tiles] f64, 4 gamma0 [n_rec][Sp] R,
+//   5 the checksums of the -DVBX_DEBUG_INPUTS build
 extern "C" long long vbx_debug_fetch(vbx_batch* b, int which, void* out, long long cap_bytes) {
     if (!b || !b->kids.empty()) return -1;
     (void)hipSetDevice(b->ctx->device);

@@ -356,8 +356,15 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
                     R tot = 0;
 #pragma unroll
                     for (int ii = 0; ii < QS; ++ii) tot += opb[r][ii] * mv_w[1][g4 * QS + ii];
+#ifdef VBX_CUT_VIA_BPERMUTE
+                    // (A/B build, tools/hazard/bpermute_compare.py: with __shfl_xor here the compiler vectorises the product
+                    //  over r into v_pk_fma_f32 ... op_sel:[0,1,0] -- the form of DESIGN section 6 -- and the build fails as round 3's did)
+                    tot += __shfl_xor(tot, 16, 64);
+                    tot += __shfl_xor(tot, 32, 64);
+#else
                     tot = add_xor<16>(tot);
                     tot = add_xor<32>(tot);
+#endif
                     x[r] = tot;
                     tj[r] = (tot > (R)0 && ope[r] > kNoMass / 2) ? ope[r] + exponent_of(tot) : kNever;
                     top = max(top, tj[r]);

@@ -136,20 +136,29 @@ template <int CTRL> __device__ __forceinline__ int dpp_mov(int v) {
     return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
 }
 
-// v + (the value lane ^ STAGE holds), STAGE = 16 or 32, on the VALU (v_permlane16/32_swap).  NOT __shfl_xor: that is a
-// ds_bpermute_b32, an LDS-queue instruction, and on gfx950 (ROCm 7.2) a bpermute whose ADDRESS register the compiler
-// re-uses in the very next VALU instruction returned another lane's value now and then once the LDS queue of the CU was
-// kept full by other workgroups' 16-byte reads -- round 4: the vector at the cut of chunk_post, wrong in ~3 of 1400 tiles,
-// only from the second round of workgroups on, only beside the f16-MFMA instances (tools/chunk_inputs_probe.py).
+// v + (the value lane ^ STAGE holds), STAGE = 16 or 32, on the VALU (v_permlane16/32_swap) instead of __shfl_xor's
+// ds_bpermute_b32 round trip through the LDS queue (56 against 92 cycles for a 64-lane butterfly, see above).
+// (Round 4 took the permute for the cause of chunk_post's wrong sums for a while; it is not -- DESIGN section 6: the
+//  cause is a packed-f32 operand form the compiler happened to emit next to it, which vbx_amd/build.py now rejects.)
+// (-DVBX_XOR_VIA_BPERMUTE: the round-3 code generation again, for tools/hazard/bpermute_compare.py)
 template <int STAGE, typename T> __device__ __forceinline__ T add_xor(T v) {
+#ifdef VBX_XOR_VIA_BPERMUTE
+    return v + __shfl_xor(v, STAGE, 64);
+#else
     T a, b;
     cross_rows<STAGE>(v, a, b);
     return a + b;
+#endif
 }
 template <int STAGE> __device__ __forceinline__ int max_xor(int v) {
+#ifdef VBX_XOR_VIA_BPERMUTE
+    const int o = __shfl_xor(v, STAGE, 64);
+    return v > o ? v : o;
+#else
     int a, b;
     cross_rows<STAGE>(v, a, b);
     return a > b ? a : b;
+#endif
 }
 
 // value held by one lane, as a wave-uniform scalar (v_readlane_b32 -> SGPR)
