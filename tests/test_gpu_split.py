@@ -180,15 +180,15 @@ def test_split_is_declined_where_the_fused_kernels_do_not_run(ctx):
     batch.close()
 
 
-@pytest.mark.parametrize('precision', ['fp32-split', 'fp32'])
-def test_a_recording_does_not_depend_on_its_batch_at_scale(ctx, precision):
+@pytest.mark.parametrize('precision,S', [('fp32-split', 30), ('fp32', 30), ('fp32-split', 50), ('fp32', 50), ('fp32', 10), ('fp64', 30)])
+def test_a_recording_does_not_depend_on_its_batch_at_scale(ctx, precision, S):
     """More workgroups than the chip holds at once (3 x 469 chunks at four per CU, so that workgroups in every phase share
     a CU): a recording's result must not depend on what else is in its batch, nor on the run.  This is the test that the
     wrong sums of DESIGN section 6 fail (a packed-f32 operand form that misreads src1 beside matrix instructions: ~3 of 1400
     chunks, only from the second round of workgroups on): three points on one shared rho with the same hyper-parameters must
     agree with each other and with a single-recording run, bit for bit, after two iterations -- twice."""
     from vbx_amd.synth import make_recording
-    T, S = 60000, 30
+    T = 60000                                              # (S = 50: the Sp = 64 kernels of C5; S = 10: Sp = 16; fp64: the default path)
     X, Phi, _ = make_recording(T, S, seed=3, kappa=0.05)
     g0 = _soft(T, S, 4)
     rec = (X, Phi, g0, 0.9, 0.3, 17.0)
