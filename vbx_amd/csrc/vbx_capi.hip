@@ -2630,8 +2630,7 @@ extern "C" int vbx_debug_clocks(long long* out, int n_words) {
 #endif
 
 // debugging aid (not part of the ABI): copy one of a plain batch's per-tile arrays to the host
-//   which = 0 mpart [tiles][Sp][Dp] R, 1 npart [tiles][Sp] R, 2 epart [tiles][Sp] f64, 3 tllpart [tiles] f64, 4 gamma0 [n_rec][Sp] R,
-//   5 the checksums of the -DVBX_DEBUG_INPUTS build
+//   which = 0 mpart [tiles][Sp][Dp] R, 1 npart [tiles][Sp] R, 2 epart [tiles][Sp] f64, 3 tllpart [tiles] f64, 4 gamma0 [n_rec][Sp] R
 extern "C" long long vbx_debug_fetch(vbx_batch* b, int which, void* out, long long cap_bytes) {
     if (!b || !b->kids.empty()) return -1;
     (void)hipSetDevice(b->ctx->device);
@@ -2645,12 +2644,6 @@ extern "C" long long vbx_debug_fetch(vbx_batch* b, int which, void* out, long lo
         case 2: src = b->d_epart; bytes = nt * sp * 8; break;
         case 3: src = b->d_tllpart; bytes = nt * 8; break;
         case 4: src = b->d_gamma0; bytes = (size_t)b->n_rec * sp * rs; break;
-#ifdef VBX_DEBUG_INPUTS
-        case 5:
-            bytes = std::min<size_t>(nt, vbx::kDbgTiles) * 8 * 8;
-            if ((long long)bytes > cap_bytes) return -(long long)bytes;
-            return hipMemcpyFromSymbol(out, HIP_SYMBOL(vbx::g_dbg_inputs), bytes) == hipSuccess ? (long long)bytes : -1;
-#endif
         default: return -1;
     }
     if (!src || (long long)bytes > cap_bytes) return -(long long)bytes;

@@ -56,10 +56,6 @@
 
 namespace vbx {
 
-#ifdef VBX_DEBUG_INPUTS
-constexpr int kDbgTiles = 16384;
-__device__ double g_dbg_inputs[kDbgTiles * 8];     // per tile: checksums of what chunk_post read (debugging aid)
-#endif
 #ifdef VBX_PHASE_CLOCKS
 constexpr int kClockTiles = 8192;
 __device__ long long g_phase_clocks[kClockTiles * 16];
@@ -185,34 +181,6 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
         }
         __syncthreads();
         VBX_STAMP();
-#ifdef VBX_DEBUG_INPUTS
-        if (!REPLAY && tile < kDbgTiles) {
-            double* d = g_dbg_inputs + (long long)tile * 8;
-            double sb = 0;                                    // boundary vector of this wave (fbound for 0 / 2, gbound for 1 / 3)
-            for (int r = 0; r < NREG; ++r) sb += (double)bnd_v[r] * (1 + so + r);
-            sb = allreduce_sum<16>(sb);
-            double so_ = 0, se = 0;
-            if (split && wave >= 2) {
-                for (int r = 0; r < NREG; ++r) {
-                    se += (double)ope[r] * (1 + so + r);
-                    for (int ii = 0; ii < QS; ++ii) so_ += (double)(wave == 2 ? opf[ii][r] : opb[r][ii]) * (1 + ii + 3 * r + 7 * lane);
-                }
-                so_ = allreduce_sum<64>(so_);
-                se = allreduce_sum<16>(se);
-            }
-            double sbt = 0;
-            for (int q = tid; q < LAT; q += 256) sbt += (double)bl[q] * (1 + (q & 1023));
-            sbt = block_sum(sbt, red);
-            double sc = 0;
-            for (int r = 0; r < NREG; ++r) sc += (double)c_l[so + r] * (1 + so + r);
-            sc = allreduce_sum<16>(sc);
-            if (lane == 0) {
-                if (wave == 1) d[0] = sb;                       // gbound as the backward wave holds it
-                (void)sbt; (void)sc;
-            }
-            __syncthreads();
-        }
-#endif
 
         // ---- re-run: wave 0 forward, wave 1 backward (VBx.py:167-171 in the linear domain) ----------------------
         // A lone wavefront on a dependent instruction stream pays ~8-10 cycles per instruction, so the loops are
@@ -381,13 +349,6 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
         }
         if (packed) {
             __syncthreads();
-#ifdef VBX_DEBUG_INPUTS
-            if (!REPLAY && tile < kDbgTiles && tid == 0) {
-                double sx = 0;
-                for (int q = 0; q < SP; ++q) sx += (double)mv_w[1][q] * (1 + q);
-                g_dbg_inputs[(long long)tile * 8 + 4] = sx;      // the backward vector at the cut as wave 3 left it
-            }
-#endif
             if (wave == 0 && hl == 1) load_pack<NREG>(a, mv_w[0] + so);      // rows 2-3: the second half starts from a_(H-1)
             if (wave == 1 && hl == 0) load_pack<NREG>(x, mv_w[1] + so);      // rows 0-1: the first half starts from x_(H-1)
         }
@@ -511,27 +472,6 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
         __syncthreads();
         VBX_STAMP();
 
-#ifdef VBX_DEBUG_INPUTS
-        if (!REPLAY && tile < kDbgTiles) {
-            // checksums of what pass 1 is about to read (after the barrier above), per producer:
-            //   a rows: r1[0:32), bl[32:64), r1[64:96), bl[96:128)  (forward, before / after the crossing of each half)
-            //   x rows: bl[0:32), r1[32:64), bl[64:96), r1[96:128)
-            double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;
-            for (int q = tid; q < LAT; q += 256) {
-                const int f = q / SP;
-                const bool low = (f & 32) == 0;
-                const double w = 1 + (q % 977);
-                if (low) s0 += (double)r1[q] * w;            // a before the crossing
-                else (f < 64 ? s3 : s1) += (double)r1[q] * w;   // x before the crossing: first half | second half
-                if (low) s2 += (double)bl[q] * w;            // x after the crossing
-            }
-            if (tid < kTileFrames) { s4 = (double)sfl[tid] * (1 + tid); s5 = (double)qfl[tid] * (1 + tid); }
-            s0 = block_sum(s0, red); s1 = block_sum(s1, red); s2 = block_sum(s2, red); s3 = block_sum(s3, red);
-            s4 = block_sum(s4, red); s5 = block_sum(s5, red);
-            if (tid == 0) { double* d = g_dbg_inputs + (long long)tile * 8; d[1] = s0; d[2] = s1; d[3] = s3; d[5] = s2; d[6] = s4; d[7] = s5; }
-            __syncthreads();
-        }
-#endif
         // ---- posteriors and the "entered" statistic                               (VBx.py:101-103,174) --
         //   gamma_t = a_t x_t / sum;   entered_j += gamma_t[j] s_{t-1} / (lp a_{t-1}[j] + c_j s_{t-1}),  t >= 1
         // rows are brought to scale 1 first (a/s sums to 1, x/q >= 1 elementwise): no product can underflow.
