@@ -43,7 +43,34 @@ __global__ __launch_bounds__(512) void probe(unsigned long long* out, int iters,
                 const float4 va = LOADER == 2 ? float4{1.f, 2.f, 3.f, (float)(it + u)} : lds[(lane + 64 * u + 17 * it) & 2047];
                 const float4 vb = LOADER == 2 ? float4{1.f, 2.f, (float)(it - u), 3.f} : lds[(lane + 64 * u + 64 + 17 * it) & 2047];
                 const h8 a = __builtin_bit_cast(h8, va), b = __builtin_bit_cast(h8, vb);
-                if (LOADER != 1) {
+                if (LOADER == 3) {                               // the exact-f32 matrix instruction of the fp32 path
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(va.x, vb.x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vb.y, va.y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(va.z, va.w, acc0, 0, 0, 0);
+                } else if (LOADER == 4) {                        // ... and the f64 one of the fp64 path
+                    typedef double d4 __attribute__((ext_vector_type(4)));
+                    d4 c = {acc0[0], acc0[1], acc1[0], acc1[1]};
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64((double)va.x, (double)vb.x, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64((double)vb.y, (double)va.y, c, 0, 0, 0);
+                    acc0[0] = (float)c[0]; acc0[1] = (float)c[1]; acc1[0] = (float)c[2]; acc1[1] = (float)c[3];
+                } else if (LOADER == 5) {                        // bf16, same shape as the f16 one
+                    typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+                    const b8 ba = __builtin_bit_cast(b8, va), bb = __builtin_bit_cast(b8, vb);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, bb, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb, ba, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, ba, acc0, 0, 0, 0);
+                } else if (LOADER == 6) {                        // the f16 instruction of the older parts (K = 16)
+                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                    const h4 ha = {a[0], a[1], a[2], a[3]}, hb = {b[0], b[1], b[2], b[3]};
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x16f16(ha, hb, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x16f16(hb, ha, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x16f16(ha, ha, acc0, 0, 0, 0);
+                } else if (LOADER == 7) {                        // fp8 (K = 32)
+                    const long la = __builtin_bit_cast(long, va.x * 1.0 + va.y), lb = __builtin_bit_cast(long, vb.x * 1.0 + vb.y);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(la, lb, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(lb, la, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(la, la, acc0, 0, 0, 0);
+                } else if (LOADER != 1) {
                     acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(b, a, acc1, 0, 0, 0);
                     acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, a, acc0, 0, 0, 0);
@@ -89,7 +116,7 @@ __global__ __launch_bounds__(512) void probe(unsigned long long* out, int iters,
 template <int FORM, int LOADER> void run(int loaders, int iters) {
     static const char* form[] = {"v_pk_fma_f32 (no operand select: control)", "v_pk_fma_f32 op_sel:[0,1,0]", "v_pk_fma_f32 op_sel:[1,0,0]", "v_pk_fma_f32 op_sel:[0,0,1] op_sel_hi:[1,1,0]",
                                  "v_pk_fma_f32 op_sel_hi:[1,0,1]", "v_pk_mul_f32 op_sel:[0,1]", "v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0]", "v_pk_mul_f32 op_sel_hi:[1,0]"};
-    static const char* loader[] = {"LDS reads + MFMA", "LDS reads only", "MFMA only"};
+    static const char* loader[] = {"LDS reads + f16 MFMA", "LDS reads only", "f16 MFMA only", "LDS + f32 MFMA 16x16x4", "LDS + f64 MFMA 16x16x4", "LDS + bf16 MFMA 16x16x32", "LDS + f16 MFMA 16x16x16", "LDS + fp8 MFMA 16x16x32"};
     unsigned long long* d;
     hipMalloc(&d, 256);
     unsigned long long h[32], tot[32] = {0};
@@ -101,7 +128,7 @@ template <int FORM, int LOADER> void run(int loaders, int iters) {
         for (int q = 0; q < 16; ++q) tot[q] += h[q];
         if (h[6] && rec[1] == 0) memcpy(rec, h + 16, sizeof(rec));
     }
-    printf("%-46s | %d of 8 wavefronts: %-16s | low half wrong %llu (rows %llu %llu %llu %llu; = select ignored: %llu), high half wrong %llu (rows %llu %llu %llu %llu; = select ignored: %llu) of %llu\n",
+    printf("%-46s | %d of 8 wavefronts: %-24s | low half wrong %llu (rows %llu %llu %llu %llu; = select ignored: %llu), high half wrong %llu (rows %llu %llu %llu %llu; = select ignored: %llu) of %llu\n",
            form[FORM], loaders, loader[LOADER], tot[1], tot[8], tot[9], tot[10], tot[11], tot[4], tot[2], tot[12], tot[13], tot[14], tot[15], tot[5], tot[3]);
     if (rec[1] != 0)
         printf("      e.g. low half got %.9g, want %.9g (select ignored: %.9g); a = (%.9g, %.9g) b = (%.9g, %.9g) c = (%.9g, %.9g)\n", rec[0], rec[1], rec[2], rec[3], rec[4], rec[5],
@@ -119,6 +146,13 @@ int main() {
     run<1, 0>(1, 300);
     run<1, 0>(2, 300);
     run<1, 0>(6, 300);
+    run<1, 3>(4, 300);
+    run<1, 4>(4, 300);
+    run<6, 3>(4, 300);
+    run<6, 4>(4, 300);
+    run<1, 5>(4, 300);
+    run<1, 6>(4, 300);
+    run<1, 7>(4, 300);
     run<2, 0>(4, 300);
     run<3, 0>(4, 300);
     run<4, 0>(4, 300);
