@@ -1,12 +1,14 @@
 // pk_opsel_probe.hip -- packed-f32 vector instructions whose LOW half takes an operand from the HIGH register of a pair
-// (op_sel bit set) while other wavefronts of the CU run 16-byte LDS reads into f16 matrix instructions: DESIGN section 6.
+// (op_sel bit set) while other wavefronts of the CU run matrix instructions: DESIGN section 6.
 //
-// tools/cut_sequence_probe.hip reproduced chunk_post's wrong sums outside the library and tools/lds_return_probe.hip reduced
+// tools/hazard/cut_sequence_probe.hip reproduced chunk_post's wrong sums outside the library and lds_return_probe.hip reduced
 // them to ONE instruction, on registers that had been valid for a long time:
-//     v_pk_fma_f32 v[6:7], v[54:55], v[10:11], v[6:7] op_sel:[0,1,0]        low half wrong in lanes 48-63, ~1e-3 of the time
-// This probe runs the operand-select forms one by one and says what the wrong value was.
+//     v_pk_fma_f32 v[6:7], v[54:55], v[10:11], v[6:7] op_sel:[0,1,0]        low half wrong in lanes 48-63, ~3e-5 of the time
+// This probe runs the operand-select forms one by one, says what the wrong value was, and varies what the other
+// wavefronts of the workgroup do: LDS reads, matrix instructions of every operand width (f16 / bf16 with K = 32 -- the
+// 128-bit operands new on gfx950 --, f32, f64, the K = 16 f16 one, fp8), both, or nothing.
 //
-//   hipcc --offload-arch=gfx950 -O3 -o pk_opsel_probe tools/pk_opsel_probe.hip && ./pk_opsel_probe
+//   hipcc --offload-arch=gfx950 -O3 -o pk_opsel_probe tools/hazard/pk_opsel_probe.hip && ./pk_opsel_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
