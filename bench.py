@@ -488,8 +488,8 @@ def main():
         for prec in ('fp32', 'fp64'):
             configs[f'S128_T10k_{prec}'] = one_config('S128', single(10000, 128, prec, 0.99), 1, 10000, 128, prec,
                                                        'one recording, T=10 000, S=128: the wide chunked scan (64 < S <= 256), unfused kernels; kernel by kernel in '
-                                                       'profiles/r04_s128_*_kernel_stats.txt: half of the iteration is the boundary walk (fb_aux), bound by the '
-                                                       'bytes one CU can pull (DESIGN section 11)', short)
+                                                       'profiles/r04_s128_*_kernel_stats.txt: the largest piece is the boundary walk (fb_aux, scan2_wide: one '
+                                                       'workgroup per direction, DESIGN section 11)', short)
         for prec in ('fp32', 'fp32-split', 'fp64'):
             configs[f'C2_T10k_S10_{prec}'] = one_config('C2', single(10000, 10, prec, 0.99), 1, 10000, 10, prec,
                                                          'configs[1]: one recording, T=10 000, S=10, Fa=0.3 Fb=17 loopProb=0.99', short)

@@ -386,7 +386,7 @@ template <typename R, int SP> void launch_scan_wide(vbx_batch* b, const BatchVie
     }
     {
         LaunchScope ls(b, VBX_K_FB_AUX);
-        hipLaunchKernelGGL((scan2_wide_kernel<R, SP>), dim3(b->n_rec, 2), dim3(1024), 0, st, v);
+        hipLaunchKernelGGL((scan2_wide_kernel<R, SP, 16>), dim3(b->n_rec, 2), dim3(1024), 0, st, v);
     }
     {
         LaunchScope ls(b, VBX_K_FB);

@@ -4,9 +4,9 @@
 // association order), other shapes: an S x S operator is 64-256 KB, so
 //   scan1_wide  one workgroup builds 16 columns of a chunk's operator (16 lanes per column, S/16 states per lane);
 //               b of the chunk goes through LDS in pieces of at most 32 KB
-//   scan2_wide  one workgroup of 1024 threads per (recording, direction) walks the chain; every mat-vec reads the
-//               operator straight from L2 / HBM (coalesced), partial sums meet in LDS.  Forward: thread = (row,
-//               column block); backward ((F^T g)_j = <column j, g>): a wavefront per output, lanes over the rows
+//   scan2_wide  one workgroup of 4-8 wavefronts per (recording, direction) walks the chain; every mat-vec reads the
+//               operator straight from L2 / HBM with 16-byte loads requested ahead of its step; wave w owns a block of
+//               rows of it, partial sums meet in LDS (forward) / in a butterfly (backward)
 //   scan3_wide  one wavefront per (chunk, direction) re-runs the chunk with lane = state (S/64 states per lane),
 //               rows of b prefetched from L2 eight frames ahead, and writes ahat / bhat / the forward scales exactly
 //               like scan3 -- post_kernel and the accumulation take it from there.
@@ -95,95 +95,153 @@ __global__ __launch_bounds__(256) void scan1_wide_kernel(BatchView<R> bt) {
 }
 
 // block-wide maximum of one int per thread of the first SP threads (SP a multiple of 64); every thread gets it
+// (an LDS barrier: the operator loads of later chain steps stay in flight across it)
 template <int SP> __device__ __forceinline__ int wide_block_max(int v, int* wmax, int tid) {
-    const int m = allreduce_max<64>(v);
-    if ((tid & 63) == 0 && tid < SP) wmax[tid >> 6] = m;
-    __syncthreads();
+    if (tid < SP) {                                    // (wave-uniform: SP is a multiple of 64)
+        const int m = allreduce_max<64>(v);
+        if ((tid & 63) == 0) wmax[tid >> 6] = m;
+    }
+    lds_barrier();
     int top = wmax[0];
 #pragma unroll
     for (int w = 1; w < SP / 64; ++w) top = max(top, wmax[w]);
     return top;
 }
 
-template <typename R, int SP>
-__global__ __launch_bounds__(1024) void scan2_wide_kernel(BatchView<R> bt) {
-    constexpr int HL = 1024 / SP, NI = SP / HL;        // forward: column blocks per row, columns per block
-    constexpr int NL = SP / 64;                        // backward: rows per lane
-    __shared__ R vec[SP];                              // the vector being pushed through the chain (weights, forward)
-    __shared__ R part[1024];
+// The boundary walk of one recording in one direction: K - 1 dependent chain steps, each a mat-vec with a chunk operator
+// that lives in HBM (or another XCD's L2), by ONE workgroup of NW wavefronts.  A step is a chain of short phases that
+// meet at four barriers -- largest exponent, weights, partial products, their sum -- plus the operator's way from memory:
+//  * the operator is read with 16-byte loads, 64 * VEC consecutive elements per wave instruction, requested D chain
+//    steps ahead (where a thread's share fits the registers D + 1 times), and the barriers of a step are LDS barriers:
+//    __syncthreads() waits for every load in flight.  Round 3 read 4 / 8 bytes per lane one step ahead behind
+//    __syncthreads(): 272 wave loads per operator at S = 128, 1.55 us per step in fp32 and 2.95 in fp64 -- a recording
+//    of 79 chunks 125 / 240 us per launch, half of its iteration.  Now 0.98 / 2.6 us per step (76 / 202 us), S = 200 in
+//    fp64 (whose walk spilled 21 registers) 1.49 -> 0.96 ms per iteration;
+//  * NW = 16: with 8 wavefronts the fp32 walk at S = 128 takes 92 us, with 4 it takes 117 (tools/cu_stream_probe.hip: one
+//    CU pulls 108 GB/s with 16 wavefronts loading, 87 with 4 at sixteen loads in flight each, 45 at four).
+// Layout: wave w owns rows [w RPW, (w + 1) RPW) of the operator (row = the index the mat-vec sums over in the forward
+// direction, the output index in the backward one); a wave instruction covers RPI whole rows (lanes l, l + LPR, ... hold
+// the same columns) or, when a row is longer than 64 * VEC elements, one NG-th of a row.
+template <typename R, int SP, int NW> struct WalkWideCfg {
+    static constexpr int VEC = 16 / (int)sizeof(R);            // elements per lane and load
+    static constexpr int EPI = 64 * VEC;                       // elements per wave instruction
+    static constexpr bool kRows = EPI >= SP;
+    static constexpr int RPI = kRows ? EPI / SP : 1;           // rows per instruction
+    static constexpr int NG = kRows ? 1 : SP / EPI;            // instructions per row
+    static constexpr int LPR = kRows ? SP / VEC : 64;          // lanes per row
+    static constexpr int RPW = SP / NW;                        // rows per wave
+    static constexpr int IPW = RPW * NG / RPI;                 // instructions per wave and operator
+    static constexpr int kDwords = IPW * 4;                    // registers one operator share takes
+    static constexpr int D = kDwords <= 16 ? 3 : (kDwords <= 32 ? 1 : 0);     // chain steps the loads run ahead (two at 32 registers spill)
+    static constexpr int CHI = D > 0 ? IPW : 8;                // instructions in registers at a time when nothing runs ahead
+    static_assert(RPI == 1 || RPI == 2, "rows per instruction");
+    static_assert(NW * 64 >= SP, "the first SP threads carry the vector");
+};
+
+template <typename R, int SP, int NW>
+__global__ __launch_bounds__(NW * 64) void scan2_wide_kernel(BatchView<R> bt) {
+    using Cfg = WalkWideCfg<R, SP, NW>;
+    constexpr int VEC = Cfg::VEC, EPI = Cfg::EPI, RPI = Cfg::RPI, NG = Cfg::NG, LPR = Cfg::LPR, RPW = Cfg::RPW, IPW = Cfg::IPW;
+    constexpr int D = Cfg::D, CHI = Cfg::CHI;
+    constexpr bool kRows = Cfg::kRows;
+    typedef R RV __attribute__((ext_vector_type(VEC)));
+    __shared__ __attribute__((aligned(16))) R vec[SP];         // the vector being pushed through the chain (weights, forward)
+    __shared__ __attribute__((aligned(16))) R part[NW * SP];   // forward: per wave and column; backward: per row
     __shared__ int wmax[SP / 64];
     const int rec = blockIdx.x, dir = blockIdx.y;
     if (bt.state[rec].done) return;
     const RecDesc rd = bt.recs[rec];
     const int K = rd.ntiles;
     const long long cb0 = rd.tile0;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int j = tid % SP, h = tid / SP;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int j = tid % SP;
     constexpr int kNone = -(1 << 28);
+    const int sub = kRows ? lane / LPR : 0;                    // which of the RPI rows of an instruction this lane reads
+    const int col0 = kRows ? (lane % LPR) * VEC : lane * VEC;  // its first column (within group g: + g * EPI)
+    // chain step n uses the operator of chunk cb0 + n (forward) / cb0 + K - 1 - n (backward); n is clamped so that the
+    // requests running ahead of the last step stay inside the recording (K >= 2 wherever this is called)
+    auto fetch = [&](int n, RV (&dst)[CHI], int& e, int i0) {
+        const int nn = min(n, K - 2);
+        const long long k = dir == 0 ? cb0 + nn : cb0 + K - 1 - nn;
+        const RV* __restrict__ src = reinterpret_cast<const RV*>(bt.op + k * SP * SP) + (long long)(wave * IPW + i0) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < CHI; ++q) dst[q] = src[q * 64];
+        if (tid < SP) e = bt.opexp[k * SP + j];
+    };
+    RV ovr[D + 1][CHI];
+    int ejr[D + 1];
+#pragma unroll
+    for (int d = 0; d <= D; ++d) ejr[d] = 0;
+
     if (dir == 0) {
         R y = 0;
         if (tid < SP) {
             y = (j < rd.S) ? (R)(bt.ip[(long long)rec * SP + j] + 1e-8) : (R)0;
             bt.fbound[cb0 * SP + j] = y;
         }
-        // The operator entries of a thread (and the exponent of its column) are requested at the top of a chain step
-        // for the NEXT step when they fit the registers twice (S <= 128), else for this step before the weights are
-        // known, as many at a time as the registers hold: a dependent global load costs ~1 us, as much as the rest of
-        // the step.
-        constexpr bool kAhead = NI <= 32;
-        constexpr int CH = kAhead ? NI : (sizeof(R) == 8 ? 32 : 64);     // operator entries in registers at a time
-        R ov[CH], ovn[kAhead ? NI : 1];
-        int ej = 0, ejn = 0;
-        if (kAhead && K > 1) {
-            const R* __restrict__ op = bt.op + cb0 * SP * SP;
-#pragma unroll
-            for (int ii = 0; ii < CH; ++ii) ov[ii] = op[(long long)(h * NI + ii) * SP + j];
-            ej = bt.opexp[cb0 * SP + j];
-        }
-        for (int n = 0; n + 1 < K; ++n) {
-            const R* __restrict__ opc = bt.op + (cb0 + n) * SP * SP;
-            if constexpr (kAhead) {
-                const long long k = cb0 + min(n + 1, K - 2);
-                const R* __restrict__ op = bt.op + k * SP * SP;
-#pragma unroll
-                for (int ii = 0; ii < NI; ++ii) ovn[ii] = op[(long long)(h * NI + ii) * SP + j];
-                ejn = bt.opexp[k * SP + j];
-            } else {
-#pragma unroll
-                for (int ii = 0; ii < CH; ++ii) ov[ii] = opc[(long long)(h * NI + ii) * SP + j];
-                ej = bt.opexp[(cb0 + n) * SP + j];
-            }
+        auto step = [&](int n, RV (&ov)[CHI], int ej) {
+            if constexpr (D == 0) fetch(n, ov, ej, 0);
             // weights y_i 2^{E_i}, shifted by the largest on the support of y
             int tj = kNone;
             if (tid < SP && y > (R)0) tj = ej + exponent_of(y);
             const int top = wide_block_max<SP>(tj, wmax, tid);
             if (tid < SP) vec[j] = (y > (R)0) ? scale2(y, ej - top) : (R)0;
-            __syncthreads();
-            R acc = 0;
+            lds_barrier();
+            R acc[NG][VEC];
 #pragma unroll
-            for (int c0 = 0; c0 < NI; c0 += CH) {
-                if (c0 > 0) {
+            for (int g = 0; g < NG; ++g)
 #pragma unroll
-                    for (int ii = 0; ii < CH; ++ii) ov[ii] = opc[(long long)(h * NI + c0 + ii) * SP + j];
+                for (int k = 0; k < VEC; ++k) acc[g][k] = 0;
+#pragma unroll
+            for (int i0 = 0; i0 < IPW; i0 += CHI) {
+                if (i0 > 0) fetch(n, ov, ej, i0);
+#pragma unroll
+                for (int q = 0; q < CHI; ++q) {
+                    const int row = kRows ? (wave * IPW + i0 + q) * RPI + sub : wave * RPW + (i0 + q) / NG;
+                    const R w = lone_register(vec[row]);       // (not the odd half of a loaded pair: vbx_device.hpp)
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[(i0 + q) % NG][k] += w * ov[q][k];
                 }
-#pragma unroll
-                for (int ii = 0; ii < CH; ++ii) acc += vec[h * NI + c0 + ii] * ov[ii];
             }
-            part[tid] = acc;
-            if constexpr (kAhead) {
+            if (RPI == 2) {                                    // lanes l and l + 32 hold the same columns
 #pragma unroll
-                for (int ii = 0; ii < NI; ++ii) ov[ii] = ovn[ii];
-                ej = ejn;
+                for (int k = 0; k < VEC; ++k) acc[0][k] = add_xor<32>(acc[0][k]);
             }
-            __syncthreads();
+            if (lane < LPR) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    RV v;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) v[k] = acc[g][k];
+                    *reinterpret_cast<RV*>(part + wave * SP + g * EPI + col0) = v;
+                }
+            }
+            lds_barrier();
             if (tid < SP) {
                 R tot = 0;
 #pragma unroll
-                for (int q = 0; q < HL; ++q) tot += part[q * SP + j];
-                y = (j < rd.S) ? tot : (R)0;           // padded speakers carry no mass
+                for (int w = 0; w < NW; ++w) tot += part[w * SP + j];
+                y = (j < rd.S) ? tot : (R)0;                   // padded speakers carry no mass
                 bt.fbound[(cb0 + n + 1) * SP + j] = y;
             }
-            __syncthreads();
+            lds_barrier();
+        };
+        if constexpr (D > 0) {
+            if (K > 1) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) fetch(d, ovr[d], ejr[d], 0);
+            }
+            for (int n = 0; n + 1 < K; n += D + 1) {
+#pragma unroll
+                for (int u = 0; u <= D; ++u) {
+                    if (n + u + 1 < K) {                       // (uniform)
+                        fetch(n + u + D, ovr[(u + D) % (D + 1)], ejr[(u + D) % (D + 1)], 0);
+                        step(n + u, ovr[u], ejr[u]);
+                    }
+                }
+            }
+        } else {
+            for (int n = 0; n + 1 < K; ++n) step(n, ovr[0], 0);
         }
     } else {
         R g = 0;
@@ -192,46 +250,37 @@ __global__ __launch_bounds__(1024) void scan2_wide_kernel(BatchView<R> bt) {
             bt.gbound[(cb0 + K - 1) * SP + j] = g;
             vec[j] = g;
         }
-        __syncthreads();
-        // (F^T g)_c = 2^{E_c} <column c, g>: a wavefront per output column, columns wave, wave + 16, ...; the columns
-        // of the next operator are requested right after the dot products of this one when the registers allow it
-        // (S <= 128), else at the top of their own step
-        constexpr int NC = SP / 16;
-        constexpr bool kAhead = NC * NL <= 16;
-        R ov[NC][NL];
-        int ej = 0;
-        auto fetch = [&](int n) {
-            const long long k = cb0 + K - 1 - min(n, K - 2);
-            const R* __restrict__ op = bt.op + k * SP * SP;
-#pragma unroll
-            for (int q = 0; q < NC; ++q)
-#pragma unroll
-                for (int r = 0; r < NL; ++r) ov[q][r] = op[(long long)(wave + 16 * q) * SP + lane + 64 * r];
-            ej = bt.opexp[k * SP + j];
-        };
-        if (kAhead && K > 1) fetch(0);
-        for (int n = 0; n + 1 < K; ++n) {
+        lds_barrier();
+        // (F^T g)_c = 2^{E_c} <row c of the stored operator, g>: the lanes of a row multiply their VEC elements with
+        // their VEC elements of g and the products meet in a butterfly over the row's lanes
+        auto step = [&](int n, RV (&ov)[CHI], int ecur) {
             const long long k = cb0 + K - 1 - n;
-            if (!kAhead) fetch(n);
-            R gl[NL];
+            if constexpr (D == 0) fetch(n, ov, ecur, 0);
+            RV gl[NG];
 #pragma unroll
-            for (int r = 0; r < NL; ++r) gl[r] = vec[lane + 64 * r];
-            R dots[NC];
+            for (int gq = 0; gq < NG; ++gq) gl[gq] = *reinterpret_cast<const RV*>(vec + gq * EPI + col0);
+            R rowdot = 0;
 #pragma unroll
-            for (int q = 0; q < NC; ++q) {
-                R acc = 0;
+            for (int i0 = 0; i0 < IPW; i0 += CHI) {
+                if (i0 > 0) fetch(n, ov, ecur, i0);
 #pragma unroll
-                for (int r = 0; r < NL; ++r) acc += ov[q][r] * gl[r];
-                dots[q] = acc;
+                for (int q = 0; q < CHI; ++q) {
+                    R p = 0;
+#pragma unroll
+                    for (int kk = 0; kk < VEC; ++kk) p += ov[q][kk] * gl[(i0 + q) % NG][kk];
+                    if constexpr (kRows) {
+                        p = allreduce_sum<(LPR < 64 ? 32 : 64)>(p);
+                        if (lane % LPR == 0) part[(wave * IPW + i0 + q) * RPI + sub] = p;
+                    } else {
+                        rowdot = ((i0 + q) % NG == 0) ? p : rowdot + p;
+                        if ((i0 + q) % NG == NG - 1) {
+                            const R t = allreduce_sum<64>(rowdot);
+                            if (lane == 0) part[wave * RPW + (i0 + q) / NG] = t;
+                        }
+                    }
+                }
             }
-            const int ecur = ej;
-            if (kAhead) fetch(n + 1);
-#pragma unroll
-            for (int q = 0; q < NC; ++q) {
-                const R acc = allreduce_sum<64>(dots[q]);
-                if (lane == 0) part[wave + 16 * q] = acc;
-            }
-            __syncthreads();
+            lds_barrier();
             R tot = 0;
             int tj = kNone;
             if (tid < SP) {
@@ -244,7 +293,24 @@ __global__ __launch_bounds__(1024) void scan2_wide_kernel(BatchView<R> bt) {
                 vec[j] = g;
                 bt.gbound[(k - 1) * SP + j] = g;
             }
-            __syncthreads();
+            lds_barrier();
+        };
+        if constexpr (D > 0) {
+            if (K > 1) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) fetch(d, ovr[d], ejr[d], 0);
+            }
+            for (int n = 0; n + 1 < K; n += D + 1) {
+#pragma unroll
+                for (int u = 0; u <= D; ++u) {
+                    if (n + u + 1 < K) {                       // (uniform)
+                        fetch(n + u + D, ovr[(u + D) % (D + 1)], ejr[(u + D) % (D + 1)], 0);
+                        step(n + u, ovr[u], ejr[u]);
+                    }
+                }
+            }
+        } else {
+            for (int n = 0; n + 1 < K; ++n) step(n, ovr[0], 0);
         }
     }
 }
