@@ -94,6 +94,26 @@ __global__ __launch_bounds__(256) void scan1_wide_kernel(BatchView<R> bt) {
     if ((tid % PH) == 0) bt.opexp[(long long)tile * SP + col] = expo;
 }
 
+// Two values (a, b) in every lane -> ONE per lane, summed over the lane pair (l, l ^ STAGE), STAGE = 16 or 32: lanes with
+// the STAGE bit clear get a(l) + a(l ^ STAGE), lanes with it set get b(l) + b(l ^ STAGE).  One v_permlane*_swap moves both
+// operands (it exchanges the upper lanes of its first register with the lower lanes of its second), so the cross-row stages
+// of a reduction of N values over a wavefront cost N / 2 + N / 4 swaps instead of 2 N.
+template <int STAGE> __device__ __forceinline__ float pair_sum_xor(float a, float b) {
+    const unsigned ua = __builtin_bit_cast(unsigned, a), ub = __builtin_bit_cast(unsigned, b);
+    const auto r = STAGE == 16 ? __builtin_amdgcn_permlane16_swap(ua, ub, false, false) : __builtin_amdgcn_permlane32_swap(ua, ub, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+template <int STAGE> __device__ __forceinline__ double pair_sum_xor(double a, double b) {
+    const unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
+    const auto lo = STAGE == 16 ? __builtin_amdgcn_permlane16_swap((unsigned)ua, (unsigned)ub, false, false)
+                                : __builtin_amdgcn_permlane32_swap((unsigned)ua, (unsigned)ub, false, false);
+    const auto hi = STAGE == 16 ? __builtin_amdgcn_permlane16_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false)
+                                : __builtin_amdgcn_permlane32_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+    const double x = __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi[0] << 32) | (unsigned)lo[0]);
+    const double y = __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi[1] << 32) | (unsigned)lo[1]);
+    return x + y;
+}
+
 // block-wide maximum of one int per thread of the first SP threads (SP a multiple of 64); every thread gets it
 // (an LDS barrier: the operator loads of later chain steps stay in flight across it)
 template <int SP> __device__ __forceinline__ int wide_block_max(int v, int* wmax, int tid) {
@@ -115,8 +135,8 @@ template <int SP> __device__ __forceinline__ int wide_block_max(int v, int* wmax
 //    steps ahead (where a thread's share fits the registers D + 1 times), and the barriers of a step are LDS barriers:
 //    __syncthreads() waits for every load in flight.  Round 3 read 4 / 8 bytes per lane one step ahead behind
 //    __syncthreads(): 272 wave loads per operator at S = 128, 1.55 us per step in fp32 and 2.95 in fp64 -- a recording
-//    of 79 chunks 125 / 240 us per launch, half of its iteration.  Now 0.98 / 2.6 us per step (76 / 202 us), S = 200 in
-//    fp64 (whose walk spilled 21 registers) 1.49 -> 0.96 ms per iteration;
+//    of 79 chunks 125 / 240 us per launch, half of its iteration.  Now 0.95 / 1.6 us per step (74 / 128 us), S = 200 in
+//    fp64 (whose walk spilled 21 registers) 1.49 -> 0.92 ms per iteration;
 //  * NW = 16: with 8 wavefronts the fp32 walk at S = 128 takes 92 us, with 4 it takes 117 (tools/cu_stream_probe.hip: one
 //    CU pulls 108 GB/s with 16 wavefronts loading, 87 with 4 at sixteen loads in flight each, 45 at four).
 // Layout: wave w owns rows [w RPW, (w + 1) RPW) of the operator (row = the index the mat-vec sums over in the forward
@@ -259,24 +279,56 @@ __global__ __launch_bounds__(NW * 64) void scan2_wide_kernel(BatchView<R> bt) {
             RV gl[NG];
 #pragma unroll
             for (int gq = 0; gq < NG; ++gq) gl[gq] = *reinterpret_cast<const RV*>(vec + gq * EPI + col0);
-            R rowdot = 0;
+            // The NV row products of a chunk of instructions are reduced over the W lanes of a row TOGETHER: the cross-row
+            // stages (xor 32, xor 16) halve the number of values a lane carries (pair_sum_xor), the four stages inside a
+            // row of 16 lanes run on what is left -- NV = 8 over 64 lanes: 4 + 2 pair exchanges and two DPP butterflies
+            // instead of eight six-stage butterflies (in fp64, where an add is half rate and a move two, those were most
+            // of the step).  Lane l ends up with the totals of the values q(l) below and the first lane of its row stores them.
+            constexpr int NV = kRows ? CHI : CHI / NG;             // row products per chunk of instructions
+            constexpr int W = (kRows && LPR < 64) ? 32 : 64;       // lanes a row is spread over
+            constexpr bool H32 = W == 64 && NV >= 2;
+            constexpr int C1 = H32 ? NV / 2 : NV;
+            constexpr bool H16 = C1 >= 2;
+            constexpr int C2 = H16 ? C1 / 2 : C1;
+            static_assert((NV & (NV - 1)) == 0, "a power of two of row products per chunk");
+            const int hb = (lane >> 5) & 1, rb = (lane >> 4) & 1;
 #pragma unroll
             for (int i0 = 0; i0 < IPW; i0 += CHI) {
                 if (i0 > 0) fetch(n, ov, ecur, i0);
+                R pr[NV];
 #pragma unroll
                 for (int q = 0; q < CHI; ++q) {
                     R p = 0;
 #pragma unroll
                     for (int kk = 0; kk < VEC; ++kk) p += ov[q][kk] * gl[(i0 + q) % NG][kk];
-                    if constexpr (kRows) {
-                        p = allreduce_sum<(LPR < 64 ? 32 : 64)>(p);
-                        if (lane % LPR == 0) part[(wave * IPW + i0 + q) * RPI + sub] = p;
+                    if constexpr (kRows) pr[q] = p;
+                    else pr[q / NG] = (q % NG == 0) ? p : pr[q / NG] + p;
+                }
+                if constexpr (W == 64) {
+                    if constexpr (H32) {
+#pragma unroll
+                        for (int i = 0; i < NV / 2; ++i) pr[i] = pair_sum_xor<32>(pr[2 * i], pr[2 * i + 1]);
                     } else {
-                        rowdot = ((i0 + q) % NG == 0) ? p : rowdot + p;
-                        if ((i0 + q) % NG == NG - 1) {
-                            const R t = allreduce_sum<64>(rowdot);
-                            if (lane == 0) part[wave * RPW + (i0 + q) / NG] = t;
-                        }
+                        pr[0] = add_xor<32>(pr[0]);
+                    }
+                }
+                if constexpr (H16) {
+#pragma unroll
+                    for (int i = 0; i < C1 / 2; ++i) pr[i] = pair_sum_xor<16>(pr[2 * i], pr[2 * i + 1]);
+                } else {
+                    pr[0] = add_xor<16>(pr[0]);
+                }
+#pragma unroll
+                for (int i = 0; i < C2; ++i) pr[i] = allreduce_sum<16>(pr[i]);
+                // lanes that differ in a bit whose stage did not halve hold the same totals: one of them stores
+                const bool writer = (lane & 15) == 0 && (H16 || rb == 0) && (W == 32 || H32 || hb == 0);
+                if (writer) {
+#pragma unroll
+                    for (int i = 0; i < C2; ++i) {
+                        const int q16 = H16 ? 2 * i + rb : i;                      // the slot before the xor-16 stage
+                        const int q = H32 ? 2 * q16 + hb : q16;                     // ... and before the xor-32 stage
+                        const int row = kRows ? (wave * IPW + i0 + q) * RPI + sub : wave * RPW + i0 / NG + q;
+                        part[row] = pr[i];
                     }
                 }
             }
