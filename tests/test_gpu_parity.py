@@ -695,6 +695,37 @@ def test_vbx_shapes_sweep_against_the_oracle(S, D):
         assert np.abs(a - ar).max() <= tol * max(1.0, np.abs(ar).max()) and np.abs(il - ir).max() <= tol
 
 
+@pytest.mark.parametrize('S', [100, 200])
+def test_wide_scan_on_recordings_of_one_to_five_chunks(ctx, S):
+    """The boundary walk of the wide chunked scan (vbx_scan_wide.hpp) requests its operators up to three chain steps ahead:
+    recordings of 1, 2, 3, 4 and 5 chunks (no step at all, fewer steps than the look-ahead, a ragged last chunk) against the
+    oracle (fp64) and against the sequential walk, which shares nothing with it (fp32: a toy of 513 frames for 200 speakers is
+    1.4e-4 from the oracle after two iterations on EITHER path -- what the EM map makes of f32 rounding, not the scan)."""
+    from vbx_amd import _capi
+    from vbx_amd.synth import make_recording
+    for T in (1, 100, 129, 300, 385, 513):
+        X, Phi, _ = make_recording(T, S, seed=S + T, kappa=0.1)
+        g0 = np.random.default_rng(S * 3 + T).gamma(1.0, size=(T, S))
+        g0 /= g0.sum(1, keepdims=True)
+        with contextlib.redirect_stdout(io.StringIO()):
+            gr, pr, Lr = _orc().VBx(X, Phi, loopProb=0.9, Fa=0.3, Fb=17.0, pi=S, gamma=g0, maxIters=2, epsilon=-1e300)
+        res = {}
+        for precision in ('fp64', 'fp32'):
+            for algo in (_capi.FB_CHUNKED, _capi.FB_SEQUENTIAL):
+                batch = _capi.Batch(ctx, [T], [S], 128, precision=precision, max_iters=2)
+                batch.set_option(_capi.OPT_FB_ALGO, algo)
+                batch.set_recording(0, X, Phi, np.ones(S) / S, g0, 0.9, 0.3, 17.0)
+                batch.run(2, -np.inf)
+                res[precision, algo] = batch.result(0, want_model=False)
+                batch.close()
+        r64, r32, s32 = res['fp64', _capi.FB_CHUNKED], res['fp32', _capi.FB_CHUNKED], res['fp32', _capi.FB_SEQUENTIAL]
+        assert np.abs(r64['gamma'] - gr).max() <= 1e-8, (T, np.abs(r64['gamma'] - gr).max())
+        assert np.abs(r64['pi'] - pr).max() <= 1e-8 and rel_err(r64['Li'], [r[0] for r in Lr]) <= 1e-10, T
+        assert np.abs(r32['gamma'] - gr).max() <= 3 * FP32_TOL, (T, np.abs(r32['gamma'] - gr).max())
+        assert np.abs(r32['gamma'] - s32['gamma']).max() <= FP32_TOL, (T, np.abs(r32['gamma'] - s32['gamma']).max())
+        assert rel_err(r32['Li'], [r[0] for r in Lr]) <= 1e-5, T
+
+
 @pytest.mark.parametrize('S', [65, 128, 200])
 def test_wide_speaker_counts_at_ten_thousand_frames(ctx, S):
     """64 < S <= 256 at T = 10 000 (AHC on a long file can hand VBx() that many clusters, vbhmm.py:150-158): the wide
