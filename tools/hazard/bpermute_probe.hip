@@ -8,7 +8,10 @@
 // register 0, 1, 2, 4 or 8 instruction slots later (s_nop in between), "load" wavefronts of the same workgroups hammer the
 // LDS with ds_read_b128, and every wrong lane value is counted.
 //
-//   hipcc --offload-arch=gfx950 -O3 -o bpermute_probe tools/bpermute_probe.hip && ./bpermute_probe
+// OUTCOME (profiles/r04_hazard/r04_bpermute_probe.txt): 0 wrong lane values in every configuration -- the permute was not the
+// cause; see tools/hazard/pk_opsel_probe.hip and DESIGN section 6.
+//
+//   hipcc --offload-arch=gfx950 -O3 -o bpermute_probe tools/hazard/bpermute_probe.hip && ./bpermute_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

@@ -7,7 +7,9 @@
 //   mode 1: is it the instruction?   v_pk_fma_f32 d, a, b, c op_sel:[0,1,0] on registers that have been valid for long
 //   mode 2: both: the loads as in mode 0, consumed by  v_pk_fma (plain) ; s_nop 0 ; v_pk_fma op_sel:[0,1,0]
 //
-//   hipcc --offload-arch=gfx950 -O3 -o lds_return_probe tools/lds_return_probe.hip && ./lds_return_probe
+// OUTCOME (profiles/r04_hazard/r04_lds_return_probe.txt): the loads alone never fail; the op_sel:[0,1,0] FMA alone does -- tools/hazard/pk_opsel_probe.hip takes it from there.
+//
+//   hipcc --offload-arch=gfx950 -O3 -o lds_return_probe tools/hazard/lds_return_probe.hip && ./lds_return_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 

@@ -11,7 +11,9 @@
 // plain v_add_f32 as the control) and three consumers (ds_bpermute_b32, ds_write_b64 + read back, global_store_dwordx2 +
 // read back); the other wavefronts of the workgroup keep the SIMDs and the LDS busy as chunk_post's do.
 //
-//   hipcc --offload-arch=gfx950 -O3 -o pk_forward_probe tools/pk_forward_probe.hip && ./pk_forward_probe
+// OUTCOME (profiles/r04_hazard/r04_pk_forward_probe.txt): 0 wrong in every configuration -- not the cause.
+//
+//   hipcc --offload-arch=gfx950 -O3 -o pk_forward_probe tools/hazard/pk_forward_probe.hip && ./pk_forward_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 

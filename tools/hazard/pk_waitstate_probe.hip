@@ -10,7 +10,9 @@
 // Victim wavefronts run producer / separator / consumer with nothing outstanding on any counter; the other wavefronts
 // of the workgroup keep the SIMDs busy with matrix instructions and 16-byte LDS reads, as chunk_post's do.
 //
-//   hipcc --offload-arch=gfx950 -O3 -o pk_waitstate_probe tools/pk_waitstate_probe.hip && ./pk_waitstate_probe
+// OUTCOME (profiles/r04_hazard/r04_pk_waitstate_probe.txt): 0 wrong in every configuration, adjacent dependent packed FMAs included -- not the cause.
+//
+//   hipcc --offload-arch=gfx950 -O3 -o pk_waitstate_probe tools/hazard/pk_waitstate_probe.hip && ./pk_waitstate_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 
