@@ -33,10 +33,14 @@ Also on the same JSON line:
                             0.9, the nine-point Fa/Fb sweep as one batch on a shared rho, and with private copies), fp32 and
                             fp64: ms per iteration, dominant kernel, algorithmic bytes, fraction of the HBM peak
   single_recording          latency-bound rate of ONE recording (batch=1) on one GPU
-  cpu_baseline              the reference's own VBx() -- oracle/_ref/VBx_reference.py, the file oracle/build_ref.py copies
-                            from /root/reference at build time (kind "reference"; git-ignored, it travels with the snapshot) --
-                            or, where that file is missing, the NumPy/SciPy restatement oracle/vbx_oracle.py (kind "port"),
-                            on the host cores, bounded sample (rank 0, N=1 only)
+  cpu_baseline              the NumPy/SciPy restatement oracle/vbx_oracle.py (kind "port": the reference's algorithm and
+                            third-party calls, pinned to the reference's outputs at this very size by
+                            tests/test_oracle_golden.py) on the host cores, bounded sample (rank 0, N=1 only).  Always the
+                            port: the same thing is timed on every box, and nothing of the reference travels
+
+Output: the FULL record goes to ``--full-out`` (default gpurun_out/bench_full.json) and to stderr; the LAST line of
+stdout is a compact JSON (< 4 KB, compact_record()) with the contract's keys, ``roofline``, ``cpu_baseline`` and a digest of
+the sub-records -- what the driver parses.
 """
 from __future__ import annotations
 
@@ -178,34 +182,16 @@ def make_sweep_batch(ctx, T, S, D, precision, max_iters, shared, loop_prob=0.9, 
     return batch
 
 
-def reference_module():
-    """The reference's own VBx.py as oracle/build_ref.py left it in oracle/_ref/ (None where that has not run)."""
-    path = os.path.join(REPO, 'oracle', '_ref', 'VBx_reference.py')
-    if not os.path.exists(path):
-        return None
-    import importlib.util
-    spec = importlib.util.spec_from_file_location('_vbx_reference', path)
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    return mod
-
-
 def cpu_baseline(T, S, D, iters, precision='fp32'):
-    """The reference's VBx() itself (kind "reference": oracle/_ref/VBx_reference.py, copied from /root/reference by
-    oracle/build_ref.py at build time) or, without it, the oracle (kind "port": same algorithm and third-party calls, pinned
-    to the reference's outputs at this very size by tests/test_oracle_golden.py).  Timed on one core; its first two
-    iterations also serve BASELINE.json's second metric: max |gamma - gamma_NumPy| of the GPU path on the same recording
-    and initialisation (two iterations: further on, fp32 and fp64 EM trajectories drift apart by themselves until they
-    meet again at convergence; tests/test_gpu_configs.py compares converged runs with the reference)."""
+    """The oracle (kind "port": oracle/vbx_oracle.py -- the reference's algorithm, arithmetic order and third-party calls
+    [scipy.special.logsumexp per frame], pinned to the reference's outputs at this very size by
+    tests/test_oracle_golden.py) timed on one core.  Its first two iterations also serve BASELINE.json's second metric:
+    max |gamma - gamma_NumPy| of the GPU path on the same recording and initialisation (two iterations: further on, fp32
+    and fp64 EM trajectories drift apart by themselves until they meet again at convergence, DESIGN section 9;
+    tests/test_gpu_configs.py compares converged runs with the reference)."""
     import contextlib
     import io
-    ref = reference_module()
-    if ref is not None:
-        vbx_oracle = ref
-        kind = 'reference'
-    else:
-        from oracle import vbx_oracle
-        kind = 'port'
+    from oracle import vbx_oracle                              # the checker / the baseline, never the product path
     from vbx_amd.synth import make_recording
     X, Phi, _ = make_recording(T, S, D=D, seed=0, kappa=0.05)
     g = np.random.default_rng(10_000).gamma(1.0, size=(T, S))
@@ -215,10 +201,9 @@ def cpu_baseline(T, S, D, iters, precision='fp32'):
     with contextlib.redirect_stdout(io.StringIO()):
         vbx_oracle.VBx(X, Phi, maxIters=iters, **kw)
     dt = time.perf_counter() - t0
-    out = {'value': iters / dt, 'unit': 'EM iterations/s', 'cores': 1, 'kind': kind,
-           'sample': f'{iters} iterations of one recording T={T} S={S} R={D} ('
-                     + ('the unmodified VBx/VBx.py::VBx of the reference' if kind == 'reference' else 'oracle/vbx_oracle.py')
-                     + f', float64, NumPy+SciPy logsumexp, {dt:.1f} s on {os.cpu_count()} visible cores; the path is single-threaded)'}
+    out = {'value': iters / dt, 'unit': 'EM iterations/s', 'cores': 1, 'kind': 'port',
+           'sample': f'{iters} iterations of one recording T={T} S={S} R={D} (oracle/vbx_oracle.py, float64, NumPy + SciPy '
+                     f'logsumexp per frame as VBx.py:167-171, {dt:.1f} s on {os.cpu_count()} visible cores; the path is single-threaded)'}
     import vbx_amd
     with contextlib.redirect_stdout(io.StringIO()):
         g_ref, pi_ref, L_ref = vbx_oracle.VBx(X, Phi, maxIters=2, **kw)
@@ -228,6 +213,84 @@ def cpu_baseline(T, S, D, iters, precision='fp32'):
         'elbo_max_rel_diff': float(max(abs(a[0] - b[0]) / abs(b[0]) for a, b in zip(L_gpu, L_ref))),
         'precision': precision, 'target': 1e-4}
     return out
+
+
+COMPACT_LIMIT = 4096            # bytes: the driver parses the LAST stdout line; round 4's 25 KB line came back unparsed
+
+
+def _sig(x, n=6):
+    """Numbers to n significant digits (the compact line is for reading and parsing, the full record keeps everything)."""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or x in (float('inf'), float('-inf')):
+        return None
+    return float(f'{x:.{n}g}')
+
+
+def compact_record(out):
+    """The last stdout line: the contract's keys verbatim, ``roofline`` and ``cpu_baseline`` reduced to their numeric
+    fields, and one digest entry {value, ms, frac, bound} per sub-record.  Pure function of the full record (tested on CPU,
+    tests/test_host_and_abi.py); guaranteed < COMPACT_LIMIT bytes -- digest entries are dropped from the end if ever needed."""
+    keep = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+            'vs_baseline', 'dtype', 'gemm', 'data')
+    c = {k: _sig(out[k], 9) for k in keep if k in out}
+    cfg = out.get('config', {})
+    c['config'] = {k: cfg[k] for k in ('workload', 'recordings_per_gpu', 'T', 'R', 'S', 'streams_per_gpu', 'parallelism') if k in cfg}
+    if len(c['config'].get('workload', '')) > 200:
+        c['config']['workload'] = c['config']['workload'][:197] + '...'
+    r = out.get('roofline')
+    if r:
+        c['roofline'] = {k: _sig(r.get(k)) for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source',
+                                                        'algorithmic_bytes_per_launch', 'avg_launch_us')}
+        c['roofline']['bound_today'] = r.get('bound_today')
+    w = out.get('roofline_whole_iteration')
+    if w:
+        c['step_frac_of_hbm_peak'] = _sig(w.get('fused_compulsory_frac_of_hbm_peak'))
+    cb = out.get('cpu_baseline')
+    if cb:
+        c['cpu_baseline'] = {k: _sig(cb.get(k)) for k in ('value', 'unit', 'cores', 'kind')}
+        c['cpu_baseline']['sample'] = cb.get('sample', '')[:160]
+        par = cb.get('parity_after_2_iterations')
+        if par:
+            c['gamma_max_abs_diff_vs_numpy'] = _sig(par['gamma_max_abs_diff'], 3)
+
+    def digest(d):
+        e = {'value': _sig(d.get('value'), 5), 'ms': _sig(d.get('ms_per_step', d.get('ms_per_iteration', d.get('ms_per_call'))), 5)}
+        roof = d.get('roofline') or d
+        if roof.get('frac') is not None:
+            e['frac'] = _sig(roof['frac'], 3)
+            e['bound'] = roof.get('bound_today', roof.get('bound'))
+        return e
+    subs = {}
+    for key in ('f32_exact', 'f32_split', 'f64', 'single_recording', 'strong_scaling_form'):
+        if key in out:
+            subs[key] = digest(out[key])
+    for key, d in out.get('configs', {}).items():
+        subs[key] = digest(d)
+    c['configs'] = subs
+    c['full_record'] = out.get('full_record')
+    line = json.dumps(c, separators=(',', ':'))
+    names = list(subs)
+    while len(line) >= COMPACT_LIMIT and names:                # (never needed at today's 25 sub-records: ~3 KB)
+        del subs[names.pop()]
+        c['configs_truncated'] = True
+        line = json.dumps(c, separators=(',', ':'))
+    assert len(line) < COMPACT_LIMIT, len(line)
+    return line
+
+
+def emit(out, full_path):
+    """Full record -> file (+ stderr); compact line -> the last line of stdout."""
+    if full_path:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(full_path)), exist_ok=True)
+            with open(full_path, 'w') as fh:
+                json.dump(out, fh, indent=1)
+            out['full_record'] = os.path.relpath(os.path.abspath(full_path), REPO)
+        except OSError as e:
+            out['full_record'] = f'not written: {e}'
+    print(json.dumps(out), file=sys.stderr, flush=True)
+    print(compact_record(out), flush=True)
 
 
 def respawn_under_torchrun(n):
@@ -265,6 +328,8 @@ def main():
     ap.add_argument('--no-f64', action='store_true', help='skip the fp64 sub-record')
     ap.add_argument('--no-configs', action='store_true', help='skip the C2 / C3 / C5 records (BASELINE.json configs[1,2,4])')
     ap.add_argument('--streams', type=int, default=None, help='HIP streams per batch (default: the library\'s choice)')
+    ap.add_argument('--full-out', default=os.path.join(REPO, 'gpurun_out', 'bench_full.json'),
+                    help="where the full record goes ('' = nowhere); stdout carries the compact line only")
     ap.add_argument('--dry-run', action='store_true', help='stop after the ranks are established (no GPU needed)')
     args = ap.parse_args()
     if args.precision == 'fp32-split':
@@ -369,14 +434,15 @@ def main():
     def roofline_of(per_kernel, dom, n_rec, T, S, D, es, workload, rho_copies=None):
         """``roofline`` of the dominant HBM-side kernel: algorithmic bytes of one launch / its HIP-event duration, the bytes it
         really moved (PMC) and what its SIMDs did meanwhile (SQ) where a profile of this workload on these kernel sources is
-        on file, and ``bound`` as those counters say (classify_bound).  ``achieved`` / ``frac`` are always against the HBM
-        peak: the algorithm is on the bandwidth side of the roofline whatever a kernel's present limit is."""
+        on file.  ``bound`` = "hbm": the roofline the path is priced against (the algorithm is on the bandwidth side, DESIGN
+        section 4) -- ``achieved`` / ``frac`` are always against the HBM peak; ``bound_today`` = what the counters say limits
+        the kernel as it stands (classify_bound)."""
         dom_bytes = algo_bytes(dom, T, D, S, es, n_rec, rho_copies)
         avg_us = per_kernel[dom]['avg_us']
         achieved = dom_bytes / (avg_us * 1e-6) / 1e9
         traffic = pmc_traffic(dom, workload)
         issue = sq_issue(dom, workload)
-        out = {'bound': classify_bound(issue, traffic[0], avg_us), 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+        out = {'bound': 'hbm', 'bound_today': classify_bound(issue, traffic[0], avg_us), 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic[0], 'traffic_source': traffic[1],
                'algorithmic_bytes_per_launch': dom_bytes, 'avg_launch_us': avg_us, 'simd_issue': issue}
         if traffic[0] is not None:
@@ -434,7 +500,7 @@ def main():
                 'blocks_of_K_steps': len(ts), 'seconds': sum(ts),
                 'dominant_kernel': dk, 'avg_us': roof['avg_launch_us'], 'algorithmic_bytes': roof['algorithmic_bytes_per_launch'],
                 'frac': roof['frac'], 'achieved_GBs': roof['achieved'], 'traffic': roof['traffic'],
-                'traffic_source': roof['traffic_source'], 'bound': roof['bound'], 'simd_issue': roof['simd_issue'],
+                'traffic_source': roof['traffic_source'], 'bound': roof['bound_today'], 'simd_issue': roof['simd_issue'],
                 'rho_copies_read': n_rec if rho_copies is None else rho_copies,
                 'iteration_compulsory_bytes': fused, 'iteration_frac_of_hbm_peak': fused / (dt / K) / 1e9 / HBM_PEAK_GBS,
                 'kernels_avg_us': {k: round(v['avg_us'], 2) for k, v in pk.items()}, 'elbo_last': elbo}
@@ -633,7 +699,7 @@ def main():
             out['cpu_baseline'] = cb
             if single_rec:
                 out['single_recording']['speedup_vs_cpu_baseline'] = single_rec['value'] / cb['value']
-        print(json.dumps(out))
+        emit(out, args.full_out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

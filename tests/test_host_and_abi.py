@@ -154,3 +154,39 @@ def test_sweep_api_host_side():
         VBx_sweep(X, Phi, [dict(Fc=1.0)], maxIters=0, pi=3, gamma=g0)
     with pytest.raises(AssertionError):                           # VBx.py:85 per point
         VBx_sweep(X, Phi, [dict(pi=4)], maxIters=0, gamma=g0)
+
+
+def test_bench_last_line_is_compact_and_complete():
+    """bench.py: the LAST stdout line (what the driver parses) is a compact JSON < 4 KB with the contract's keys, `roofline`
+    and `cpu_baseline` -- formatted here from a canned full record (the closing bench line of round 4, 25 KB, which the
+    driver could not parse) with today's key names patched in."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location('bench_under_test', os.path.join(REPO, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    full = json.load(open(os.path.join(REPO, 'profiles', 'r04_bench_driver_args.json')))
+    assert len(json.dumps(full)) > 20000                      # (the record that went unparsed)
+    for roof in [full['roofline']] + [full[k]['roofline'] for k in ('f32_split', 'f64')]:
+        roof['bound_today'], roof['bound'] = roof['bound'], 'hbm'
+    full['cpu_baseline']['kind'] = 'port'
+    line = bench.compact_record(full)
+    assert '\n' not in line and len(line) < 4096, len(line)
+    c = json.loads(line)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'configs'):
+        assert k in c, k
+    assert c['steps'] == 20 and c['warmup'] == 5 and c['n_gpus'] == 1 and 'workload' in c['config']
+    assert abs(c['value'] - full['value']) < 1e-6 * full['value']
+    assert abs(c['ms_per_step'] - full['ms_per_step']) < 1e-6 * full['ms_per_step']
+    assert set(c['roofline']) >= {'bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source',
+                                  'algorithmic_bytes_per_launch', 'avg_launch_us'}
+    assert c['roofline']['bound'] in ('hbm', 'mfma') and abs(c['roofline']['frac'] - c['roofline']['achieved'] / c['roofline']['peak']) < 1e-4
+    assert set(c['cpu_baseline']) == {'value', 'unit', 'cores', 'kind', 'sample'} and c['cpu_baseline']['kind'] == 'port'
+    assert set(full['configs']) <= set(c['configs']) and 'f32_split' in c['configs'] and 'f64' in c['configs']
+    for name, d in c['configs'].items():
+        assert set(d) <= {'value', 'ms', 'frac', 'bound'} and d['value'] is not None, name
+    # a record three times the size still fits: entries are dropped from the end and the line says so
+    big = dict(full, configs={f'{k}_{i}': v for k, v in full['configs'].items() for i in range(6)})
+    line = bench.compact_record(big)
+    assert len(line) < 4096 and json.loads(line).get('configs_truncated') is True
