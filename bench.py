@@ -453,8 +453,9 @@ def main():
     # upper bound on the iterations a batch will be asked for (the ELBO history lives on the device)
     budget = W + K * (args.max_blocks + 2) + 16
 
-    def headline(precision, max_iters, streams):
-        return make_batch(ctx, args.batch, args.T, args.S, args.D, precision, seed0=rank * args.batch,
+    def headline(precision, max_iters, streams, n_rec=None):
+        n_rec = args.batch if n_rec is None else n_rec
+        return make_batch(ctx, n_rec, args.T, args.S, args.D, precision, seed0=rank * n_rec,
                           max_iters=max_iters, streams=streams)
 
     per_kernel, dom, probe_ms_per_step, probe_blocks = kernel_probe(lambda mi, st: headline(head_prec, mi, st),
@@ -471,6 +472,17 @@ def main():
     med = statistics.median(times)
     if args.precision == 'fp32':
         assert gemm_ran == args.gemm, f'--gemm {args.gemm} but the library multiplied {gemm_ran}'
+
+    # ---- a multi-GPU run also measures BASELINE configs[3] AS STATED -- 64 recordings over ALL ranks, 64 / N per GPU
+    # (strong scaling) -- next to the weak-scaling headline, so that one driver sweep N = 1, 2, 4, 8 yields both curves
+    strong = None
+    STATED_TOTAL = 64
+    if world > 1 and args.total_recordings is None and STATED_TOTAL % world == 0:
+        bs = headline(head_prec, budget, args.streams, n_rec=STATED_TOTAL // world)
+        bs.run(W, -np.inf)
+        ts_ = timed_blocks(bs, args.min_seconds / 2, args.max_blocks)
+        strong = (ts_, bs.streams)
+        bs.close()
 
     # ---- the other configurations of BASELINE.json, each with its own kernel-level figure (rank 0 measures what fits one
     # GPU by itself; the multi-GPU metric is the batch above).  value = recording-iterations/s like the headline.
@@ -686,6 +698,14 @@ def main():
                           'one_stream_ms_per_step': ms64,
                           'note': 'same batch on the fp64 path (f64 storage, v_mfma_f64_16x16x4_f64): what vbhmm.py '
                                   'gets, its inputs being float64; reproduces the reference\'s iteration counts'}
+        if strong:
+            ms_ = statistics.median(strong[0])
+            out['strong_scaling_form'] = {
+                'value': STATED_TOTAL * K / ms_, 'unit': 'recording-EM-iterations/s', 'ms_per_step': 1e3 * ms_ / K,
+                'scaling': 'strong', 'recordings_total': STATED_TOTAL, 'recordings_per_gpu': STATED_TOTAL // world,
+                'streams_per_gpu': strong[1], 'blocks_of_K_steps': len(strong[0]),
+                'note': 'BASELINE configs[3] as stated: 64 recordings over all ranks (python bench.py --gpus N '
+                        '--total-recordings 64 makes this the headline); 8 per GPU at N = 8 is the launch-latency regime'}
         if configs:
             out['configs'] = configs
             out['configs_note'] = ('the other configurations of BASELINE.json, each measured like the headline: ms per EM iteration '

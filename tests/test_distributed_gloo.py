@@ -70,6 +70,23 @@ def _worker(rank, world, port, outdir):
         assert have == (list(range(len(res))) if rank == 0 else mine), (rank, have, mine)
         for b in have:
             assert all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(at_root[b], res[b]))
+        # a rank normalises only what it owns; foreign recordings cost it the RNG draw (gamma=None) or nothing (gamma given)
+        from vbx_amd import batch as vb
+        mixed = _recordings()
+        g_rng = np.random.default_rng(3)
+        for k in (0, 3):
+            T, S = mixed[k]['X'].shape[0], mixed[k]['pi']
+            g = g_rng.gamma(1.0, size=(T, S))
+            mixed[k]['gamma'] = g / g.sum(1, keepdims=True)
+        calls, real = [], vb._normalise
+        vb._normalise = lambda rec, defaults: (calls.append(rec['X'].shape[0]), real(rec, defaults))[1]
+        try:
+            np.random.seed(11)
+            part = VBx_batch_distributed(mixed, maxIters=3, epsilon=-np.inf, Fa=0.3, Fb=17.0, run_shard=_oracle_shard, gather=False)
+        finally:
+            vb._normalise = real
+        assert sorted(calls) == sorted(mixed[b]['X'].shape[0] for b in mine), (rank, calls, mine)
+        np.savez(os.path.join(outdir, f'mixed{rank}.npz'), **{f'g{b}': r[0] for b, r in enumerate(part) if r is not None})
         np.savez(os.path.join(outdir, f'rank{rank}.npz'), mine=np.array(mine),
                  **{f'g{b}': r[0] for b, r in enumerate(res)}, **{f'pi{b}': r[1] for b, r in enumerate(res)},
                  **{f'L{b}': np.array(r[2]) for b, r in enumerate(res)},
@@ -98,6 +115,21 @@ def test_two_rank_gloo_sharding_matches_single_process(tmp_path):
             assert np.array_equal(ranks[r][f'a{b}'], ref[3])
     assert set(ranks[0]['mine'].tolist()) | set(ranks[1]['mine'].tolist()) == set(range(len(recs)))
     assert not set(ranks[0]['mine'].tolist()) & set(ranks[1]['mine'].tolist())
+    # the mixed list (two recordings bring their gamma, three draw it): every rank's own results are what one process gets
+    mixed = _recordings()
+    g_rng = np.random.default_rng(3)
+    for k in (0, 3):
+        g = g_rng.gamma(1.0, size=(mixed[k]['X'].shape[0], mixed[k]['pi']))
+        mixed[k]['gamma'] = g / g.sum(1, keepdims=True)
+    np.random.seed(11)
+    one = VBx_batch_distributed(mixed, maxIters=3, epsilon=-np.inf, Fa=0.3, Fb=17.0, run_shard=_oracle_shard)
+    seen = set()
+    for r in range(world):
+        with np.load(tmp_path / f'mixed{r}.npz') as z:
+            for key in z.files:
+                assert np.array_equal(z[key], one[int(key[1:])][0]), (r, key)
+                seen.add(int(key[1:]))
+    assert seen == set(range(len(mixed)))
 
 
 def test_lpt_assignment_is_balanced_and_deterministic():

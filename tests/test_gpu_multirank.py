@@ -96,3 +96,61 @@ def test_driver_under_torchrun_on_one_gpu(tmp_path):
     assert sorted(t['rank'] for t in timings) == [0, 1] and all(t['world'] == 2 for t in timings), res.stdout
     assert sorted(t['recordings'] for t in timings) == [1, 2]                  # recA on one rank, recB + recC on the other
     td._check_rttm(paths)
+
+
+# ---- RCCL: only on a box with more than one GPU (the single-GPU test boxes skip; a multi-GPU lease tests RCCL, not gloo) ----
+def _gpu_count():
+    import torch
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+def _rccl_worker(rank, world, port, outdir):
+    sys.path.insert(0, REPO)
+    os.environ['VBX_AMD_DEVICE'] = str(rank)                    # one GPU per rank
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    import torch
+    import torch.distributed as dist
+    from vbx_amd.batch import VBx_batch_distributed
+    torch.cuda.set_device(rank)
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world,
+                            device_id=torch.device('cuda', rank))
+    try:
+        one = torch.ones(1, device='cuda')
+        dist.all_reduce(one)                                    # RCCL carries a byte
+        assert int(one.item()) == world
+        np.random.seed(11)
+        res = VBx_batch_distributed(_recordings(), maxIters=6, epsilon=1e-6, Fa=0.3, Fb=17.0, return_model=True, gather='root')
+        have = [b for b, r in enumerate(res) if r is not None]
+        np.savez(os.path.join(outdir, f'rccl{rank}.npz'), have=np.array(have),
+                 **{f'g{b}': res[b][0] for b in have}, **{f'pi{b}': res[b][1] for b in have})
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason='RCCL needs one GPU per rank: fewer than two GPUs on this box')
+def test_rccl_gather_to_root_on_a_multi_gpu_box(tmp_path):
+    """Two ranks, two GPUs, backend nccl (= RCCL): an all_reduce, then VBx_batch_distributed(gather='root') == VBx_batch."""
+    import torch.multiprocessing as mp
+    from vbx_amd.batch import VBx_batch
+    world, port = 2, _free_port()
+    mp.spawn(_rccl_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    np.random.seed(11)
+    single = VBx_batch(_recordings(), maxIters=6, epsilon=1e-6, Fa=0.3, Fb=17.0, return_model=True)
+    root = np.load(tmp_path / 'rccl0.npz')
+    assert root['have'].tolist() == list(range(len(single)))
+    for b in range(len(single)):
+        np.testing.assert_allclose(root[f'g{b}'], single[b][0], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(root[f'pi{b}'], single[b][1], rtol=0, atol=1e-13)
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason='fewer than two GPUs on this box')
+def test_bench_two_gpus_prints_a_compact_line_with_both_scaling_forms():
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    res = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '2',
+                          '--min-seconds', '0.1', '--batch', '8', '--full-out', ''], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith('{')][-1]
+    rec = json.loads(line)
+    assert len(line) < 4096 and rec['n_gpus'] == 2 and rec['scaling'] == 'weak' and rec['value'] > 0
+    assert rec['configs']['strong_scaling_form']['value'] > 0

@@ -90,7 +90,7 @@ def test_device_code_holds_no_packed_f32_instruction_that_selects_src1_from_the_
     (tools/hazard/pk_opsel_probe.hip) -- the cause of round 4's wrong sums in ``chunk_post``.  ``vbx_amd.build.audit_isa``
     finds the form in a disassembly; the built library must be free of it (no GPU needed)."""
     from vbx_amd import build as hipbuild
-    if not os.path.exists(hipbuild.OBJDUMP) or not os.path.exists(hipbuild.LIB):
+    if not hipbuild.OBJDUMP or not os.path.exists(hipbuild.LIB):
         pytest.skip('llvm-objdump or the built library not available')
     asm = hipbuild.disassemble()
     assert 'v_mfma_f32_16x16x32_f16' in asm and 'v_permlane32_swap' in asm and 'v_pk_fma_f32' in asm     # (it is the device code)

@@ -361,10 +361,14 @@ class Batch:
         ctx.check(self._lib.vbx_batch_create(ctx._h, self.n, Ta, Sa, self.D, self.precision, self.max_iters,
                                              C.byref(h)), 'vbx_batch_create')
         self._h = h
+        def choice(var, value, table):
+            if value not in table:
+                raise ValueError(f'{var}={value!r}: expected one of {", ".join(map(repr, table))}')
+            return table[value]
         algo = os.environ.get('VBX_AMD_FB_ALGO')          # 'sequential' | 'chunked' (default: auto)
         if algo:
-            self.set_option(OPT_FB_ALGO, {'auto': FB_AUTO, 'sequential': FB_SEQUENTIAL,
-                                          'chunked': FB_CHUNKED}[algo])
+            self.set_option(OPT_FB_ALGO, choice('VBX_AMD_FB_ALGO', algo, {'auto': FB_AUTO, 'sequential': FB_SEQUENTIAL,
+                                                                          'chunked': FB_CHUNKED}))
         if os.environ.get('VBX_AMD_TWO_LEVEL_FROM') is not None:
             self.set_option(OPT_TWO_LEVEL_FROM, int(os.environ['VBX_AMD_TWO_LEVEL_FROM']))
         group = os.environ.get('VBX_AMD_SCAN_GROUP')      # chunks per group of the two-level boundary walk
@@ -378,7 +382,11 @@ class Batch:
         split = os.environ.get('VBX_AMD_SPLIT_TILES')     # 1 / 2: half-tile re-runs on / off (0: the library's choice)
         if split is not None:
             self.set_option(OPT_SPLIT_TILES, int(split))
-        gemm = os.environ.get('VBX_AMD_GEMM')             # 'exact' | 'split' (VBX_OPT_GEMM)
+        # VBX_OPT_GEMM: the precision argument decides where it names a mode ('fp32-split'); VBX_AMD_GEMM = exact | split
+        # decides for a plain 'fp32' -- an explicit argument is never overridden by the environment, in either direction
+        gemm = os.environ.get('VBX_AMD_GEMM')
+        if gemm:
+            choice('VBX_AMD_GEMM', gemm, {'exact': GEMM_EXACT, 'split': GEMM_SPLIT})
         if isinstance(precision, str) and precision in SPLIT_NAMES:
             gemm = 'split'
         if gemm:

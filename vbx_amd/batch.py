@@ -65,6 +65,22 @@ def _normalise(rec, defaults):
                 Fb=kw['Fb'], alpha=kw['alpha'], invL=kw['invL'])
 
 
+def _shape_of(rec, defaults):
+    """(T, S, alphaQInit or None) of a recording WITHOUT normalising it: what sharding needs from a recording another rank
+    will run.  The third entry is the Dirichlet parameter when the recording draws its initialisation from the global RNG
+    (``gamma`` absent or None, VBx.py:79-83), else None.  Same validation of the keys as _normalise."""
+    bad = (set(rec) | set(defaults)) - set(PER_RECORDING) - set(PER_BATCH) - {'X', 'Phi'}
+    if bad:
+        raise TypeError(f'VBx_batch: unexpected per-recording argument(s) {sorted(bad)}; accepted: '
+                        f'{", ".join(PER_RECORDING)} (and, ignored, the per-batch ones: {", ".join(PER_BATCH)})')
+    kw = {k: v for k, v in defaults.items() if k in PER_RECORDING}
+    kw.update({k: v for k, v in rec.items() if k in PER_RECORDING})
+    pi = kw.get('pi', 10)
+    S = pi if type(pi) is int else len(pi)
+    T = np.shape(rec['X'])[0]
+    return int(T), int(S), (kw.get('alphaQInit', 1.0) if kw.get('gamma') is None else None)
+
+
 def _padded_states(n_states):
     """The padded state count a vbx_batch of this many speakers runs with (vbx_capi.hip: powers of two from 16)."""
     sp = 16
@@ -182,9 +198,11 @@ def VBx_batch_distributed(recordings, maxIters=10, epsilon=1e-4, precision=None,
     Every rank passes the same list; rank r computes the recordings assigned to it (LPT on T x S) on its own GPU.  There
     is no collective on the data path; what happens to the RESULTS afterwards is the caller's choice:
 
-      gather=True / 'all'    ``all_gather_object``: every rank returns the complete list (the behaviour ``True`` has always
-                             had; world x the bytes of the responsibilities: 8 T S per recording -- 2.4 MB at T = 10 000,
-                             S = 30, 154 MB per rank for BASELINE config 4)
+      gather=True / 'all'    ``all_gather_object``: every rank returns the complete list.  (Rounds 1-3 implemented ``True`` as
+                             one gather to rank 0 while documenting "every rank"; since round 4 the code does what the
+                             documentation said.  It costs world x the bytes of the responsibilities: 8 T S per recording
+                             -- 2.4 MB at T = 10 000, S = 30, 154 MB per rank for BASELINE config 4 -- so anything that
+                             only WRITES results should ask for 'root' or False)
       gather='root'          one ``gather_object`` to rank 0, which returns the complete list; every other rank returns
                              its own results and ``None`` for the rest -- the responsibilities travel once, to the rank
                              that writes them out (what ``vbx_amd.vbhmm`` and ``bench.py`` want)
@@ -195,19 +213,29 @@ def VBx_batch_distributed(recordings, maxIters=10, epsilon=1e-4, precision=None,
 
     ``run_shard(items, maxIters, epsilon)`` defaults to the HIP path; the CPU test-suite injects the oracle here."""
     import torch.distributed as dist
+    if gather not in (True, False, 'root', 'all'):
+        raise ValueError(f"gather={gather!r}: expected True / 'all' (every rank gets everything), 'root' (rank 0 does) or False")
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
-    items = [_normalise(r, defaults) for r in recordings]                  # same RNG draws on every rank
-    costs = [it['X'].shape[0] * len(it['pi']) for it in items]
-    assignment = shard_recordings(costs, world)
-    mine = [b for b in range(len(items)) if assignment[b] == rank]
+    # Who runs what follows from the shapes alone, so a rank normalises (copies, checks, converts) only the recordings it
+    # owns: host work per rank is O(its shard), not O(corpus).  The one thing every rank must do for every recording is
+    # the global-RNG draw of a ``gamma=None`` initialisation (VBx.py:79-83): the draws come from ONE stream in list order,
+    # so a rank that skipped a foreign recording's draw would initialise its own later recordings differently from a
+    # single process.  Recordings that bring their gamma cost a foreign rank nothing.
+    shapes = [_shape_of(r, defaults) for r in recordings]
+    assignment = shard_recordings([t * s for t, s, _ in shapes], world)
+    mine, items = [], {}
+    for b, rec in enumerate(recordings):
+        if assignment[b] == rank:
+            items[b] = _normalise(rec, defaults)                           # (draws, if it has to, at its place in the order)
+            mine.append(b)
+        elif shapes[b][2] is not None:
+            np.random.gamma(shapes[b][2], size=(shapes[b][0], shapes[b][1]))     # keep the global stream in step; discard
     if run_shard is None:
         def run_shard(sub, mi, eps):
             return run_shard_hip(sub, mi, eps, precision=precision)
     local = run_shard([items[b] for b in mine], int(maxIters), epsilon) if mine else []
     local = {b: res for b, res in zip(mine, local)}
-    if gather not in (True, False, 'root', 'all'):
-        raise ValueError(f"gather={gather!r}: expected True / 'root', 'all' or False")
     merged = dict(local)
     if gather and world > 1:
         if gather in (True, 'all'):
@@ -218,4 +246,4 @@ def VBx_batch_distributed(recordings, maxIters=10, epsilon=1e-4, precision=None,
             dist.gather_object(local, parts, dst=0)
         for p in parts or []:
             merged.update(p)
-    return [(_as_tuple(merged[b], return_model, warn=b in local) if b in merged else None) for b in range(len(items))]
+    return [(_as_tuple(merged[b], return_model, warn=b in local) if b in merged else None) for b in range(len(recordings))]

@@ -12,7 +12,25 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.environ.get('VBX_AMD_LIB') or os.path.join(CSRC, 'libvbx_hip.so')   # (VBX_AMD_LIB: an experiment build, tools/build_variants.sh)
-OBJDUMP = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+
+
+def _find_objdump() -> str | None:
+    """llvm-objdump of the ROCm in use: $ROCM_PATH, next to the hipcc that compiles, /opt/rocm, then PATH."""
+    cands = []
+    for root in (os.environ.get('ROCM_PATH'), os.environ.get('HIP_PATH')):
+        if root:
+            cands.append(os.path.join(root, 'lib', 'llvm', 'bin', 'llvm-objdump'))
+    hipcc = os.environ.get('HIPCC') or shutil.which('hipcc')
+    if hipcc:
+        cands.append(os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc))), 'lib', 'llvm', 'bin', 'llvm-objdump'))
+    cands += ['/opt/rocm/lib/llvm/bin/llvm-objdump', shutil.which('llvm-objdump')]
+    for c in cands:
+        if c and os.path.exists(c):
+            return c
+    return None
+
+
+OBJDUMP = _find_objdump()
 SOURCES = ['vbx_capi.hip']
 HEADERS = ['vbx_device.hpp', 'vbx_kernels.hpp', 'vbx_scan.hpp', 'vbx_scan_wide.hpp', 'vbx_fb_dense.hpp', 'vbx_operator.hpp', 'vbx_split.hpp', 'vbx_chunk_loglik.hpp', 'vbx_chunk_post.hpp', 'vbx_linkage.hpp', 'vbx_ahc.hpp', 'vbx_frontend.hpp', os.path.join('..', '..', 'include', 'vbx_hip.h')]
 # -slp-vectorize-hor=false: the compiler's vectorised sums end in "v_pk_add_f32 d, p, p op_sel:[0,1]" (x + y of a register
@@ -65,7 +83,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if not force and not is_stale():
             return LIB
         tmp = f'{LIB}.{os.getpid()}.tmp'
-        cmd = [_hipcc()] + FLAGS + ['-o', tmp] + SOURCES
+        # a library that cannot be audited (audit_isa below) is built so that it refuses the split GEMM mode -- the one mode
+        # the packed-f32 misread of DESIGN section 6 was ever seen in -- instead of accepting it unchecked
+        audit = OBJDUMP is not None and not os.environ.get('VBX_AMD_SKIP_ISA_AUDIT')
+        if not audit:
+            import warnings
+            warnings.warn('libvbx_hip.so: no ISA audit (' + ('VBX_AMD_SKIP_ISA_AUDIT is set' if OBJDUMP else 'llvm-objdump not found')
+                          + '); built with -DVBX_ISA_UNAUDITED: VBX_GEMM_SPLIT / precision="fp32-split" will be refused')
+        cmd = [_hipcc()] + FLAGS + ([] if audit else ['-DVBX_ISA_UNAUDITED=1']) + ['-o', tmp] + SOURCES
         if verbose:
             print(' '.join(cmd))
         res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
@@ -73,7 +98,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             if os.path.exists(tmp):
                 os.remove(tmp)
             raise RuntimeError('hipcc failed:\n' + res.stdout + res.stderr)
-        if os.path.exists(OBJDUMP) and not os.environ.get('VBX_AMD_SKIP_ISA_AUDIT'):
+        if audit:
             bad = audit_isa(disassemble(tmp))
             if bad:
                 os.remove(tmp)

@@ -43,14 +43,30 @@ __device__ __forceinline__ f4 mfma_split(h8 ah, h8 al, h8 bh, h8 bl, f4 c) {
     return mfma_h(ah, bh, c);
 }
 
-// largest |rho| of a recording -> amax[0] (bits of a non-negative float order like integers); grid = tiles of the recording
+// largest |rho| of a recording -> amax[0], and the smallest over its frames of the frame's largest |rho| -> amax[1] (bits of
+// a non-negative float order like integers; all-zero frames do not count); grid = tiles of the recording.  The pair is the
+// dynamic range the ONE power-of-two scale of a recording has to cover: a frame whose largest element sits more than
+// kSplitRangeBits below the recording's largest would carry its lo halves as f16 subnormals (fewer than the 22 bits the
+// mode promises), so such a batch multiplies exactly instead (prepare_split, vbx_capi.hip).  NaN / Inf: fmaxf drops a NaN, so
+// the scale comes from the finite elements and the NaN itself reaches the matrix cores as an f16 NaN -- the result is NaN
+// in both modes.
+constexpr int kSplitRangeBits = 10;
 __global__ __launch_bounds__(256) void rho_absmax_kernel(const float* __restrict__ rho, int T, int Dp, int* __restrict__ amax) {
-    const long long n = (long long)min(kTileFrames, T - (int)blockIdx.x * kTileFrames) * Dp;
+    const int rows = min(kTileFrames, T - (int)blockIdx.x * kTileFrames);
     const float* __restrict__ src = rho + (long long)blockIdx.x * kTileFrames * Dp;
-    float m = 0.0f;
-    for (long long q = threadIdx.x; q < n; q += 256) m = fmaxf(m, fabsf(src[q]));
-    m = allreduce_max<64>(m);
-    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(amax, __builtin_bit_cast(int, m));
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float m = 0.0f, lo = __builtin_huge_valf();
+    for (int r = wave; r < rows; r += 4) {             // a wave per frame
+        float rm = 0.0f;
+        for (int d = lane; d < Dp; d += 64) rm = fmaxf(rm, fabsf(src[(long long)r * Dp + d]));
+        rm = allreduce_max<64>(rm);
+        m = fmaxf(m, rm);
+        if (rm > 0.0f) lo = fminf(lo, rm);
+    }
+    if (lane == 0) {
+        if (m > 0.0f) atomicMax(amax, __builtin_bit_cast(int, m));
+        if (lo < __builtin_huge_valf()) atomicMin(amax + 1, __builtin_bit_cast(int, lo));
+    }
 }
 
 // rho (f32, [T][Dp]) of one recording -> its tiles of rho_a and rho_b; grid = tiles of the recording, block = 256.
