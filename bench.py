@@ -25,9 +25,14 @@ Also on the same JSON line:
   roofline                  dominant kernel: algorithmic bytes / HIP-event time vs the 8 TB/s HBM peak
   roofline_whole_iteration  the five launches of an iteration together, against the survey's byte count (SURVEY 8d:
                             one kernel per stage) and against the fused design's compulsory bytes
-  f32_split                 the same batch with the two GEMMs on f16 operand pairs (VBX_OPT_GEMM = split: v_mfma_f32_16x16x32_f16,
-                            fp32 storage and accumulation; vbx_amd/csrc/vbx_split.hpp), with its own roofline.  `value` stays the
-                            exact-f32 line (--gemm exact) unless --gemm split is asked for
+  f32_exact                 the headline (`value`) multiplies rho alpha^T and gamma^T rho with f16 operand pairs on the matrix
+                            cores (VBX_OPT_GEMM = split: v_mfma_f32_16x16x32_f16, three products per pair, fp32 storage and
+                            accumulation; vbx_amd/csrc/vbx_split.hpp) -- the headline since round 5 under the condition the
+                            round-4 review set: every parity entry of tests/test_gpu_configs.py within north_star's 1e-4 (all
+                            nine C5 points against the extended-precision referee included), geometric mean of the deviations
+                            split / exact <= 1.2, a recording's result independent of its batch (tests/test_gpu_split.py).
+                            f32_exact = the same batch with the exact f32 matrix instruction (--gemm exact makes it the
+                            headline and the split the sub-record f32_split), with its own roofline
   f64                       the same batch on the fp64 path (what vbhmm.py gets: its inputs are float64), with its own roofline
   configs                   BASELINE.json configs[1], [2], [4]: C2 (T=10k, S=10), C3 (T=50k, S=30), C5 (T=200k, S=50, loopProb
                             0.9, the nine-point Fa/Fb sweep as one batch on a shared rho, and with private copies), fp32 and
@@ -48,7 +53,7 @@ import argparse
 import json
 import os
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')   # before any HIP runtime starts (torch included): the library's stream
-                                                    # groups want one hardware queue per stream (vbx_capi.hip)
+                                                    # groups want one hardware queue per stream (vbx_host_state.hpp)
 import socket
 import statistics
 import sys
@@ -161,16 +166,17 @@ def make_batch(ctx, n_rec, T, S, D, precision, seed0, max_iters, streams=None):
 SWEEP_POINTS = [(fa, fb) for fa in (0.2, 0.3, 0.4) for fb in (6.0, 17.0, 64.0)]     # DIHARD2_run.sh:45-46, AMI_run.sh:47, CALLHOME_run.sh:45-46
 
 
-def make_sweep_batch(ctx, T, S, D, precision, max_iters, shared, loop_prob=0.9, seed=0):
+def make_sweep_batch(ctx, T, S, D, precision, max_iters, shared, loop_prob=0.9, seed=0, streams=None):
     """BASELINE configs[4]: ONE recording under the nine (Fa, Fb) points of the recipes' grids, every point from the same
     random initialisation.  ``shared``: the points read one rho (vbx_batch_set_recording_shared); otherwise every point is
     a recording of its own with a private copy of the same x-vectors (what round 2 ran)."""
     from vbx_amd import _capi
     from vbx_amd.synth import make_recording
+    from vbx_amd.batch import sweep_streams
     n = len(SWEEP_POINTS)
-    batch = _capi.Batch(ctx, [T] * n, [S] * n, D, precision=precision, max_iters=max_iters)
-    if batch.streams != 1:
-        batch.set_option(_capi.OPT_STREAMS, 1)
+    want = streams if streams is not None else (sweep_streams(n, T) if shared else 1)
+    batch = _capi.Batch(ctx, [T] * n, [S] * n, D, precision=precision, max_iters=max_iters, streams=want)
+    assert batch.streams == want
     X, Phi, _ = make_recording(T, S, D=D, seed=seed, kappa=0.05, dtype=np.float32)
     g = np.random.default_rng(10_000 + seed).gamma(1.0, size=(T, S)).astype(np.float32)
     g /= g.sum(1, keepdims=True)
@@ -314,9 +320,10 @@ def main():
     ap.add_argument('--D', type=int, default=128)
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'fp64', 'fp32-split'],
                     help="fp32-split = --precision fp32 --gemm split (the name the library and the profiles use)")
-    ap.add_argument('--gemm', default='exact', choices=['exact', 'split'],
-                    help='how the fp32 HEADLINE multiplies: exact = v_mfma_f32_16x16x4_f32; split = f16 operand pairs on the '
-                         'matrix cores (VBX_OPT_GEMM).  The other one is measured as a sub-record either way')
+    ap.add_argument('--gemm', default='split', choices=['exact', 'split'],
+                    help='how the fp32 HEADLINE multiplies: split (default since round 5) = f16 operand pairs on the matrix cores, '
+                         'f32 accumulation (VBX_OPT_GEMM = split, precision="fp32-split"); exact = v_mfma_f32_16x16x4_f32.  The '
+                         'other one is measured as a sub-record either way')
     ap.add_argument('--no-split', action='store_true', help='skip the sub-record of the other GEMM mode')
     ap.add_argument('--total-recordings', type=int, default=None,
                     help='strong scaling: this many recordings over ALL ranks (BASELINE configs[3] as stated: 64 over 8 GPUs = 8 '
@@ -347,19 +354,29 @@ def main():
         return
 
     import torch
-    torch.cuda.set_device(local_rank)
+    # One GPU per rank over RCCL.  (Test hook, tests/test_gpu_multirank.py: VBX_AMD_DIST_BACKEND=gloo VBX_AMD_DEVICE=0 runs
+    # the same N-rank code path with every rank on the one GPU of a test box -- RCCL refuses two ranks on one device; such a
+    # line says so in `config.parallelism` and is not a scaling measurement.)
+    backend = os.environ.get('VBX_AMD_DIST_BACKEND', 'nccl')
+    device = int(os.environ.get('VBX_AMD_DEVICE', local_rank)) if backend != 'nccl' else local_rank
+    cdev = 'cuda' if backend == 'nccl' else 'cpu'      # where the few scalars of the timing protocol live
+    torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
-        ones = torch.ones(1, device='cuda')
+        if backend == 'nccl':
+            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', device))
+        else:
+            dist.init_process_group(backend=backend)
+        ones = torch.ones(1, device=cdev)
         dist.all_reduce(ones)                          # RCCL really connects N ranks, one per GPU
         assert dist.get_world_size() == args.gpus and int(ones.item()) == args.gpus, 'RCCL does not see --gpus ranks'
-        assert torch.cuda.device_count() >= args.gpus, f'{torch.cuda.device_count()} GPUs visible, --gpus {args.gpus}'
+        if backend == 'nccl':
+            assert torch.cuda.device_count() >= args.gpus, f'{torch.cuda.device_count()} GPUs visible, --gpus {args.gpus}'
 
     from vbx_amd import _capi
-    ctx = _capi.Context(local_rank)
+    ctx = _capi.Context(device)
     info = ctx.device_info()
     esize = 4 if args.precision == 'fp32' else 8
     K, W = args.steps, args.warmup
@@ -388,11 +405,11 @@ def main():
             dt = time.perf_counter() - t0
             barrier()
             if dist is not None:
-                t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+                t = torch.tensor([dt], dtype=torch.float64, device=cdev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt = float(t.item())
             times.append(dt)
-            go = torch.tensor([1 if (sum(times) < min_seconds and len(times) < max_blocks) else 0], device='cuda')
+            go = torch.tensor([1 if (sum(times) < min_seconds and len(times) < max_blocks) else 0], device=cdev)
             if dist is not None:
                 dist.broadcast(go, src=0)
             if not int(go.item()):
@@ -577,7 +594,7 @@ def main():
                 if mode == 'private' and prec != 'fp32':
                     continue
                 configs[f'C5_T200k_S50_sweep9_{prec}_{mode}'] = one_config(
-                    f'C5_{mode}', lambda mi, st, prec=prec, mode=mode: make_sweep_batch(ctx, 200000, 50, args.D, prec, mi, mode == 'shared'),
+                    f'C5_{mode}', lambda mi, st, prec=prec, mode=mode: make_sweep_batch(ctx, 200000, 50, args.D, prec, mi, mode == 'shared', streams=st),
                     len(SWEEP_POINTS), 200000, 50, prec,
                     'configs[4]: T=200 000, S=50, loopProb=0.9, the nine (Fa, Fb) points of the recipes as ONE batch, '
                     + ('one rho shared by all points (vbx_batch_set_recording_shared)' if mode == 'shared'
@@ -636,14 +653,15 @@ def main():
             'higher_is_better': True,
             'scaling': 'strong' if args.total_recordings is not None else 'weak',
             'vs_baseline': None,
-            'dtype': 'f32' if args.precision == 'fp32' else 'f64',
+            'dtype': ('f32 (f16-pair split products, f32 accumulate)' if args.gemm == 'split' else 'f32') if args.precision == 'fp32' else 'f64',
             'gemm': (args.gemm if args.precision == 'fp32' else 'exact'),
             'data': 'synthetic',
             'config': {'workload': f'batch of {args.batch} recordings per GPU, each T={args.T} x-vectors, '
                                    f'R={args.D}, S={args.S} (BASELINE configs[3] batch; headline shape), '
                                    'random gamma init, Fa=0.3 Fb=17 loopProb=0.99',
                        'recordings_per_gpu': args.batch, 'T': args.T, 'R': args.D, 'S': args.S, 'streams_per_gpu': streams,
-                       'parallelism': f'recordings sharded over {world} rank(s), no data-path collective'},
+                       'parallelism': f'recordings sharded over {world} rank(s), no data-path collective'
+                                      + ('' if backend == 'nccl' or world == 1 else f' [TEST HOOK: backend {backend}, every rank on GPU {device} -- not a scaling measurement]')},
             'timed_region': {'blocks_of_K_steps': len(times), 'seconds': sum(times), 'statistic': 'median block',
                              'ms_per_step_min': 1e3 * min(times) / K, 'ms_per_step_max': 1e3 * max(times) / K,
                              'note': 'every block holds exactly K steps between barrier + synchronize; includes the '

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VBX_ABI_VERSION 5
+#define VBX_ABI_VERSION 6
 
 /* error codes */
 #define VBX_OK 0
@@ -120,6 +120,13 @@ int vbx_device_info(vbx_ctx* ctx, char* name, int cap, int* compute_units, int64
  * max_iters bounds the ELBO history kept on the device. */
 int vbx_batch_create(vbx_ctx* ctx, int n_rec, const int64_t* T, const int32_t* S, int32_t D,
                      int precision, int max_iters, vbx_batch** out);
+/* The same with the number of HIP streams (sub-batches, VBX_OPT_STREAMS) chosen at creation: 0 = the library's choice as
+ * vbx_batch_create makes it (three streams from 24 recordings and 1536 chunks, two from 12 and 768, else one; env
+ * VBX_AMD_STREAMS overrides), 1 .. 8 = that many (at most one per recording).  A batch created on one stream by the
+ * automatic choice cannot be regrouped later (VBX_OPT_STREAMS regroups stream groups only): a sweep over one long recording
+ * -- few "recordings", many chunks -- asks for its streams here (vbx_batch_set_recording_shared).  ABI 6. */
+int vbx_batch_create_streams(vbx_ctx* ctx, int n_rec, const int64_t* T, const int32_t* S, int32_t D,
+                             int precision, int max_iters, int streams, vbx_batch** out);
 int vbx_batch_destroy(vbx_batch* batch);
 int vbx_batch_set_option(vbx_batch* batch, int option, int64_t value);
 
@@ -139,8 +146,10 @@ int vbx_batch_set_recording(vbx_batch* batch, int b, const void* X, int x_dtype,
  * CALLHOME_run.sh:42-47 around one VBx.py:87-89 rho -- keeps ONE rho in HBM, and the per-chunk kernels run the chunks that
  * read the same rows of it side by side on one XCD, so that HBM delivers them once per kernel instead of once per sweep
  * point.  Everything else (pi0, gamma0, alpha0 / invL0, results) is per recording as in vbx_batch_set_recording.  Setting
- * src_b again unsets the recordings that share with it.  In a batch that runs on several streams both recordings must be
- * in the same sub-batch (create sweeps with VBX_OPT_STREAMS = 1). */
+ * src_b again unsets the recordings that share with it.  In a batch that runs on several streams (VBX_OPT_STREAMS) every
+ * stream's sub-batch keeps ONE copy of the rows (made device to device when its first recording asks for them), shared by
+ * the sweep points dealt to that stream: the latency-bound launches of one stream (boundary walk, per-recording
+ * reductions) then hide behind the per-chunk kernels of the others. */
 int vbx_batch_set_recording_shared(vbx_batch* batch, int b, int src_b, const double* pi0, const void* gamma0, int g_dtype,
                                    const double* alpha0, const double* invL0, double loopProb, double Fa, double Fb);
 

@@ -2,7 +2,9 @@
 
 tests/golden/config_*.npz were written by tests/golden/make_golden_configs.py from the unmodified
 /root/reference/VBx/VBx.py::VBx (pi, ELBO history, alpha, invL in full; gamma on 2000 fixed rows + its column sums).
-Tolerances: fp64 path 5e-6 absolute on gamma, fp32 path 1e-4 -- the tolerance BASELINE.json's north_star states.
+Tolerances: fp64 path 5e-6 absolute on gamma, fp32 path 1e-4 -- the tolerance BASELINE.json's north_star states -- with no
+exemption: where the reference itself is further than that from the exact result of its algorithm (two points of the C5 sweep,
+REFERENCE_OFF below) the paths are held to the same bounds against an extended-precision referee instead.
 The fp64 floor is the reference's own rounding, not the kernels': its log-domain recursion works at |lfw| ~ 1e2 T, so
 after ONE iteration its gamma rows miss summing to one by 1e-7 (T = 10 000) to 1e-6 (T = 50 000) and that perturbation
 feeds the next M-step -- the first ELBO agrees to 2e-13, the second to 6e-10 (T = 10 000) / 3e-9 (T = 50 000), with the
@@ -64,34 +66,44 @@ def _write_report():
         pass
 
 
-# Fixture points at which the reference's OWN rounding is amplified beyond every bound above: (Fa, Fb) = (.3, 64) and (.4, 64)
-# of the C5 sweep, two iterations from a random start on 200 000 frames.  The fp64 kernels -- which reproduce the reference to
-# 1e-7 on every small case and to 2e-5 on this very recording run to convergence -- are 1.3e-4 / 1.5e-4 from it there, fp32
-# 1.07e-4 / 1.20e-4, fp32-split 1.13e-4 / 1.16e-4: the reference's log-domain recursion rounds at |lfw| ~ 2e7 and the EM map of
-# these points multiplies that by ~1e4
-# (DESIGN section 9).  No implementation in working precision can be held closer to such a point than the reference is to
-# itself; it stays in the fixture, reported, with a bound of its own on gamma / pi / the column sums.
-ILL_CONDITIONED = {'c5/fa0.3_fb64/it2': 2.5e-4, 'c5/fa0.4_fb64/it2': 2.5e-4}
+# Two fixture points at which the REFERENCE is the outlier: (Fa, Fb) = (.3, 64) and (.4, 64) of the C5 sweep, two iterations from a
+# random start on 200 000 frames.  Settled in round 5 by a referee (oracle/vbx_oracle_x.py: the reference's own log-domain
+# algorithm in numpy.longdouble, cross-checked against the linear-domain formulation in longdouble -- the two agree to 3e-8;
+# tests/golden/config_c5referee.npz, profiles/r05_c5_referee_reference.json): the reference's gamma is 1.32e-4 / 1.47e-4 from the
+# exact result of its own algorithm on these inputs (its log-domain recursion rounds at |lfw| ~ 2e7 and the EM map of these points
+# multiplies that by ~1e4), at the other seven points 1.2e-6 ... 2.6e-5.  Every path of this repository is therefore held to
+# north_star's 1e-4 against the REFEREE at all nine points (check_against_truth); against the reference these two points are
+# reported, not bounded -- no implementation can be closer to the reference there than the reference is to the truth.
+REFERENCE_OFF = ('c5/fa0.3_fb64/it2', 'c5/fa0.4_fb64/it2')
 
 
-def check(name, precision, d, n_iters=None, T=10000, fp32_gamma_tol=None):
+def check_against_truth(name, precision, d, n_iters):
+    """A path against the extended-precision referee: north_star's 1e-4 on gamma / pi / alpha / invL for the fp32 paths with no
+    exemption; the fp64 path at 5e-6 (its own bound everywhere else, T = 200 000 included: against the TRUTH the growth of the
+    reference's rounding with T does not enter)."""
     _REPORT[f'{name}/{precision}'] = d
-    loose = next((v for k, v in ILL_CONDITIONED.items() if name.startswith(k)), None)
-    if loose is not None:
+    tol = TOL[precision]
+    assert d['n_iters'][0] == d['n_iters'][1] == n_iters, (name, precision, d)
+    assert d['gamma'] <= tol and d['pi'] <= tol, (name, precision, d)
+    assert d['Li_rel'] <= (2e-8 if precision == 'fp64' else 1e-6), (name, precision, d)
+    assert d['alpha'] <= tol and d['invL_rel'] <= tol, (name, precision, d)
+    assert d['gamma_colsum_rel'] <= (2e-4 if precision != 'fp64' else 4 * tol), (name, precision, d)
+
+
+def check(name, precision, d, n_iters=None, T=10000):
+    _REPORT[f'{name}/{precision}'] = d
+    if any(name.startswith(k) for k in REFERENCE_OFF):        # reported only (see REFERENCE_OFF)
         assert d['n_iters'][0] == d['n_iters'][1] == n_iters, (name, precision, d)
-        assert d['gamma'] <= loose and d['pi'] <= loose and d['gamma_colsum_rel'] <= 2 * loose, (name, precision, d)
-        assert d['Li_rel'] <= 1e-6 and d['alpha'] <= 1e-4 and d['invL_rel'] <= 1e-4, (name, precision, d)
         return
     # (the reference's own rounding grows with T: at T = 200 000 its gamma is 7e-6 ... 1.8e-5 from the fp64 kernels after two
     #  iterations -- 2.6e-5 at (Fa, Fb) = (.4, 17), where fp32 is 2.5e-5 and fp32-split 2.3e-5 from it: the deviation is the
     #  reference's -- and 2.0e-5 at its own stop, where fp64, fp32 and fp32-split agree with EACH OTHER to 1e-7; the ELBO of
     #  -1.1e7 agrees to 3.7e-8 there; module docstring)
     tol = TOL[precision] * (max(1.0, T / 25000) if precision == 'fp64' else 1.0)
-    gtol = tol if (precision == 'fp64' or fp32_gamma_tol is None) else fp32_gamma_tol
     if n_iters is not None:
         assert d['n_iters'][0] == n_iters, (name, precision, d)
     assert d['n_iters'][0] == d['n_iters'][1], (name, precision, d)
-    assert d['gamma'] <= gtol, (name, precision, d)
+    assert d['gamma'] <= tol, (name, precision, d)
     assert d['pi'] <= tol, (name, precision, d)
     assert d['Li_rel'] <= (2e-8 * max(1.0, T / 50000) if precision == 'fp64' else 1e-6), (name, precision, d)
     # gamma_colsum_rel is a sum over T per-frame deviations (module docstring): reported, and bounded at 1.5 x the largest
@@ -229,11 +241,16 @@ def test_c5_sweep_on_one_shared_rho(ctx, precision):
 @pytest.mark.parametrize('precision', PRECISIONS)
 def test_c5_all_nine_sweep_points_through_VBx_sweep(precision):
     """configs[4] in full: the nine (Fa, Fb) points of the recipes' grids (DIHARD2_run.sh:45-46, AMI_run.sh:47,
-    CALLHOME_run.sh:45-46) on ONE rho through ``VBx_sweep`` -- the call a user of the sweep makes -- against the
-    unmodified reference after two iterations, point by point (tests/golden/config_c5sweep.npz, one reference process
-    per point)."""
+    CALLHOME_run.sh:45-46) on ONE rho per stream through ``VBx_sweep`` -- the call a user of the sweep makes -- after two
+    iterations, point by point, against
+      * the extended-precision referee (tests/golden/config_c5referee.npz): every point, every path, north_star's bound;
+      * the unmodified reference (tests/golden/config_c5sweep.npz, one reference process per point): the seven points where
+        the reference itself is within 3e-5 of the referee, under the bounds of every other config; the two where it is not
+        (REFERENCE_OFF) are reported."""
     from vbx_amd.batch import VBx_sweep
     cfg = load_config('c5sweep')
+    truth = load_config('c5referee')
+    truth['c5/rows'] = cfg['c5/rows']
     X, Phi, g0 = config_inputs(cfg, 'c5', g0_seed=4)
     grid = [(fa, fb) for fa in (0.2, 0.3, 0.4) for fb in (6.0, 17.0, 64.0)]
     points = [dict(Fa=fa, Fb=fb, loopProb=0.9, pi=50, gamma=g0) for fa, fb in grid]
@@ -242,14 +259,10 @@ def test_c5_all_nine_sweep_points_through_VBx_sweep(precision):
     failures = []
     for (fa, fb), (gamma, pi, Li, alpha, invL) in zip(grid, out):
         tag = f'c5/fa{fa}_fb{fb:g}/it2'
-        try:
-            # Two iterations from a random start on 200 000 frames is where the EM map amplifies a rounding error most, and
-            # the Fb = 64 points most of all: the fp64 kernels themselves are 1.8e-5 from the reference there (7e-6 elsewhere),
-            # fp32 1.07e-4 at (Fa, Fb) = (.3, 64) -- the one point of the nine above 1e-4 (exact f32 and split alike; the
-            # point run to the reference's own stop agrees to 2e-5 on every precision).  Bound for these nine: 1.5e-4.
-            check(tag + '/sweep9', precision, config_diffs(cfg, tag, gamma, pi, [r[0] for r in Li], alpha, invL), 2, T=200000,
-                  fp32_gamma_tol=1.5e-4)
-        except AssertionError as exc:                       # (every point is measured and reported before the test fails)
+        try:                                                # (every point is measured and reported before the test fails)
+            check_against_truth(tag + '/truth', precision, config_diffs(truth, tag, gamma, pi, [r[0] for r in Li], alpha, invL), 2)
+            check(tag + '/sweep9', precision, config_diffs(cfg, tag, gamma, pi, [r[0] for r in Li], alpha, invL), 2, T=200000)
+        except AssertionError as exc:
             failures.append(str(exc)[:400])
     assert not failures, failures
 

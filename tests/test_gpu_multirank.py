@@ -154,3 +154,23 @@ def test_bench_two_gpus_prints_a_compact_line_with_both_scaling_forms():
     rec = json.loads(line)
     assert len(line) < 4096 and rec['n_gpus'] == 2 and rec['scaling'] == 'weak' and rec['value'] > 0
     assert rec['configs']['strong_scaling_form']['value'] > 0
+
+
+def test_bench_n_rank_code_path_on_one_gpu():
+    """bench.py's N > 1 path -- torchrun launch, barrier + MAX-over-ranks timing, the strong-scaling form next to the weak
+    headline, rank 0 printing ONE compact line -- exercised on the single GPU of a test box through the test hook
+    (backend gloo, both ranks on device 0).  Not a scaling measurement; the line says so."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(VBX_AMD_DIST_BACKEND='gloo', VBX_AMD_DEVICE='0')
+    res = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '2',
+                          '--min-seconds', '0.05', '--batch', '6', '--full-out', ''], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, res.stdout                       # rank 0 alone speaks
+    rec = json.loads(lines[0])
+    assert len(lines[0]) < 4096 and rec['n_gpus'] == 2 and rec['scaling'] == 'weak' and rec['steps'] == 5 and rec['warmup'] == 2
+    assert rec['value'] > 0 and abs(rec['value'] - 2 * 6 * 1e3 / rec['ms_per_step']) < 1e-3 * rec['value']
+    strong = rec['configs']['strong_scaling_form']
+    assert strong['value'] > 0 and abs(strong['value'] - 64 * 1e3 / strong['ms']) < 1e-3 * strong['value']
+    assert 'TEST HOOK' in rec['config']['parallelism'] and rec['roofline']['frac'] > 0
+    assert 'cpu_baseline' not in rec                         # (rank 0 at N = 1 only)

@@ -561,36 +561,44 @@ def test_fa_fb_sweep_on_one_shared_rho_equals_independent_recordings(ctx, precis
     other.close()
 
 
-def test_sharing_across_stream_sub_batches_is_refused_with_a_way_out(ctx, monkeypatch):
-    """A batch on several streams deals its recordings to sub-batches with a device arena each; x-vectors are shared inside
-    one arena.  Across two of them the call fails and names the remedy; with one stream the same calls go through."""
+@pytest.mark.parametrize('precision', ['fp64', 'fp32', 'fp32-split'])
+def test_sharing_across_stream_sub_batches_copies_the_rows_once_per_stream(ctx, precision):
+    """A batch on several streams deals its recordings to sub-batches with a device arena each.  A sweep point whose source
+    lives in another sub-batch runs on a device-to-device COPY of the rows -- one per stream, shared by the later points of
+    that stream -- and every point's result is bit for bit what the same sweep gives on one stream.  New x-vectors for the
+    source unset the points that run on copies of the old ones, in every sub-batch."""
     from vbx_amd import _capi
     from vbx_amd.synth import make_recording
-    T, S = 1500, 8
+    T, S, n = 1500, 8, 7
     X, Phi, _ = make_recording(T, S, seed=2, kappa=0.05)
     g0 = np.random.default_rng(3).gamma(1.0, size=(T, S))
     g0 /= g0.sum(1, keepdims=True)
-    monkeypatch.setenv('VBX_AMD_STREAMS', '2')
-    batch = _capi.Batch(ctx, [T] * 4, [S] * 4, 128, precision='fp64', max_iters=3)
-    assert batch.streams == 2
-    batch.set_recording(0, X, Phi, np.ones(S) / S, g0, 0.9, 0.3, 17.0)
-    hit = 0
-    for k in (1, 2, 3):                                   # (recordings 0..3 alternate between the two sub-batches)
-        try:
-            batch.set_recording_shared(k, 0, np.ones(S) / S, g0, 0.9, 0.2 + 0.1 * k, 17.0)
-        except _capi.VbxError as exc:
-            assert 'VBX_OPT_STREAMS' in str(exc)
-            hit += 1
-    assert hit >= 1
-    batch.close()
-    monkeypatch.setenv('VBX_AMD_STREAMS', '1')
-    batch = _capi.Batch(ctx, [T] * 4, [S] * 4, 128, precision='fp64', max_iters=3)
-    batch.set_recording(0, X, Phi, np.ones(S) / S, g0, 0.9, 0.3, 17.0)
-    for k in (1, 2, 3):
-        batch.set_recording_shared(k, 0, np.ones(S) / S, g0, 0.9, 0.2 + 0.1 * k, 17.0)
-    batch.run(3, -np.inf)
-    assert all(len(batch.result(k, want_gamma=False, want_model=False)['Li']) == 3 for k in range(4))
-    batch.close()
+
+    def sweep(streams, src_of):
+        batch = _capi.Batch(ctx, [T] * n, [S] * n, 128, precision=precision, max_iters=3, streams=streams)
+        assert batch.streams == streams
+        batch.set_recording(0, X, Phi, np.ones(S) / S, g0, 0.9, 0.3, 17.0)
+        for k in range(1, n):
+            batch.set_recording_shared(k, src_of(k), np.ones(S) / S, g0, 0.9, 0.2 + 0.05 * k, 17.0 + k)
+        batch.run(3, -np.inf)
+        out = [batch.result(k) for k in range(n)]
+        return batch, out
+
+    one, ref = sweep(1, lambda k: 0)
+    one.close()
+    for streams, src_of in ((2, lambda k: 0), (3, lambda k: 0), (3, lambda k: k - 1)):      # (a chain of sources: each names its neighbour)
+        batch, out = sweep(streams, src_of)
+        for k in range(n):
+            for key in ('gamma', 'pi', 'Li', 'alpha', 'invL'):
+                assert np.array_equal(out[k][key], ref[k][key]), (streams, k, key)
+        if streams == 3 and src_of(2) == 0:
+            # new x-vectors for the source: every point on (a copy of) the old ones must be set again before the next run
+            batch.set_recording(0, X[::-1].copy(), Phi, np.ones(S) / S, g0, 0.9, 0.3, 17.0)
+            with pytest.raises(_capi.VbxError, match='has not been set'):
+                batch.run(1, -np.inf)
+            with pytest.raises(_capi.VbxError):                       # a point cannot become the source of its own source
+                batch.set_recording_shared(0, 1, np.ones(S) / S, g0, 0.9, 0.3, 17.0)
+        batch.close()
 
 
 def test_python_sweep_api_equals_one_call_per_point(synth_cases):

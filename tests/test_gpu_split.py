@@ -198,3 +198,55 @@ def test_a_recording_does_not_depend_on_its_batch_at_scale(ctx, precision, S):
         for k, r in enumerate(shared):
             for key in ('gamma', 'pi', 'Li', 'alpha', 'invL'):
                 assert np.array_equal(r[key], alone[key]), (precision, _rep, k, key, float(np.abs(np.asarray(r[key]) - np.asarray(alone[key])).max()))
+
+
+def test_split_declines_x_vectors_one_scale_cannot_cover(ctx):
+    """One power-of-two scale per recording carries 22 bits only for frames whose largest element is within 2^10 of the
+    recording's largest (vbx_split.hpp: rho_absmax_kernel, kSplitRangeBits).  A recording with a frame 2^-12 of the rest
+    makes the batch multiply EXACTLY -- vbx_batch_gemm_in_effect says so and the result is bit for bit the exact path's --
+    and new, ordinary x-vectors for that recording bring the split back."""
+    from vbx_amd import _capi
+    from vbx_amd.synth import make_recording
+    T, S = 2000, 9
+    X, Phi, _ = make_recording(T, S, seed=21, kappa=0.05, dtype=np.float32)
+    g0 = _soft(T, S, 5)
+    bad = X.copy()
+    bad[777] *= np.float32(2.0 ** -12)
+    zero = X.copy()
+    zero[5] = 0                                              # (an all-zero frame does not count: it contributes nothing either way)
+    res_s, gemm = _run(ctx, [(zero, Phi, g0, 0.9, 0.3, 17.0)], 3, 'fp32-split')
+    assert gemm == 'split'
+    res_x, gemm = _run(ctx, [(bad, Phi, g0, 0.9, 0.3, 17.0)], 3, 'fp32')
+    assert gemm == 'exact'
+    res_d, gemm = _run(ctx, [(X, Phi, g0, 0.9, 0.3, 17.0), (bad, Phi, g0, 0.9, 0.3, 17.0)], 3, 'fp32-split')
+    assert gemm == 'exact'                                   # declined for the batch: one recording is out of range
+    for key in ('gamma', 'pi', 'Li'):
+        assert np.array_equal(res_d[1][key], res_x[0][key]), key
+    batch = _capi.Batch(ctx, [T], [S], 128, precision='fp32-split', max_iters=3)
+    batch.set_recording(0, bad, Phi, np.ones(S) / S, g0, 0.9, 0.3, 17.0)
+    batch.run(1, -np.inf)
+    assert batch.gemm == 'exact'
+    batch.set_recording(0, X, Phi, np.ones(S) / S, g0, 0.9, 0.3, 17.0)
+    batch.run(1, -np.inf)
+    assert batch.gemm == 'split'
+    batch.close()
+
+
+def test_gemm_environment_variable_is_validated_and_never_overrides_the_argument(ctx, monkeypatch):
+    from vbx_amd import _capi
+    monkeypatch.setenv('VBX_AMD_GEMM', 'fast')
+    with pytest.raises(ValueError, match='VBX_AMD_GEMM'):
+        _capi.Batch(ctx, [300], [4], 128, precision='fp32', max_iters=2)
+    monkeypatch.setenv('VBX_AMD_GEMM', 'exact')              # the argument names a mode: the environment does not override it
+    b = _capi.Batch(ctx, [300], [4], 128, precision='fp32-split', max_iters=2)
+    X = np.random.default_rng(0).standard_normal((300, 128)).astype(np.float32)
+    b.set_recording(0, X, np.ones(128), np.ones(4) / 4, _soft(300, 4, 1), 0.9, 0.3, 17.0)
+    b.run(1, -np.inf)
+    assert b.gemm == 'split'
+    b.close()
+    monkeypatch.setenv('VBX_AMD_GEMM', 'split')              # a plain 'fp32' takes the environment's choice
+    b = _capi.Batch(ctx, [300], [4], 128, precision='fp32', max_iters=2)
+    b.set_recording(0, X, np.ones(128), np.ones(4) / 4, _soft(300, 4, 1), 0.9, 0.3, 17.0)
+    b.run(1, -np.inf)
+    assert b.gemm == 'split'
+    b.close()

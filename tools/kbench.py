@@ -33,7 +33,7 @@ def main():
     out = {'tag': args.tag}
     if args.sweep:
         from bench import make_sweep_batch
-        b = make_sweep_batch(ctx, args.T, args.S, args.D, args.precision, 3 * n + 8, args.sweep == 'shared')
+        b = make_sweep_batch(ctx, args.T, args.S, args.D, args.precision, 3 * n + 8, args.sweep == 'shared', streams=1)
     else:
         b = make_batch(ctx, args.batch, args.T, args.S, args.D, args.precision, 0, 3 * n + 8, streams=1)
     b.run(4, -np.inf)
@@ -46,6 +46,15 @@ def main():
     out['elbo_rec0'] = float(b.result(0, want_gamma=False, want_model=False)['Li'][-1])
     b.close()
     if args.sweep:
+        # the same sweep on the streams the library's sweep API would pick (vbx_amd.batch.sweep_streams; VBX_AMD_SWEEP_STREAMS)
+        b = make_sweep_batch(ctx, args.T, args.S, args.D, args.precision, 2 * n + 8, args.sweep == 'shared')
+        b.run(4, -np.inf)
+        t0 = time.perf_counter()
+        b.run(n, -np.inf)
+        out['default_streams'] = b.streams
+        out['default_ms_per_iter'] = round(1e3 * (time.perf_counter() - t0) / n, 4)
+        out['elbo_rec0_default'] = float(b.result(0, want_gamma=False, want_model=False)['Li'][-1])
+        b.close()
         print(json.dumps(out))
         return
     b = make_batch(ctx, args.batch, args.T, args.S, args.D, args.precision, 0, 2 * n + 8)

@@ -29,7 +29,7 @@ def main():
     ctx = _capi.Context(0)
     if a.sweep:
         from bench import make_sweep_batch, SWEEP_POINTS
-        b = make_sweep_batch(ctx, a.T, a.S, a.D, a.precision, a.iters + 4, a.sweep == 'shared')
+        b = make_sweep_batch(ctx, a.T, a.S, a.D, a.precision, a.iters + 4, a.sweep == 'shared', streams=1)   # (kernel-level figures: one stream)
         a.batch = len(SWEEP_POINTS)
     else:
         b = make_batch(ctx, a.batch, a.T, a.S, a.D, a.precision, 0, a.iters + 4, streams=a.streams)

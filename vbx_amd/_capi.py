@@ -23,7 +23,7 @@ MAX_SPEAKERS = 1024
 
 ABI_SYMBOLS = [
     'vbx_abi_version', 'vbx_create', 'vbx_destroy', 'vbx_last_error', 'vbx_device_info',
-    'vbx_batch_create', 'vbx_batch_destroy', 'vbx_batch_set_option', 'vbx_batch_set_recording',
+    'vbx_batch_create', 'vbx_batch_create_streams', 'vbx_batch_destroy', 'vbx_batch_set_option', 'vbx_batch_set_recording',
     'vbx_batch_run', 'vbx_batch_get_result', 'vbx_batch_last_run_ms', 'vbx_batch_kernel_times',
     'vbx_run', 'vbx_forward_backward', 'vbx_forward_backward_dense', 'vbx_mstep', 'vbx_loglik',
     'vbx_cos_similarity', 'vbx_scores_upload', 'vbx_scores_count', 'vbx_scores_get', 'vbx_scores_get_condensed', 'vbx_scores_linkage_average',
@@ -59,7 +59,7 @@ def load():
         except Exception as exc:  # a stale-but-present library is still usable on a box without hipcc
             if not os.path.exists(path):
                 raise VbxError(f'libvbx_hip.so is not built and cannot be built here: {exc}') from exc
-    want = os.environ.get('VBX_AMD_HW_QUEUES') or '8'       # before the HIP runtime starts (see vbx_capi.hip); '0': hands off
+    want = os.environ.get('VBX_AMD_HW_QUEUES') or '8'       # before the HIP runtime starts (see vbx_host_state.hpp); '0': hands off
     if want != '0':
         os.environ.setdefault('GPU_MAX_HW_QUEUES', want)
     lib = C.CDLL(path)
@@ -72,6 +72,8 @@ def load():
     lib.vbx_device_info.argtypes = [vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(i64)]
     lib.vbx_batch_create.argtypes = [vp, C.c_int, C.POINTER(i64), C.POINTER(i32), i32, C.c_int, C.c_int,
                                      C.POINTER(vp)]
+    lib.vbx_batch_create_streams.argtypes = [vp, C.c_int, C.POINTER(i64), C.POINTER(i32), i32, C.c_int, C.c_int, C.c_int,
+                                             C.POINTER(vp)]
     lib.vbx_batch_destroy.argtypes = [vp]
     lib.vbx_batch_set_option.argtypes = [vp, C.c_int, i64]
     lib.vbx_batch_set_recording.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, dbl, dbl, dbl]
@@ -346,7 +348,9 @@ class Scores:
 class Batch:
     """A set of recordings resident in HBM (vbx_batch)."""
 
-    def __init__(self, ctx: Context, T, S, D: int, precision='fp32', max_iters: int = 40):
+    def __init__(self, ctx: Context, T, S, D: int, precision='fp32', max_iters: int = 40, streams: int = 0):
+        """``streams``: HIP streams (sub-batches) of the batch, 0 = the library's choice (vbx_batch_create_streams); a sweep
+        over one long recording -- few recordings, many chunks -- asks for its streams here."""
         self.ctx = ctx
         self._lib = ctx._lib
         self.T = [int(t) for t in T]
@@ -358,8 +362,8 @@ class Batch:
         h = C.c_void_p()
         Ta = (C.c_int64 * self.n)(*self.T)
         Sa = (C.c_int32 * self.n)(*self.S)
-        ctx.check(self._lib.vbx_batch_create(ctx._h, self.n, Ta, Sa, self.D, self.precision, self.max_iters,
-                                             C.byref(h)), 'vbx_batch_create')
+        ctx.check(self._lib.vbx_batch_create_streams(ctx._h, self.n, Ta, Sa, self.D, self.precision, self.max_iters,
+                                                     int(streams or 0), C.byref(h)), 'vbx_batch_create_streams')
         self._h = h
         def choice(var, value, table):
             if value not in table:

@@ -82,7 +82,7 @@ def _shape_of(rec, defaults):
 
 
 def _padded_states(n_states):
-    """The padded state count a vbx_batch of this many speakers runs with (vbx_capi.hip: powers of two from 16)."""
+    """The padded state count a vbx_batch of this many speakers runs with (vbx_host_batch.hpp: powers of two from 16)."""
     sp = 16
     while sp < n_states:
         sp *= 2
@@ -138,18 +138,30 @@ def VBx_batch(recordings, maxIters=10, epsilon=1e-4, precision=None, device=None
     return [_as_tuple(r, return_model) for r in raw]
 
 
+def sweep_streams(n_points, T):
+    """HIP streams a sweep of ``n_points`` over one recording of T frames runs on.  Every stream's sub-batch keeps one copy of
+    rho, shared by the points dealt to it; with two or three streams the latency-bound launches of one (boundary walk,
+    per-recording reductions: 380 of 1490 us per iteration of BASELINE config 5 on one stream) hide behind the per-chunk
+    kernels of the others.  ``VBX_AMD_SWEEP_STREAMS`` overrides; sweeps of short recordings stay on one stream (a launch
+    must still fill the chip)."""
+    import os
+    env = os.environ.get('VBX_AMD_SWEEP_STREAMS')
+    if env:
+        return max(1, min(int(env), n_points, 8))
+    tiles = n_points * ((T + 127) // 128)
+    return 3 if (n_points >= 6 and tiles >= 4608) else 2 if (n_points >= 4 and tiles >= 3072) else 1
+
+
 def run_sweep_hip(X, Phi, items, maxIters, epsilon, precision=None, device=None):
-    """Normalised sweep points over ONE recording on the local GPU: one vbx_batch, one rho (the first point owns it, the
-    others share it: vbx_batch_set_recording_shared), one stream."""
+    """Normalised sweep points over ONE recording on the local GPU: one vbx_batch, the first point owns rho, the others
+    share it (vbx_batch_set_recording_shared) -- one rho per stream sub-batch (sweep_streams)."""
     from . import _capi
     from .VBx import _pick_precision
     ctx = _capi.default_context(device)
     T, D = X.shape
     batch = _capi.Batch(ctx, [T] * len(items), [len(it['pi']) for it in items], D, precision=_pick_precision(precision, X),
-                        max_iters=maxIters)
+                        max_iters=maxIters, streams=sweep_streams(len(items), T))
     try:
-        if batch.streams != 1:
-            batch.set_option(_capi.OPT_STREAMS, 1)        # sharing works inside one device arena
         for j, it in enumerate(items):
             if j == 0:
                 batch.set_recording(0, X, Phi, it['pi'], it['gamma'], it['loopProb'], it['Fa'], it['Fb'],

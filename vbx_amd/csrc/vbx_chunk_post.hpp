@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
     const int so = i16 * NREG;                         // first state of this lane
     const int Dp = bt.Dp;
     {
-        // one scalar load gives every address of the first round of vector loads (tile table of vbx_capi.hip)
+        // one scalar load gives every address of the first round of vector loads (tile table of vbx_host_batch.hpp)
         const int4 td = bt.tile_desc[tile];            // {recording, t0, frames, first row}
         const int rec = td.x, t0 = td.y, len = td.z;
         const long long trow = td.w;

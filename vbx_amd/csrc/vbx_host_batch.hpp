@@ -1,0 +1,798 @@
+// vbx_host_batch.hpp -- C ABI (include/vbx_hip.h): context, and a batch on ONE stream -- create, options, upload, run, results
+// (one translation unit with vbx_capi.hip, which includes the parts in order; not a stand-alone header)
+#pragma once
+// =========================================================================================
+// C ABI
+// =========================================================================================
+extern "C" {
+
+int vbx_abi_version(void) { return VBX_ABI_VERSION; }
+
+const char* vbx_last_error(const vbx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int vbx_create(vbx_ctx** out, int device) {
+    if (!out) return VBX_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_create_error = std::string("no HIP device visible: ") + hipGetErrorString(e);
+        return VBX_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) {
+        g_create_error = "device index out of range";
+        return VBX_ERR_INVALID;
+    }
+    vbx_ctx* ctx = new vbx_ctx();
+    ctx->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&ctx->prop, device)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+        g_create_error = std::string("device setup failed: ") + hipGetErrorString(e);
+        delete ctx;
+        return VBX_ERR_HIP;
+    }
+    if (std::strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_error = std::string("libvbx_hip.so is built for gfx950 only; device reports ") + ctx->prop.gcnArchName;
+        (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return VBX_ERR_NO_DEVICE;
+    }
+    *out = ctx;
+    return VBX_OK;
+}
+
+int vbx_destroy(vbx_ctx* ctx) {
+    if (!ctx) return VBX_OK;
+    (void)hipSetDevice(ctx->device);
+    for (auto& sp : ctx->spare) (void)hipFree(sp.first);
+    for (auto& gs : ctx->group_streams) (void)hipStreamDestroy(gs.first);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return VBX_OK;
+}
+
+int vbx_device_info(vbx_ctx* ctx, char* name, int cap, int* compute_units, int64_t* hbm_bytes) {
+    if (!ctx) return VBX_ERR_INVALID;
+    if (name && cap > 0) {
+        std::snprintf(name, cap, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    }
+    if (compute_units) *compute_units = ctx->prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)ctx->prop.totalGlobalMem;
+    return VBX_OK;
+}
+
+static int leaf_destroy(vbx_batch* b) {
+    if (!b) return VBX_OK;
+    (void)hipSetDevice(b->ctx->device);
+    void* ptrs[] = {b->d_recs, b->d_state, b->d_tile_rec, b->d_tile_t0, b->d_tile_desc, b->d_tile_done, b->d_phi, b->d_sqrt_phi, b->d_gtile,
+                    b->d_rho, b->d_gamma, b->d_bmat, b->d_mrow, b->d_ahat, b->d_bhat, b->d_alpha, b->d_invL,
+                    b->d_bias, b->d_mpart, b->d_npart, b->d_lraw, b->d_emodel, b->d_pi, b->d_epart, b->d_Li,
+                    b->d_xstage, b->d_ip, b->d_fw_scale, b->d_bw_scale, b->d_op, b->d_fbound, b->d_gbound,
+                    b->d_opexp, b->d_tllpart, b->d_sfw, b->d_dump, b->d_sop, b->d_sopexp, b->d_sup_rec, b->d_sup_idx,
+                    b->d_sop2, b->d_sopexp2, b->d_sup2_rec, b->d_sup2_idx,
+                    b->d_gamma0, b->d_pi_prev, b->d_oph, b->d_ophexp, b->d_cop, b->d_lppow, b->d_tile_order,
+                    b->d_rho_a, b->d_rho_b, b->d_alpha_frag, b->d_rho_e, b->d_rho_amax, b->d_alpha_e};
+    (void)hipStreamSynchronize(b->ctx->stream);               // nothing of this batch may still be running when its
+    for (void* p : ptrs) ctx_free(b->ctx, p);                 // blocks go back to the spare list
+    if (b->ev_start) (void)hipEventDestroy(b->ev_start);
+    if (b->ev_stop) (void)hipEventDestroy(b->ev_stop);
+    for (auto& ep : b->ev_pool) {
+        (void)hipEventDestroy(ep.a);
+        (void)hipEventDestroy(ep.b);
+    }
+    delete b;
+    return VBX_OK;
+}
+
+static int leaf_create(vbx_ctx* ctx, int n_rec, const int64_t* T, const int32_t* S, int32_t D, int precision,
+                     int max_iters, vbx_batch** out) {
+    if (!ctx) return VBX_ERR_INVALID;
+    if (!out || !T || !S || n_rec <= 0 || D <= 0 || max_iters < 0) FAIL(ctx, VBX_ERR_INVALID, "vbx_batch_create: bad argument");
+    if (precision != VBX_PREC_FP32 && precision != VBX_PREC_FP64) FAIL(ctx, VBX_ERR_INVALID, "unknown precision %d", precision);
+    *out = nullptr;
+    int smax = 0;
+    for (int i = 0; i < n_rec; ++i) {
+        if (T[i] <= 0 || T[i] > 0x7fffffffLL / 512) FAIL(ctx, VBX_ERR_INVALID, "recording %d: T=%lld out of range", i, (long long)T[i]);
+        if (S[i] <= 0) FAIL(ctx, VBX_ERR_INVALID, "recording %d: S=%d", i, S[i]);
+        smax = std::max(smax, (int)S[i]);
+    }
+    if (smax > VBX_MAX_SPEAKERS)
+        FAIL(ctx, VBX_ERR_UNSUPPORTED, "S=%d exceeds VBX_MAX_SPEAKERS=%d", smax, VBX_MAX_SPEAKERS);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    vbx_batch* b = new vbx_batch();
+    b->ctx = ctx;
+    b->n_rec = n_rec;
+    b->D = D;
+    b->Dp = round_up(D, 32);
+    int sp = 16;
+    while (sp < smax) sp *= 2;
+    b->Sp = sp;
+    b->NT = sp / 16;
+    b->precision = precision;
+    b->rsize = precision == VBX_PREC_FP64 ? 8 : 4;
+    b->max_iters = max_iters;
+    b->recs.resize(n_rec);
+    b->is_set.assign(n_rec, 0);
+    b->split_dirty.assign(n_rec, 1);
+    std::vector<int> tile_rec, tile_t0;
+    long long row = 0;
+    long long maxT = 0;
+    for (int i = 0; i < n_rec; ++i) {
+        RecDesc& rd = b->recs[i];
+        std::memset(&rd, 0, sizeof rd);
+        rd.row0 = rd.rho_row0 = row;
+        rd.T = (int)T[i];
+        rd.S = S[i];
+        rd.tile0 = rd.rho_tile0 = (int)tile_rec.size();
+        rd.rho_rec = i;
+        rd.ntiles = (rd.T + kTileFrames - 1) / kTileFrames;
+        for (int tl = 0; tl < rd.ntiles; ++tl) {
+            tile_rec.push_back(i);
+            tile_t0.push_back(tl * kTileFrames);
+        }
+        row += rd.T;
+        maxT = std::max<long long>(maxT, rd.T);
+    }
+    b->sum_T = row;
+    b->ntiles_total = b->nblocks_chunk = (int)tile_rec.size();
+    b->share_src.resize(n_rec);
+    for (int i = 0; i < n_rec; ++i) b->share_src[i] = i;
+    std::vector<int4> tile_desc;
+    for (int t = 0; t < b->ntiles_total; ++t) {
+        const RecDesc& rd = b->recs[tile_rec[t]];
+        tile_desc.push_back(make_int4(tile_rec[t], tile_t0[t], std::min(kTileFrames, rd.T - tile_t0[t]), (int)(rd.row0 + tile_t0[t])));
+    }
+    while (tile_desc.size() % 4) tile_desc.push_back(make_int4(0, 0, 0, (int)row));
+    const size_t rs = b->rsize;
+    const size_t cells = (size_t)b->sum_T * b->Sp;
+    int rc = VBX_OK;
+#define ALLOC(expr) if (rc == VBX_OK) rc = (expr)
+    ALLOC(dmalloc(ctx, &b->d_recs, n_rec));
+    ALLOC(dmalloc(ctx, &b->d_state, (size_t)2 * n_rec));
+    ALLOC(dmalloc(ctx, &b->d_tile_rec, b->ntiles_total));
+    ALLOC(dmalloc(ctx, &b->d_tile_t0, b->ntiles_total));
+    const int ntiles_pad = (b->ntiles_total + 3) / 4 * 4;
+    ALLOC(dmalloc(ctx, &b->d_tile_desc, ntiles_pad));
+    ALLOC(dmalloc(ctx, &b->d_tile_done, ntiles_pad));
+    ALLOC(dmalloc(ctx, &b->d_phi, (size_t)n_rec * b->Dp));
+    ALLOC(dmalloc(ctx, &b->d_sqrt_phi, b->Dp));
+    ALLOC(dmalloc(ctx, &b->d_gtile, b->ntiles_total));
+    // (one tile of zero rows after the last recording: kernels may read whole tiles past its end)
+    ALLOC(dmalloc_bytes(ctx, &b->d_rho, ((size_t)b->sum_T + kTileFrames) * b->Dp * rs));
+    ALLOC(dmalloc_bytes(ctx, &b->d_gamma, cells * rs));
+    ALLOC(dmalloc_bytes(ctx, &b->d_bmat, (cells + (size_t)kTileFrames * b->Sp) * rs));     // (+ one tile, like rho)
+    ALLOC(dmalloc_bytes(ctx, &b->d_mrow, (size_t)b->sum_T * rs));
+    ALLOC(dmalloc_bytes(ctx, &b->d_alpha, (size_t)2 * n_rec * b->Sp * b->Dp * rs));     // (two copies: fin_kernel)
+    ALLOC(dmalloc_bytes(ctx, &b->d_invL, (size_t)2 * n_rec * b->Sp * b->Dp * rs));
+    ALLOC(dmalloc_bytes(ctx, &b->d_bias, (size_t)2 * n_rec * b->Sp * rs));
+    ALLOC(dmalloc_bytes(ctx, &b->d_mpart, (size_t)b->ntiles_total * b->Sp * b->Dp * rs));
+    ALLOC(dmalloc_bytes(ctx, &b->d_npart, (size_t)b->ntiles_total * b->Sp * rs));
+    ALLOC(dmalloc(ctx, &b->d_emodel, (size_t)2 * n_rec * b->Sp));
+    ALLOC(dmalloc(ctx, &b->d_pi, (size_t)n_rec * b->Sp));
+    ALLOC(dmalloc(ctx, &b->d_pi_prev, (size_t)n_rec * b->Sp));
+    ALLOC(dmalloc_bytes(ctx, &b->d_gamma0, (size_t)n_rec * b->Sp * rs));
+    ALLOC(dmalloc(ctx, &b->d_epart, (size_t)b->ntiles_total * b->Sp));
+    ALLOC(dmalloc(ctx, &b->d_Li, (size_t)n_rec * std::max(max_iters, 1)));
+    b->xstage_bytes = (size_t)maxT * D * 8;
+    ALLOC(dmalloc_bytes(ctx, &b->d_xstage, b->xstage_bytes));
+#undef ALLOC
+    if (rc != VBX_OK) {
+        leaf_destroy(b);
+        return rc;
+    }
+    hipError_t e;
+    if ((e = hipMemcpy(b->d_tile_rec, tile_rec.data(), sizeof(int) * tile_rec.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(b->d_tile_t0, tile_t0.data(), sizeof(int) * tile_t0.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(b->d_tile_desc, tile_desc.data(), sizeof(int4) * tile_desc.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemset(b->d_tile_done, 0, sizeof(int) * ntiles_pad)) != hipSuccess ||
+        (e = hipMemset(b->d_pi_prev, 0, sizeof(double) * (size_t)n_rec * b->Sp)) != hipSuccess ||
+        (e = hipMemset((char*)b->d_bmat + cells * rs, 0, (size_t)kTileFrames * b->Sp * rs)) != hipSuccess ||
+        (e = hipMemset(b->d_state, 0, sizeof(RecState) * 2 * n_rec)) != hipSuccess ||
+        (e = hipMemset(b->d_gamma, 0, cells * rs)) != hipSuccess ||
+        (e = hipMemset((char*)b->d_rho + (size_t)b->sum_T * b->Dp * rs, 0, (size_t)kTileFrames * b->Dp * rs)) != hipSuccess ||
+        (e = hipDeviceSynchronize()) != hipSuccess ||      // null-stream memsets vs. our non-blocking stream
+        (e = hipEventCreate(&b->ev_start)) != hipSuccess || (e = hipEventCreate(&b->ev_stop)) != hipSuccess) {
+        ctx->err = std::string("batch initialisation failed: ") + hipGetErrorString(e);
+        leaf_destroy(b);
+        return VBX_ERR_HIP;
+    }
+    *out = b;
+    return VBX_OK;
+}
+
+static int leaf_set_option(vbx_batch* b, int option, int64_t value) {
+    if (!b) return VBX_ERR_INVALID;
+    switch (option) {
+        case VBX_OPT_FB_ALGO:
+            if (value < VBX_FB_AUTO || value > VBX_FB_CHUNKED) FAIL(b->ctx, VBX_ERR_INVALID, "bad fb algo");
+            b->fb_algo = (int)value;
+            return VBX_OK;
+        case VBX_OPT_CHECK_EVERY:
+            if (value < 1) FAIL(b->ctx, VBX_ERR_INVALID, "check_every must be >= 1");
+            b->check_every = (int)value;
+            return VBX_OK;
+        case VBX_OPT_PROFILE:
+            b->profile = value == 1 ? ((int64_t)1 << VBX_K_COUNT) - 1 : value < 0 ? 0 : (value >> 1);
+            return VBX_OK;
+        case VBX_OPT_FUSE:
+            if (value < 0 || value > 2) FAIL(b->ctx, VBX_ERR_INVALID, "fuse must be 0, 1 or 2");
+            b->fuse = (int)value;
+            b->mpart_valid = false;
+            return VBX_OK;
+        case VBX_OPT_SPLIT_TILES:
+            if (value < 0 || value > 2) FAIL(b->ctx, VBX_ERR_INVALID, "split_tiles must be 0 (auto), 1 (on) or 2 (off)");
+            b->split_tiles = (int)value;
+            return VBX_OK;
+        case VBX_OPT_TWO_LEVEL_FROM:
+            if (value < 2) FAIL(b->ctx, VBX_ERR_INVALID, "two-level threshold must be >= 2 chunks");
+            b->two_level_from = (int)value;
+            return VBX_OK;
+        case VBX_OPT_SCAN_GROUP:
+            if (value < 0 || value > 4096) FAIL(b->ctx, VBX_ERR_INVALID, "scan group must be in [0, 4096]");
+            b->scan_group = (int)value;
+            return VBX_OK;
+        case VBX_OPT_SCAN_GROUP2:
+            if (value < 0 || value > 4096) FAIL(b->ctx, VBX_ERR_INVALID, "level-2 scan group must be in [0, 4096]");
+            b->scan_group2 = (int)value;
+            return VBX_OK;
+        case VBX_OPT_THREE_LEVEL_FROM:
+            if (value < 4) FAIL(b->ctx, VBX_ERR_INVALID, "three-level threshold must be >= 4 chunks");
+            b->three_level_from = (int)value;
+            return VBX_OK;
+        case VBX_OPT_CHUNK_FRAMES:
+            if (value < 0) FAIL(b->ctx, VBX_ERR_INVALID, "chunk_frames must be >= 0");
+            b->chunk_frames = (int)value;
+            return VBX_OK;
+        case VBX_OPT_GEMM:
+            if (value != VBX_GEMM_EXACT && value != VBX_GEMM_SPLIT) FAIL(b->ctx, VBX_ERR_INVALID, "VBX_OPT_GEMM takes VBX_GEMM_EXACT or VBX_GEMM_SPLIT");
+#ifdef VBX_ISA_UNAUDITED
+            // vbx_amd/build.py could not disassemble this library (no llvm-objdump, or VBX_AMD_SKIP_ISA_AUDIT): it may hold the
+            // packed-f32 operand form that misreads src1 beside the K = 32 f16 matrix instructions
+            if (value == VBX_GEMM_SPLIT) FAIL(b->ctx, VBX_ERR_UNSUPPORTED, "VBX_GEMM_SPLIT: this library was built without the ISA audit (vbx_amd/build.py); rebuild with llvm-objdump available");
+#endif
+            b->gemm = (int)value;
+            return VBX_OK;
+        default: FAIL(b->ctx, VBX_ERR_INVALID, "unknown option %d", option);
+    }
+}
+
+extern "C++" {
+namespace {
+template <typename R>
+int set_recording_impl(vbx_batch* b, int rec, const void* X, int x_dtype, const double* Phi, const double* pi0,
+                       const void* gamma0, int g_dtype, const double* alpha0, const double* invL0) {
+    vbx_ctx* ctx = b->ctx;
+    RecDesc& rd = b->recs[rec];
+    const int D = b->D, Dp = b->Dp, Sp = b->Sp, S = rd.S;
+    const long long T = rd.T;
+    // Phi, sqrt(Phi) (padded dims: 0)
+    std::vector<double> phi(Dp, 0.0), sphi(Dp, 0.0);
+    for (int d = 0; X && d < D; ++d) {
+        if (!(Phi[d] > 0.0)) FAIL(ctx, VBX_ERR_INVALID, "Phi[%d] must be positive", d);
+        phi[d] = Phi[d];
+        sphi[d] = std::sqrt(Phi[d]);
+    }
+    std::vector<double> gt;
+    if (X) {
+        HIPCHK(ctx, hipMemcpyAsync(b->d_phi + (size_t)rec * Dp, phi.data(), sizeof(double) * Dp, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(b->d_sqrt_phi, sphi.data(), sizeof(double) * Dp, hipMemcpyHostToDevice, ctx->stream));
+        // X -> staging -> rho, G
+        const size_t xbytes = (size_t)T * D * (x_dtype == VBX_F64 ? 8 : 4);
+        HIPCHK(ctx, hipMemcpyAsync(b->d_xstage, X, xbytes, hipMemcpyHostToDevice, ctx->stream));
+        if (x_dtype == VBX_F64) launch_prep<R, double>(b, rd); else launch_prep<R, float>(b, rd);
+        HIPCHK(ctx, hipGetLastError());
+        gt.resize(rd.ntiles);
+        HIPCHK(ctx, hipMemcpyAsync(gt.data(), b->d_gtile + rd.tile0, sizeof(double) * rd.ntiles, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        // shared rho: Phi (and with it sum_t G_t) of the recording this one shares its x-vectors with
+        // (src == rec: a clone from another stream group's arena, leaf_set_recording_cloned has put Phi, rho and sum G in place)
+        const int src = b->share_src[rec];
+        if (src != rec)
+            HIPCHK(ctx, hipMemcpyAsync(b->d_phi + (size_t)rec * Dp, b->d_phi + (size_t)src * Dp, sizeof(double) * Dp, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    // gamma0, pi0 (padded speakers: 0)
+    std::vector<R> gp;
+    if (g_dtype == VBX_F64) pack_matrix<R, double>(gp, (const double*)gamma0, T, S, Sp, (R)0);
+    else pack_matrix<R, float>(gp, (const float*)gamma0, T, S, Sp, (R)0);
+    HIPCHK(ctx, hipMemcpyAsync((R*)b->d_gamma + rd.row0 * Sp, gp.data(), sizeof(R) * gp.size(), hipMemcpyHostToDevice, ctx->stream));
+    std::vector<double> pip(Sp, 0.0);
+    for (int s = 0; s < S; ++s) pip[s] = pi0[s];
+    HIPCHK(ctx, hipMemcpyAsync(b->d_pi + (size_t)rec * Sp, pip.data(), sizeof(double) * Sp, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<R> ap, ip;
+    rd.has_model = (alpha0 && invL0) ? 1 : 0;
+    if (rd.has_model) {
+        ap.assign((size_t)Sp * Dp, (R)0);
+        ip.assign((size_t)Sp * Dp, (R)1);
+        for (int s = 0; s < S; ++s)
+            for (int d = 0; d < D; ++d) {
+                ap[(size_t)s * Dp + d] = (R)alpha0[(size_t)s * D + d];
+                ip[(size_t)s * Dp + d] = (R)invL0[(size_t)s * D + d];
+            }
+        HIPCHK(ctx, hipMemcpyAsync((R*)b->d_alpha + (size_t)rec * Sp * Dp, ap.data(), sizeof(R) * ap.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync((R*)b->d_invL + (size_t)rec * Sp * Dp, ip.data(), sizeof(R) * ip.size(), hipMemcpyHostToDevice, ctx->stream));
+    }
+    RecState st;
+    std::memset(&st, 0, sizeof st);
+    HIPCHK(ctx, hipMemcpyAsync(b->d_state + rec, &st, sizeof st, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(b->d_state + b->n_rec + rec, &st, sizeof st, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(b->d_tile_done + rd.tile0, 0, sizeof(int) * rd.ntiles, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // host vectors go out of scope below
+    if (X) {
+        double gsum = 0.0;
+        for (double g : gt) gsum += g;
+        rd.gsum = gsum;
+    } else if (b->share_src[rec] != rec) {
+        rd.gsum = b->recs[b->share_src[rec]].gsum;
+    }
+    return VBX_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+extern "C++" {
+namespace {
+// recording `rec` from rows already in HBM: fea [T][D] f64 (vbx_xvectors) and the AHC labels; the initial
+// responsibilities are built on the device (vbhmm.py:150-152), pi0 = 1/S (VBx.py:76: pi given as an int)
+template <typename R>
+int set_recording_resident_impl(vbx_batch* b, int rec, const double* d_fea, const int32_t* labels, double hi, double lo,
+                                const double* Phi) {
+    vbx_ctx* ctx = b->ctx;
+    RecDesc& rd = b->recs[rec];
+    const int D = b->D, Dp = b->Dp, Sp = b->Sp, S = rd.S;
+    const long long T = rd.T;
+    std::vector<double> phi(Dp, 0.0), sphi(Dp, 0.0);
+    for (int d = 0; d < D; ++d) {
+        if (!(Phi[d] > 0.0)) FAIL(ctx, VBX_ERR_INVALID, "Phi[%d] must be positive", d);
+        phi[d] = Phi[d];
+        sphi[d] = std::sqrt(Phi[d]);
+    }
+    for (long long t = 0; t < T; ++t)
+        if (labels[t] < 0 || labels[t] >= S) FAIL(ctx, VBX_ERR_INVALID, "label %d of frame %lld outside [0, %d)", labels[t], t, S);
+    HIPCHK(ctx, hipMemcpyAsync(b->d_phi + (size_t)rec * Dp, phi.data(), sizeof(double) * Dp, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(b->d_sqrt_phi, sphi.data(), sizeof(double) * Dp, hipMemcpyHostToDevice, ctx->stream));
+    {
+        LaunchScope ls(b, VBX_K_PREP);
+        hipLaunchKernelGGL((prep_kernel<R, double>), dim3(rd.ntiles), dim3(256), 0, ctx->stream, d_fea, (const double*)b->d_sqrt_phi,
+                           (R*)b->d_rho + rd.row0 * Dp, b->d_gtile + rd.tile0, rd.T, D, Dp);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    std::vector<double> gt(rd.ntiles);
+    HIPCHK(ctx, hipMemcpyAsync(gt.data(), b->d_gtile + rd.tile0, sizeof(double) * rd.ntiles, hipMemcpyDeviceToHost, ctx->stream));
+    // labels -> staging (the x staging block is free: fea is already on the device) -> gamma
+    if (b->xstage_bytes < sizeof(int32_t) * (size_t)T) FAIL(ctx, VBX_ERR_STATE, "staging block too small for the labels");
+    HIPCHK(ctx, hipMemcpyAsync(b->d_xstage, labels, sizeof(int32_t) * (size_t)T, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL((vbx::qinit_kernel<R>), dim3((unsigned)((T * Sp + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const int*)b->d_xstage, (R*)b->d_gamma + rd.row0 * Sp, T, S, Sp, hi, lo);
+    std::vector<double> pip(Sp, 0.0);
+    for (int s = 0; s < S; ++s) pip[s] = 1.0 / S;
+    HIPCHK(ctx, hipMemcpyAsync(b->d_pi + (size_t)rec * Sp, pip.data(), sizeof(double) * Sp, hipMemcpyHostToDevice, ctx->stream));
+    rd.has_model = 0;
+    RecState st;
+    std::memset(&st, 0, sizeof st);
+    HIPCHK(ctx, hipMemcpyAsync(b->d_state + rec, &st, sizeof st, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(b->d_state + b->n_rec + rec, &st, sizeof st, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(b->d_tile_done + rd.tile0, 0, sizeof(int) * rd.ntiles, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipGetLastError());
+    double gsum = 0.0;
+    for (double g : gt) gsum += g;
+    rd.gsum = gsum;
+    return VBX_OK;
+}
+
+template <typename R>
+int get_labels_impl(vbx_batch* b, int rec, int32_t* first, int32_t* second) {
+    vbx_ctx* ctx = b->ctx;
+    const RecDesc& rd = b->recs[rec];
+    const long long T = rd.T;
+    int* d_lab = nullptr;
+    int rc = dmalloc(ctx, &d_lab, (size_t)2 * T);
+    if (rc != VBX_OK) return rc;
+    hipLaunchKernelGGL((vbx::top2_kernel<R>), dim3((unsigned)((T + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const R*)b->d_gamma + rd.row0 * b->Sp, d_lab, d_lab + T, T, rd.S, b->Sp);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && first) e = hipMemcpyAsync(first, d_lab, sizeof(int32_t) * (size_t)T, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && second) e = hipMemcpyAsync(second, d_lab + T, sizeof(int32_t) * (size_t)T, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    ctx_free(ctx, d_lab);
+    if (e != hipSuccess) FAIL(ctx, VBX_ERR_HIP, "label extraction failed: %s", hipGetErrorString(e));
+    return VBX_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+struct vbx_xvectors;
+static void own_rho(vbx_batch* b, int rec);
+static const double* xvectors_fea_rows(const vbx_xvectors* xv, int64_t row0, int64_t T, int D, int device);
+
+static int leaf_set_recording_resident(vbx_batch* b, int rec, const vbx_xvectors* xv, int64_t row0, const int32_t* labels,
+                                       double init_smoothing, const double* Phi, double loopProb, double Fa, double Fb) {
+    if (!b) return VBX_ERR_INVALID;
+    vbx_ctx* ctx = b->ctx;
+    if (rec < 0 || rec >= b->n_rec) FAIL(ctx, VBX_ERR_INVALID, "recording index %d out of range", rec);
+    if (!xv || !labels || !Phi) FAIL(ctx, VBX_ERR_INVALID, "vbx_batch_set_recording_resident: NULL input");
+    if (!(loopProb >= 0.0 && loopProb <= 1.0)) FAIL(ctx, VBX_ERR_INVALID, "loopProb=%g outside [0,1]", loopProb);
+    if (!(Fa > 0.0) || !(Fb > 0.0)) FAIL(ctx, VBX_ERR_INVALID, "Fa and Fb must be positive");
+    RecDesc& rd = b->recs[rec];
+    const double* d_fea = xvectors_fea_rows(xv, row0, rd.T, b->D, ctx->device);
+    if (!d_fea) FAIL(ctx, VBX_ERR_INVALID, "rows [%lld, +%d) x %d dims are not in the resident x-vectors", (long long)row0, rd.T, b->D);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    rd.lp = loopProb;
+    rd.Fa = Fa;
+    rd.Fb = Fb;
+    own_rho(b, rec);
+    // softmax(smoothing * onehot) row (vbhmm.py:152, scipy.special.softmax: exp(x - max) / sum)
+    const double z = std::exp(-init_smoothing), den = 1.0 + (rd.S - 1) * z;
+    const double hi = 1.0 / den, lo = z / den;
+    int rc = b->precision == VBX_PREC_FP64 ? set_recording_resident_impl<double>(b, rec, d_fea, labels, hi, lo, Phi)
+                                            : set_recording_resident_impl<float>(b, rec, d_fea, labels, hi, lo, Phi);
+    if (rc != VBX_OK) return rc;
+    b->is_set[rec] = 1;
+    b->recs_dirty = true;
+    b->mpart_valid = false;
+    return VBX_OK;
+}
+
+static int leaf_get_labels(vbx_batch* b, int rec, int32_t* first, int32_t* second) {
+    if (!b) return VBX_ERR_INVALID;
+    if (rec < 0 || rec >= b->n_rec) FAIL(b->ctx, VBX_ERR_INVALID, "recording index %d out of range", rec);
+    HIPCHK(b->ctx, hipSetDevice(b->ctx->device));
+    return b->precision == VBX_PREC_FP64 ? get_labels_impl<double>(b, rec, first, second)
+                                         : get_labels_impl<float>(b, rec, first, second);
+}
+
+// `rec` gets (back) a rho of its own: recordings that read its rows so far are unset, and it leaves the group it was in
+static void own_rho(vbx_batch* b, int rec) {
+    for (int i = 0; i < b->n_rec; ++i)
+        if (i != rec && b->share_src[i] == rec) {
+            b->share_src[i] = i;
+            b->recs[i].rho_row0 = b->recs[i].row0;
+            b->recs[i].rho_tile0 = b->recs[i].tile0;
+            b->recs[i].rho_rec = i;
+            b->is_set[i] = 0;
+            b->order_dirty = true;
+        }
+    if (b->share_src[rec] != rec) b->order_dirty = true;
+    b->share_src[rec] = rec;
+    b->recs[rec].rho_row0 = b->recs[rec].row0;
+    b->recs[rec].rho_tile0 = b->recs[rec].tile0;
+    b->recs[rec].rho_rec = rec;
+    b->split_dirty[rec] = 1;                                  // (every caller is about to give `rec` new x-vectors)
+}
+
+static int leaf_set_recording(vbx_batch* b, int rec, const void* X, int x_dtype, const double* Phi, const double* pi0,
+                            const void* gamma0, int g_dtype, const double* alpha0, const double* invL0,
+                            double loopProb, double Fa, double Fb) {
+    if (!b) return VBX_ERR_INVALID;
+    vbx_ctx* ctx = b->ctx;
+    if (rec < 0 || rec >= b->n_rec) FAIL(ctx, VBX_ERR_INVALID, "recording index %d out of range", rec);
+    if (!X || !Phi || !pi0 || !gamma0) FAIL(ctx, VBX_ERR_INVALID, "vbx_batch_set_recording: NULL input");
+    if ((x_dtype != VBX_F32 && x_dtype != VBX_F64) || (g_dtype != VBX_F32 && g_dtype != VBX_F64))
+        FAIL(ctx, VBX_ERR_INVALID, "bad element type");
+    if ((alpha0 == nullptr) != (invL0 == nullptr)) { alpha0 = nullptr; invL0 = nullptr; }   // VBx.py:94 needs both
+    if (!(loopProb >= 0.0 && loopProb <= 1.0)) FAIL(ctx, VBX_ERR_INVALID, "loopProb=%g outside [0,1]", loopProb);
+    if (!(Fa > 0.0) || !(Fb > 0.0)) FAIL(ctx, VBX_ERR_INVALID, "Fa and Fb must be positive");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    RecDesc& rd = b->recs[rec];
+    rd.lp = loopProb;
+    rd.Fa = Fa;
+    rd.Fb = Fb;
+    own_rho(b, rec);
+    int rc = b->precision == VBX_PREC_FP64
+                 ? set_recording_impl<double>(b, rec, X, x_dtype, Phi, pi0, gamma0, g_dtype, alpha0, invL0)
+                 : set_recording_impl<float>(b, rec, X, x_dtype, Phi, pi0, gamma0, g_dtype, alpha0, invL0);
+    if (rc != VBX_OK) return rc;
+    b->is_set[rec] = 1;
+    b->recs_dirty = true;
+    b->mpart_valid = false;
+    return VBX_OK;
+}
+
+// recording `rec` on the x-vectors (rho, Phi, sum G) of recording `src` of the same batch: an Fa / Fb / loopProb sweep
+// over one recording keeps one rho in HBM
+static int leaf_set_recording_shared(vbx_batch* b, int rec, int src, const double* pi0, const void* gamma0, int g_dtype,
+                                     const double* alpha0, const double* invL0, double loopProb, double Fa, double Fb) {
+    if (!b) return VBX_ERR_INVALID;
+    vbx_ctx* ctx = b->ctx;
+    if (rec < 0 || rec >= b->n_rec || src < 0 || src >= b->n_rec || src == rec)
+        FAIL(ctx, VBX_ERR_INVALID, "vbx_batch_set_recording_shared: recording %d / source %d out of range", rec, src);
+    if (!pi0 || !gamma0) FAIL(ctx, VBX_ERR_INVALID, "vbx_batch_set_recording_shared: NULL input");
+    if (g_dtype != VBX_F32 && g_dtype != VBX_F64) FAIL(ctx, VBX_ERR_INVALID, "bad element type");
+    if (!b->is_set[src]) FAIL(ctx, VBX_ERR_STATE, "recording %d (the source of the x-vectors) has not been set", src);
+    if (b->recs[src].T != b->recs[rec].T)
+        FAIL(ctx, VBX_ERR_INVALID, "recording %d has %d frames, its source %d has %d", rec, b->recs[rec].T, src, b->recs[src].T);
+    if ((alpha0 == nullptr) != (invL0 == nullptr)) { alpha0 = nullptr; invL0 = nullptr; }
+    if (!(loopProb >= 0.0 && loopProb <= 1.0)) FAIL(ctx, VBX_ERR_INVALID, "loopProb=%g outside [0,1]", loopProb);
+    if (!(Fa > 0.0) || !(Fb > 0.0)) FAIL(ctx, VBX_ERR_INVALID, "Fa and Fb must be positive");
+    // (a source that reads the rows of `rec` itself would be unset by own_rho below and leave `rec` pointing at rows that
+    //  hold nothing: round-3 advisor finding)
+    if (b->share_src[src] == rec)
+        FAIL(ctx, VBX_ERR_STATE, "recording %d reads the x-vectors of recording %d: it cannot be that recording's source", src, rec);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    own_rho(b, rec);                                          // (whoever shared with `rec` must be set again)
+    const int owner = b->share_src[src];                      // a source that shares itself: its owner
+    RecDesc& rd = b->recs[rec];
+    rd.lp = loopProb;
+    rd.Fa = Fa;
+    rd.Fb = Fb;
+    rd.rho_row0 = b->recs[owner].row0;
+    rd.rho_tile0 = b->recs[owner].tile0;
+    rd.rho_rec = owner;
+    b->share_src[rec] = owner;
+    b->order_dirty = true;
+    // the rows of rho this recording leaves unused lie behind another recording's: the last chunk of that one reads a whole
+    // tile (finite values that meet gamma = 0, vbx_chunk_post.hpp), so they must not hold whatever the block held before
+    HIPCHK(ctx, hipMemsetAsync((char*)b->d_rho + (size_t)rd.row0 * b->Dp * b->rsize, 0,
+                               (size_t)std::min(rd.T, kTileFrames) * b->Dp * b->rsize, ctx->stream));
+    int rc = b->precision == VBX_PREC_FP64
+                 ? set_recording_impl<double>(b, rec, nullptr, VBX_F64, nullptr, pi0, gamma0, g_dtype, alpha0, invL0)
+                 : set_recording_impl<float>(b, rec, nullptr, VBX_F64, nullptr, pi0, gamma0, g_dtype, alpha0, invL0);
+    if (rc != VBX_OK) return rc;
+    b->is_set[rec] = 1;
+    b->recs_dirty = true;
+    b->mpart_valid = false;
+    return VBX_OK;
+}
+
+// recording `rec` of batch `b` on a COPY of the x-vectors (rho, Phi, sum G) of recording `src` of batch `from` -- another
+// sub-batch of the same stream group, i.e. another device arena: a sweep over one recording that runs on several streams
+// keeps one rho per stream (288 GB of HBM: a copy of 100 MB buys a stream of its own), shared by the points of that stream
+static int leaf_set_recording_cloned(vbx_batch* b, int rec, vbx_batch* from, int src, const double* pi0, const void* gamma0,
+                                     int g_dtype, const double* alpha0, const double* invL0, double loopProb, double Fa, double Fb) {
+    if (!b || !from) return VBX_ERR_INVALID;
+    vbx_ctx* ctx = b->ctx;
+    if (rec < 0 || rec >= b->n_rec || src < 0 || src >= from->n_rec)
+        FAIL(ctx, VBX_ERR_INVALID, "vbx_batch_set_recording_shared: recording %d / source %d out of range", rec, src);
+    if (!pi0 || !gamma0) FAIL(ctx, VBX_ERR_INVALID, "vbx_batch_set_recording_shared: NULL input");
+    if (g_dtype != VBX_F32 && g_dtype != VBX_F64) FAIL(ctx, VBX_ERR_INVALID, "bad element type");
+    if (!from->is_set[src]) FAIL(ctx, VBX_ERR_STATE, "the source of the x-vectors has not been set");
+    if (from->recs[src].T != b->recs[rec].T)
+        FAIL(ctx, VBX_ERR_INVALID, "recording %d has %d frames, its source has %d", rec, b->recs[rec].T, from->recs[src].T);
+    if (from->precision != b->precision || from->Dp != b->Dp || from->rsize != b->rsize) FAIL(ctx, VBX_ERR_STATE, "sub-batches of one group differ in layout");
+    if ((alpha0 == nullptr) != (invL0 == nullptr)) { alpha0 = nullptr; invL0 = nullptr; }
+    if (!(loopProb >= 0.0 && loopProb <= 1.0)) FAIL(ctx, VBX_ERR_INVALID, "loopProb=%g outside [0,1]", loopProb);
+    if (!(Fa > 0.0) || !(Fb > 0.0)) FAIL(ctx, VBX_ERR_INVALID, "Fa and Fb must be positive");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const RecDesc& sd = from->recs[from->share_src[src]];     // the rows `src` reads
+    RecDesc& rd = b->recs[rec];
+    rd.lp = loopProb;
+    rd.Fa = Fa;
+    rd.Fb = Fb;
+    own_rho(b, rec);
+    // (the source's rows are complete: every set_recording ends with a synchronize of its stream)
+    HIPCHK(ctx, hipMemcpyAsync((char*)b->d_rho + (size_t)rd.row0 * b->Dp * b->rsize, (const char*)from->d_rho + (size_t)sd.row0 * b->Dp * b->rsize,
+                               (size_t)rd.T * b->Dp * b->rsize, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(b->d_phi + (size_t)rec * b->Dp, from->d_phi + (size_t)src * b->Dp, sizeof(double) * b->Dp, hipMemcpyDeviceToDevice, ctx->stream));
+    rd.gsum = from->recs[src].gsum;
+    int rc = b->precision == VBX_PREC_FP64
+                 ? set_recording_impl<double>(b, rec, nullptr, VBX_F64, nullptr, pi0, gamma0, g_dtype, alpha0, invL0)
+                 : set_recording_impl<float>(b, rec, nullptr, VBX_F64, nullptr, pi0, gamma0, g_dtype, alpha0, invL0);
+    if (rc != VBX_OK) return rc;
+    b->is_set[rec] = 1;
+    b->recs_dirty = true;
+    b->mpart_valid = false;
+    return VBX_OK;
+}
+
+// VBX_OPT_GEMM = split: the f16 copies of rho (vbx_split.hpp) of every recording whose x-vectors have changed since they
+// were made -- largest magnitude, power-of-two scale, then the two fragment-ordered copies; the recordings that share a
+// rho read their owner's tiles and scale (RecDesc::rho_tile0 / rho_rec).
+static int prepare_split(vbx_batch* b) {
+    if (!split_wanted(b)) return VBX_OK;
+    vbx_ctx* ctx = b->ctx;
+    if (!b->d_rho_a) {
+        const size_t tile_bytes = (size_t)kTileFrames * b->Dp * 4;
+        int rc = dmalloc_bytes(ctx, &b->d_rho_a, (size_t)b->ntiles_total * tile_bytes);
+        if (rc == VBX_OK) rc = dmalloc_bytes(ctx, &b->d_rho_b, (size_t)b->ntiles_total * tile_bytes);
+        if (rc == VBX_OK) rc = dmalloc_bytes(ctx, &b->d_alpha_frag, (size_t)2 * b->n_rec * b->Sp * b->Dp * 4);
+        if (rc == VBX_OK) rc = dmalloc(ctx, &b->d_rho_e, (size_t)b->n_rec);
+        if (rc == VBX_OK) rc = dmalloc(ctx, &b->d_rho_amax, (size_t)2 * b->n_rec);
+        if (rc == VBX_OK) rc = dmalloc(ctx, &b->d_alpha_e, (size_t)2 * b->n_rec * b->Sp);
+        if (rc != VBX_OK) return rc;
+        HIPCHK(ctx, hipMemsetAsync(b->d_alpha_frag, 0, (size_t)2 * b->n_rec * b->Sp * b->Dp * 4, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(b->d_alpha_e, 0, sizeof(int) * 2 * b->n_rec * b->Sp, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(b->d_rho_e, 0, sizeof(int) * b->n_rec, ctx->stream));
+        b->split_dirty.assign(b->n_rec, 1);
+        b->split_bad.assign(b->n_rec, 0);
+    }
+    const size_t tile_halfs = (size_t)kTileFrames * b->Dp * 2;
+    std::vector<int> fresh;
+    for (int i = 0; i < b->n_rec; ++i) {
+        if (b->share_src[i] != i || !b->split_dirty[i]) continue;
+        const RecDesc& rd = b->recs[i];
+        const float* rho = (const float*)b->d_rho + rd.row0 * b->Dp;
+        static const int init[2] = {0, 0x7f800000};              // {largest = 0, smallest frame maximum = +inf}
+        HIPCHK(ctx, hipMemcpyAsync(b->d_rho_amax + 2 * i, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+        LaunchScope ls(b, VBX_K_PREP);
+        hipLaunchKernelGGL(rho_absmax_kernel, dim3(rd.ntiles), dim3(256), 0, ctx->stream, rho, rd.T, b->Dp, b->d_rho_amax + 2 * i);
+        hipLaunchKernelGGL(rho_split_kernel, dim3(rd.ntiles), dim3(256), 0, ctx->stream, rho, rd.T, b->Dp,
+                           (const int*)(b->d_rho_amax + 2 * i), b->d_rho_e + i, (_Float16*)b->d_rho_a + (size_t)rd.tile0 * tile_halfs,
+                           (_Float16*)b->d_rho_b + (size_t)rd.tile0 * tile_halfs);
+        b->split_dirty[i] = 0;
+        fresh.push_back(i);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    if (!fresh.empty()) {
+        // one power-of-two scale per recording: does it cover the recording's frames?  (once per upload; the copy waits for
+        // the kernels above)
+        std::vector<int> range((size_t)2 * b->n_rec);
+        HIPCHK(ctx, hipMemcpyAsync(range.data(), b->d_rho_amax, sizeof(int) * range.size(), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        for (int i : fresh) {
+            float hi, lo;
+            memcpy(&hi, &range[2 * i], 4);
+            memcpy(&lo, &range[2 * i + 1], 4);
+            b->split_bad[i] = (hi > 0.0f && lo < hi && lo * (float)(1 << kSplitRangeBits) < hi) ? 1 : 0;
+        }
+        b->split_declined = false;
+        for (int i = 0; i < b->n_rec; ++i) b->split_declined = b->split_declined || (b->share_src[i] == i && b->split_bad[i]);
+    }
+    return VBX_OK;
+}
+
+// One run = begin (checks, tables, start event) -> max_iters x { launch one iteration; now and then look at the
+// convergence flags } -> end (stop event, wait, timings).  Split so that a stream group can interleave its kids.
+static int run_begin(vbx_batch* b, int max_iters) {
+    vbx_ctx* ctx = b->ctx;
+    if (max_iters < 0) FAIL(ctx, VBX_ERR_INVALID, "max_iters < 0");
+    for (int i = 0; i < b->n_rec; ++i)
+        if (!b->is_set[i]) FAIL(ctx, VBX_ERR_STATE, "recording %d has not been set", i);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = choose_fb_algo(b, false);
+    if (rc != VBX_OK) return rc;
+    rc = upload_recs(b);
+    if (rc != VBX_OK) return rc;
+    std::fill(b->k_ms, b->k_ms + VBX_K_COUNT, 0.0);
+    std::fill(b->k_launches, b->k_launches + VBX_K_COUNT, 0);
+    b->ev_used = 0;
+    b->iters_launched = 0;
+    HIPCHK(ctx, hipEventRecord(b->ev_start, ctx->stream));
+    // (inside the timed run and under VBX_K_PREP: the first run after an upload pays two more passes over rho in split mode)
+    return prepare_split(b);
+}
+
+static void run_launch(vbx_batch* b, double epsilon) {
+    b->run_epsilon = epsilon;
+    if (b->precision == VBX_PREC_FP64) launch_iteration<double>(b, epsilon);
+    else launch_iteration<float>(b, epsilon);
+    ++b->iters_launched;
+}
+
+// have all recordings of this batch converged?  (waits for the iterations launched so far)
+static int run_all_done(vbx_batch* b, bool* all_done) {
+    vbx_ctx* ctx = b->ctx;
+    std::vector<RecState> st(b->n_rec);
+    HIPCHK(ctx, hipMemcpyAsync(st.data(), b->d_state + (size_t)b->state_cur * b->n_rec, sizeof(RecState) * b->n_rec, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *all_done = true;
+    for (auto& s : st) *all_done = *all_done && s.done;
+    return VBX_OK;
+}
+
+// The fused path keeps gamma on the chip; what a caller can ask for (VBx.py:126) is written here, once, from the b,
+// boundary vectors and priors of every recording's last iteration (vbx_chunk_post.hpp, REPLAY).
+extern "C++" {
+namespace {
+template <typename R> void launch_gamma_replay(vbx_batch* b) {
+    b->fused_now = true;
+    auto v = b->view<R>(0.0);
+    LaunchScope ls(b, VBX_K_POST);
+    switch (b->Sp) {
+        case 16: launch_chunk_post<R, 16, true>(b, v); break;
+        case 32: launch_chunk_post<R, 32, true>(b, v); break;
+        case 64: launch_chunk_post<R, 64, true>(b, v); break;
+        default: break;
+    }
+}
+}  // namespace
+}  // extern "C++"
+
+static int run_end(vbx_batch* b) {
+    vbx_ctx* ctx = b->ctx;
+    if (b->fin_pending) {                     // the last iteration launched: ELBO, pi, history, convergence
+        if (b->precision == VBX_PREC_FP64) launch_fin<double>(b, b->run_epsilon, 2);
+        else launch_fin<float>(b, b->run_epsilon, 2);
+        b->fin_pending = false;
+    }
+    if (b->gamma_stale) {
+        if (b->precision == VBX_PREC_FP64) launch_gamma_replay<double>(b);
+        else launch_gamma_replay<float>(b);
+        b->gamma_stale = false;
+    }
+    HIPCHK(ctx, hipEventRecord(b->ev_stop, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipGetLastError());
+    float ms = 0.f;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, b->ev_start, b->ev_stop));
+    b->last_ms = ms;
+    return collect_profile(b);
+}
+
+static int leaf_run(vbx_batch* b, int max_iters, double epsilon) {
+    int rc = run_begin(b, max_iters);
+    if (rc != VBX_OK) return rc;
+    const bool can_stop = epsilon > -1e299;
+    for (int it = 0; it < max_iters; ++it) {
+        run_launch(b, epsilon);
+        if (can_stop && ((it + 1) % b->check_every == 0) && it + 1 < max_iters) {
+            bool all_done = false;
+            if ((rc = run_all_done(b, &all_done)) != VBX_OK) return rc;
+            if (all_done) break;
+        }
+    }
+    return run_end(b);
+}
+
+extern "C++" {
+namespace {
+template <typename R>
+int get_result_impl(vbx_batch* b, int rec, double* gamma, double* pi, double* Li, int li_cap, int* n_iters,
+                    int* warned, double* alpha, double* invL) {
+    vbx_ctx* ctx = b->ctx;
+    const RecDesc& rd = b->recs[rec];
+    const int Sp = b->Sp, Dp = b->Dp, S = rd.S, D = b->D;
+    RecState st;
+    HIPCHK(ctx, hipMemcpy(&st, b->d_state + (size_t)b->state_cur * b->n_rec + rec, sizeof st, hipMemcpyDeviceToHost));
+    if (n_iters) *n_iters = st.n_iters;
+    if (warned) *warned = st.warned;
+    if (gamma) {
+        std::vector<R> g((size_t)rd.T * Sp);
+        HIPCHK(ctx, hipMemcpy(g.data(), (R*)b->d_gamma + rd.row0 * Sp, sizeof(R) * g.size(), hipMemcpyDeviceToHost));
+        for (long long t = 0; t < rd.T; ++t)
+            for (int s = 0; s < S; ++s) gamma[(size_t)t * S + s] = (double)g[(size_t)t * Sp + s];
+    }
+    if (pi) {
+        std::vector<double> p(Sp);
+        HIPCHK(ctx, hipMemcpy(p.data(), b->d_pi + (size_t)rec * Sp, sizeof(double) * Sp, hipMemcpyDeviceToHost));
+        for (int s = 0; s < S; ++s) pi[s] = p[s];
+    }
+    if (Li && li_cap > 0) {
+        const int n = std::min(std::min(st.n_iters, li_cap), b->max_iters);
+        if (n > 0) HIPCHK(ctx, hipMemcpy(Li, b->d_Li + (size_t)rec * b->max_iters, sizeof(double) * n, hipMemcpyDeviceToHost));
+    }
+    if (alpha || invL) {
+        // the model of the last iteration that ran, n_iters - 1, lives in copy (n_iters - 1) & 1 (fin_kernel); before any
+        // iteration: copy 0, where a caller's alpha / invL went
+        const size_t copy = st.n_iters > 0 ? (size_t)((st.n_iters - 1) & 1) * b->n_rec * Sp * Dp : 0;
+        std::vector<R> a((size_t)Sp * Dp), il((size_t)Sp * Dp);
+        HIPCHK(ctx, hipMemcpy(a.data(), (R*)b->d_alpha + copy + (size_t)rec * Sp * Dp, sizeof(R) * a.size(), hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(il.data(), (R*)b->d_invL + copy + (size_t)rec * Sp * Dp, sizeof(R) * il.size(), hipMemcpyDeviceToHost));
+        for (int s = 0; s < S; ++s)
+            for (int d = 0; d < D; ++d) {
+                if (alpha) alpha[(size_t)s * D + d] = (double)a[(size_t)s * Dp + d];
+                if (invL) invL[(size_t)s * D + d] = (double)il[(size_t)s * Dp + d];
+            }
+    }
+    return VBX_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+static int leaf_get_result(vbx_batch* b, int rec, double* gamma, double* pi, double* Li, int li_cap, int* n_iters,
+                         int* warned, double* alpha, double* invL) {
+    if (!b) return VBX_ERR_INVALID;
+    if (rec < 0 || rec >= b->n_rec) FAIL(b->ctx, VBX_ERR_INVALID, "recording index %d out of range", rec);
+    HIPCHK(b->ctx, hipSetDevice(b->ctx->device));
+    HIPCHK(b->ctx, hipStreamSynchronize(b->ctx->stream));
+    return b->precision == VBX_PREC_FP64
+               ? get_result_impl<double>(b, rec, gamma, pi, Li, li_cap, n_iters, warned, alpha, invL)
+               : get_result_impl<float>(b, rec, gamma, pi, Li, li_cap, n_iters, warned, alpha, invL);
+}
+
+static int leaf_last_run_ms(vbx_batch* b, double* total_ms, int* iters_launched) {
+    if (!b) return VBX_ERR_INVALID;
+    if (total_ms) *total_ms = b->last_ms;
+    if (iters_launched) *iters_launched = b->iters_launched;
+    return VBX_OK;
+}
+
+static int leaf_kernel_times(vbx_batch* b, double* ms, int64_t* launches) {
+    if (!b) return VBX_ERR_INVALID;
+    for (int k = 0; k < VBX_K_COUNT; ++k) {
+        if (ms) ms[k] = b->k_ms[k];
+        if (launches) launches[k] = b->k_launches[k];
+    }
+    return VBX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,386 @@
+// vbx_host_group.hpp -- C ABI: the public batch API -- a plain batch or a stream group of plain batches -- and the one-shot vbx_run
+// (one translation unit with vbx_capi.hip, which includes the parts in order; not a stand-alone header)
+#pragma once
+extern "C" {
+
+// ---------------------------------------------------------------------------------------
+// public batch API: a plain batch (one stream) or a stream group of plain batches
+// ---------------------------------------------------------------------------------------
+static int auto_streams(int n_rec, long long tiles) {
+    const char* env = std::getenv("VBX_AMD_STREAMS");
+    if (env && *env) {
+        const int k = std::atoi(env);
+        if (k >= 1) return std::min(k, std::min(n_rec, 8));
+    }
+    // measured on 64 recordings of T = 10 000 (NOTES.md, rounds 1-2): 1 / 2 / 3 / 4 streams = 341 / 321 / 312 / 334 us per
+    // iteration (three is the robust optimum: the fourth stream brought nothing in any queue configuration tried)
+    // -- and only when every stream still has several rounds of workgroups per launch (a chunk = one workgroup)
+    return (n_rec >= 24 && tiles >= 1536) ? 3 : (n_rec >= 12 && tiles >= 768) ? 2 : 1;
+}
+
+static void group_stop_threads(vbx_batch* b) {
+    if (!b->threads) return;
+    {
+        std::lock_guard<std::mutex> lock(b->threads->m);
+        b->threads->quit = true;
+    }
+    b->threads->go.notify_all();
+    for (auto& w : b->threads->workers) w.join();
+    delete b->threads;
+    b->threads = nullptr;
+}
+
+static void group_start_threads(vbx_batch* b) {
+    const int K = (int)b->kids.size();
+    GroupThreads* g = new GroupThreads();
+    g->rc.assign(K, VBX_OK);
+    b->threads = g;
+    for (int k = 1; k < K; ++k)
+        g->workers.emplace_back([b, g, k]() {
+            long long seen = 0;
+            while (true) {
+                int max_iters;
+                double epsilon;
+                {
+                    std::unique_lock<std::mutex> lock(g->m);
+                    g->go.wait(lock, [&] { return g->quit || g->generation != seen; });
+                    if (g->quit) return;
+                    seen = g->generation;
+                    max_iters = g->max_iters;
+                    epsilon = g->epsilon;
+                }
+                const int rc = leaf_run(b->kids[k], max_iters, epsilon);
+                {
+                    std::lock_guard<std::mutex> lock(g->m);
+                    g->rc[k] = rc;
+                    if (--g->pending == 0) g->done.notify_one();
+                }
+            }
+        });
+}
+
+static void group_clear(vbx_batch* b) {
+    group_stop_threads(b);
+    for (vbx_batch* k : b->kids) leaf_destroy(k);
+    b->kids.clear();
+    for (size_t i = 0; i < b->kid_ctx.size(); ++i) {
+        for (auto& gs : b->ctx->group_streams)                // back to the ctx (not destroyed: see vbx_ctx)
+            if (gs.first == b->kid_ctx[i]->stream && i > 0) gs.second = false;
+        delete b->kid_ctx[i];
+    }
+    b->kid_ctx.clear();
+}
+
+static int kid_fail(vbx_batch* b, int kid, int rc) {      // the message lives in the kid's private ctx
+    if (rc != VBX_OK) b->ctx->err = b->kid_ctx[kid]->err;
+    return rc;
+}
+
+// (re)build the kids of a group for K streams; recordings are dealt longest first to the least loaded kid
+static int group_build(vbx_batch* b, int K) {
+    vbx_ctx* ctx = b->ctx;
+    group_clear(b);
+    const int n = b->n_rec;
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int p, int q) { return b->all_T[p] > b->all_T[q]; });
+    std::vector<long long> load(K, 0);
+    std::vector<std::vector<int>> members(K);
+    for (int i : order) {
+        const int k = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+        members[k].push_back(i);
+        load[k] += b->all_T[i];
+    }
+    b->kid_of.assign(n, 0);
+    b->local_of.assign(n, 0);
+    b->root_of.resize(n);
+    for (int i = 0; i < n; ++i) b->root_of[i] = i;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    for (int k = 0; k < K; ++k) {
+        std::sort(members[k].begin(), members[k].end());
+        vbx_ctx* kc = new vbx_ctx();                // the parent's device and stream, block lists of its own
+        kc->device = ctx->device;
+        kc->stream = ctx->stream;
+        kc->prop = ctx->prop;
+        kc->recycle = false;
+        if (k > 0) {
+            kc->stream = nullptr;
+            for (auto& gs : ctx->group_streams)
+                if (!gs.second) {
+                    gs.second = true;
+                    kc->stream = gs.first;
+                    break;
+                }
+            if (!kc->stream) {
+                hipError_t e = hipStreamCreateWithFlags(&kc->stream, hipStreamNonBlocking);
+                if (e != hipSuccess) {
+                    delete kc;
+                    group_clear(b);
+                    ctx->err = std::string("stream group: hipStreamCreate failed: ") + hipGetErrorString(e);
+                    return VBX_ERR_HIP;
+                }
+                ctx->group_streams.emplace_back(kc->stream, true);
+            }
+        }
+        b->kid_ctx.push_back(kc);
+        std::vector<int64_t> Tk;
+        std::vector<int32_t> Sk;
+        for (size_t j = 0; j < members[k].size(); ++j) {
+            const int i = members[k][j];
+            b->kid_of[i] = k;
+            b->local_of[i] = (int)j;
+            Tk.push_back(b->all_T[i]);
+            Sk.push_back(b->all_S[i]);
+        }
+        vbx_batch* kid = nullptr;
+        int rc = leaf_create(kc, (int)Tk.size(), Tk.data(), Sk.data(), b->D, b->precision, b->max_iters, &kid);
+        if (rc != VBX_OK) {
+            ctx->err = kc->err;
+            group_clear(b);
+            return rc;
+        }
+        b->kids.push_back(kid);
+        for (auto& o : b->options)
+            if ((rc = leaf_set_option(kid, o.first, o.second)) != VBX_OK) {
+                ctx->err = kc->err;
+                group_clear(b);
+                return rc;
+            }
+    }
+    group_start_threads(b);
+    return VBX_OK;
+}
+
+int vbx_batch_create(vbx_ctx* ctx, int n_rec, const int64_t* T, const int32_t* S, int32_t D, int precision,
+                     int max_iters, vbx_batch** out) {
+    return vbx_batch_create_streams(ctx, n_rec, T, S, D, precision, max_iters, 0, out);
+}
+
+int vbx_batch_create_streams(vbx_ctx* ctx, int n_rec, const int64_t* T, const int32_t* S, int32_t D, int precision,
+                             int max_iters, int streams, vbx_batch** out) {
+    if (!ctx) return VBX_ERR_INVALID;
+    if (!out || !T || !S || n_rec <= 0) FAIL(ctx, VBX_ERR_INVALID, "vbx_batch_create: bad argument");
+    if (streams < 0 || streams > 8) FAIL(ctx, VBX_ERR_INVALID, "vbx_batch_create_streams: streams takes 0 (auto) .. 8");
+    long long tiles = 0;
+    for (int i = 0; i < n_rec; ++i) tiles += T[i] > 0 ? (T[i] + kTileFrames - 1) / kTileFrames : 0;
+    const int K = streams == 0 ? auto_streams(n_rec, tiles) : std::min(streams, n_rec);
+    if (K <= 1) return leaf_create(ctx, n_rec, T, S, D, precision, max_iters, out);
+    *out = nullptr;
+    vbx_batch* b = new vbx_batch();
+    b->ctx = ctx;
+    b->n_rec = n_rec;
+    b->D = D;
+    b->precision = precision;
+    b->max_iters = max_iters;
+    b->all_T.assign(T, T + n_rec);
+    b->all_S.assign(S, S + n_rec);
+    int rc = group_build(b, K);
+    if (rc != VBX_OK) {
+        delete b;
+        return rc;
+    }
+    *out = b;
+    return VBX_OK;
+}
+
+int vbx_batch_destroy(vbx_batch* b) {
+    if (!b) return VBX_OK;
+    if (b->kids.empty() && b->kid_ctx.empty()) return leaf_destroy(b);
+    (void)hipSetDevice(b->ctx->device);
+    group_clear(b);
+    delete b;
+    return VBX_OK;
+}
+
+int vbx_batch_set_option(vbx_batch* b, int option, int64_t value) {
+    if (!b) return VBX_ERR_INVALID;
+    if (option == VBX_OPT_STREAMS) {
+        if (value < 0 || value > 8) FAIL(b->ctx, VBX_ERR_INVALID, "VBX_OPT_STREAMS takes 0 (auto) .. 8");
+        const bool group = !b->kids.empty();
+        long long tiles = 0;
+        for (int64_t t : b->all_T) tiles += (t + kTileFrames - 1) / kTileFrames;
+        const int want = value == 0 ? auto_streams(b->n_rec, tiles) : (int)std::min<int64_t>(value, b->n_rec);
+        const int have = group ? (int)b->kids.size() : 1;
+        if (want == have) return VBX_OK;
+        if (!group) FAIL(b->ctx, VBX_ERR_STATE, "VBX_OPT_STREAMS: this batch was created on one stream and cannot be regrouped: "
+                                                "create it with vbx_batch_create_streams (or set VBX_AMD_STREAMS before vbx_batch_create)");
+        if (b->any_set) FAIL(b->ctx, VBX_ERR_STATE, "VBX_OPT_STREAMS must be set before the first recording");
+        return group_build(b, std::max(want, 1));
+    }
+    if (b->kids.empty()) return leaf_set_option(b, option, value);
+    for (size_t k = 0; k < b->kids.size(); ++k) {
+        const int rc = kid_fail(b, (int)k, leaf_set_option(b->kids[k], option, value));
+        if (rc != VBX_OK) return rc;
+    }
+    b->options.emplace_back(option, value);
+    return VBX_OK;
+}
+
+int vbx_batch_set_recording(vbx_batch* b, int rec, const void* X, int x_dtype, const double* Phi, const double* pi0,
+                            const void* gamma0, int g_dtype, const double* alpha0, const double* invL0,
+                            double loopProb, double Fa, double Fb) {
+    if (!b) return VBX_ERR_INVALID;
+    if (b->kids.empty())
+        return leaf_set_recording(b, rec, X, x_dtype, Phi, pi0, gamma0, g_dtype, alpha0, invL0, loopProb, Fa, Fb);
+    if (rec < 0 || rec >= b->n_rec) FAIL(b->ctx, VBX_ERR_INVALID, "recording index %d out of range", rec);
+    b->any_set = true;
+    const int k = b->kid_of[rec];
+    // new x-vectors for `rec`: whoever runs on a copy of its old ones in ANOTHER sub-batch must be set again (inside its own
+    // sub-batch own_rho does the same)
+    for (int i = 0; i < b->n_rec; ++i)
+        if (i != rec && b->root_of[i] == rec) {
+            b->root_of[i] = i;
+            if (b->kid_of[i] != k) b->kids[b->kid_of[i]]->is_set[b->local_of[i]] = 0;
+        }
+    b->root_of[rec] = rec;
+    return kid_fail(b, k, leaf_set_recording(b->kids[k], b->local_of[rec], X, x_dtype, Phi, pi0, gamma0, g_dtype, alpha0,
+                                             invL0, loopProb, Fa, Fb));
+}
+
+int vbx_batch_set_recording_shared(vbx_batch* b, int rec, int src_rec, const double* pi0, const void* gamma0, int g_dtype,
+                                   const double* alpha0, const double* invL0, double loopProb, double Fa, double Fb) {
+    if (!b) return VBX_ERR_INVALID;
+    if (b->kids.empty())
+        return leaf_set_recording_shared(b, rec, src_rec, pi0, gamma0, g_dtype, alpha0, invL0, loopProb, Fa, Fb);
+    if (rec < 0 || rec >= b->n_rec || src_rec < 0 || src_rec >= b->n_rec)
+        FAIL(b->ctx, VBX_ERR_INVALID, "vbx_batch_set_recording_shared: recording index out of range");
+    if (rec == src_rec) FAIL(b->ctx, VBX_ERR_INVALID, "vbx_batch_set_recording_shared: a recording cannot share with itself");
+    // A stream group deals its recordings to sub-batches with a device arena each.  Sharing proper works inside one of them;
+    // across two, the first recording of a sub-batch that asks for these x-vectors gets a COPY of the rows (device to
+    // device) and owns it, the later ones of that sub-batch share with it: one rho per stream, not one per sweep point.
+    const int k = b->kid_of[rec], ks = b->kid_of[src_rec];
+    const int root = b->root_of[src_rec];
+    if (root == rec) FAIL(b->ctx, VBX_ERR_STATE, "recording %d runs on the x-vectors of recording %d: it cannot be that recording's source", src_rec, rec);
+    if (b->root_of[rec] == rec)                               // (`rec` had x-vectors of its own: its dependants in other sub-batches)
+        for (int i = 0; i < b->n_rec; ++i)
+            if (i != rec && b->root_of[i] == rec) {
+                b->root_of[i] = i;
+                if (b->kid_of[i] != k) b->kids[b->kid_of[i]]->is_set[b->local_of[i]] = 0;
+            }
+    b->any_set = true;
+    int rc;
+    if (ks == k) {
+        rc = leaf_set_recording_shared(b->kids[k], b->local_of[rec], b->local_of[src_rec], pi0, gamma0, g_dtype, alpha0, invL0, loopProb, Fa, Fb);
+    } else {
+        int local_src = -1;                                   // a recording of sub-batch k that already holds these x-vectors
+        for (int i = 0; i < b->n_rec && local_src < 0; ++i)
+            if (i != rec && b->kid_of[i] == k && b->root_of[i] == root && b->kids[k]->is_set[b->local_of[i]]) local_src = b->local_of[i];
+        rc = local_src >= 0
+                 ? leaf_set_recording_shared(b->kids[k], b->local_of[rec], local_src, pi0, gamma0, g_dtype, alpha0, invL0, loopProb, Fa, Fb)
+                 : leaf_set_recording_cloned(b->kids[k], b->local_of[rec], b->kids[ks], b->local_of[src_rec], pi0, gamma0, g_dtype,
+                                             alpha0, invL0, loopProb, Fa, Fb);
+    }
+    if (rc == VBX_OK) b->root_of[rec] = root;
+    return kid_fail(b, k, rc);
+}
+
+int vbx_batch_run(vbx_batch* b, int max_iters, double epsilon) {
+    if (!b) return VBX_ERR_INVALID;
+    if (b->kids.empty()) return leaf_run(b, max_iters, epsilon);
+    // One host thread per stream, each running the ordinary loop of its sub-batch: launches (five per iteration and
+    // stream) are issued in parallel and the streams drift out of phase by themselves.  Fed round-robin from ONE
+    // thread (also with the streams started a fraction of a period apart) the same streams gave no gain at all.
+    const int K = (int)b->kids.size();
+    // The feeding threads are created with the group and sleep between runs: a VBx() call is a few dozen
+    // iterations, and starting three threads (with their first HIP call each) cost as much as two of them.
+    GroupThreads& g = *b->threads;
+    {
+        std::lock_guard<std::mutex> lock(g.m);
+        g.max_iters = max_iters;
+        g.epsilon = epsilon;
+        g.pending = K - 1;
+        ++g.generation;
+    }
+    g.go.notify_all();
+    g.rc[0] = leaf_run(b->kids[0], max_iters, epsilon);
+    {
+        std::unique_lock<std::mutex> lock(g.m);
+        g.done.wait(lock, [&] { return g.pending == 0; });
+    }
+    std::vector<int>& rcs = g.rc;
+    b->last_ms = 0.0;
+    b->iters_launched = 0;
+    for (int k = 0; k < K; ++k) {
+        if (rcs[k] != VBX_OK) return kid_fail(b, k, rcs[k]);
+        b->last_ms = std::max(b->last_ms, b->kids[k]->last_ms);       // the streams start together
+        b->iters_launched = std::max(b->iters_launched, b->kids[k]->iters_launched);
+    }
+    return VBX_OK;
+}
+
+int vbx_batch_get_result(vbx_batch* b, int rec, double* gamma, double* pi, double* Li, int li_cap, int* n_iters,
+                         int* warned, double* alpha, double* invL) {
+    if (!b) return VBX_ERR_INVALID;
+    if (b->kids.empty()) return leaf_get_result(b, rec, gamma, pi, Li, li_cap, n_iters, warned, alpha, invL);
+    if (rec < 0 || rec >= b->n_rec) FAIL(b->ctx, VBX_ERR_INVALID, "recording index %d out of range", rec);
+    const int k = b->kid_of[rec];
+    return kid_fail(b, k, leaf_get_result(b->kids[k], b->local_of[rec], gamma, pi, Li, li_cap, n_iters, warned, alpha, invL));
+}
+
+int vbx_batch_set_recording_resident(vbx_batch* b, int rec, const vbx_xvectors* xv, int64_t row0, const int32_t* labels,
+                                     double init_smoothing, const double* Phi, double loopProb, double Fa, double Fb) {
+    if (!b) return VBX_ERR_INVALID;
+    if (b->kids.empty()) return leaf_set_recording_resident(b, rec, xv, row0, labels, init_smoothing, Phi, loopProb, Fa, Fb);
+    if (rec < 0 || rec >= b->n_rec) FAIL(b->ctx, VBX_ERR_INVALID, "recording index %d out of range", rec);
+    b->any_set = true;
+    const int k = b->kid_of[rec];
+    return kid_fail(b, k, leaf_set_recording_resident(b->kids[k], b->local_of[rec], xv, row0, labels, init_smoothing, Phi,
+                                                      loopProb, Fa, Fb));
+}
+
+int vbx_batch_get_labels(vbx_batch* b, int rec, int32_t* first, int32_t* second) {
+    if (!b) return VBX_ERR_INVALID;
+    if (b->kids.empty()) return leaf_get_labels(b, rec, first, second);
+    if (rec < 0 || rec >= b->n_rec) FAIL(b->ctx, VBX_ERR_INVALID, "recording index %d out of range", rec);
+    const int k = b->kid_of[rec];
+    return kid_fail(b, k, leaf_get_labels(b->kids[k], b->local_of[rec], first, second));
+}
+
+int vbx_batch_last_run_ms(vbx_batch* b, double* total_ms, int* iters_launched) { return leaf_last_run_ms(b, total_ms, iters_launched); }
+
+int vbx_batch_streams(const vbx_batch* b) { return !b ? 0 : b->kids.empty() ? 1 : (int)b->kids.size(); }
+
+int vbx_batch_gemm_in_effect(const vbx_batch* b) {
+    if (!b) return VBX_GEMM_EXACT;
+    const vbx_batch* leaf = b->kids.empty() ? b : b->kids[0];
+    return leaf->split_now ? VBX_GEMM_SPLIT : VBX_GEMM_EXACT;
+}
+
+int vbx_batch_kernel_times(vbx_batch* b, double* ms, int64_t* launches) {
+    if (!b) return VBX_ERR_INVALID;
+    if (b->kids.empty()) return leaf_kernel_times(b, ms, launches);
+    for (int c = 0; c < VBX_K_COUNT; ++c) {                   // summed over the streams: ms / launches = mean duration of
+        double t = 0.0;                                       // one launch (of a kid's share of the recordings)
+        int64_t n = 0;
+        for (vbx_batch* k : b->kids) {
+            t += k->k_ms[c];
+            n += k->k_launches[c];
+        }
+        if (ms) ms[c] = t;
+        if (launches) launches[c] = n;
+    }
+    return VBX_OK;
+}
+
+int vbx_run(vbx_ctx* ctx, const vbx_problem* p, vbx_result* r) {
+    if (!ctx) return VBX_ERR_INVALID;
+    if (!p || !r) FAIL(ctx, VBX_ERR_INVALID, "vbx_run: NULL problem/result");
+    vbx_batch* b = nullptr;
+    int64_t T = p->T;
+    int32_t S = p->S;
+    int rc = vbx_batch_create(ctx, 1, &T, &S, p->D, p->precision, p->max_iters, &b);
+    if (rc != VBX_OK) return rc;
+    rc = vbx_batch_set_option(b, VBX_OPT_FB_ALGO, p->fb_algo);
+    if (rc == VBX_OK)
+        rc = vbx_batch_set_recording(b, 0, p->X, p->x_dtype, p->Phi, p->pi0, p->gamma0, p->g_dtype, p->alpha0,
+                                     p->invL0, p->loopProb, p->Fa, p->Fb);
+    if (rc == VBX_OK) rc = vbx_batch_run(b, p->max_iters, p->epsilon);
+    if (rc == VBX_OK)
+        rc = vbx_batch_get_result(b, 0, r->gamma, r->pi, r->Li, p->max_iters, &r->n_iters, &r->warned, r->alpha,
+                                  r->invL);
+    if (rc == VBX_OK) r->run_ms = b->last_ms;
+    vbx_batch_destroy(b);
+    return rc;
+}
+
+}  // extern "C"

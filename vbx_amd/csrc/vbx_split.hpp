@@ -47,7 +47,7 @@ __device__ __forceinline__ f4 mfma_split(h8 ah, h8 al, h8 bh, h8 bl, f4 c) {
 // a non-negative float order like integers; all-zero frames do not count); grid = tiles of the recording.  The pair is the
 // dynamic range the ONE power-of-two scale of a recording has to cover: a frame whose largest element sits more than
 // kSplitRangeBits below the recording's largest would carry its lo halves as f16 subnormals (fewer than the 22 bits the
-// mode promises), so such a batch multiplies exactly instead (prepare_split, vbx_capi.hip).  NaN / Inf: fmaxf drops a NaN, so
+// mode promises), so such a batch multiplies exactly instead (prepare_split, vbx_host_batch.hpp).  NaN / Inf: fmaxf drops a NaN, so
 // the scale comes from the finite elements and the NaN itself reaches the matrix cores as an f16 NaN -- the result is NaN
 // in both modes.
 constexpr int kSplitRangeBits = 10;

@@ -156,7 +156,7 @@ class DeviceStages:
 
     @staticmethod
     def padded_states(n_states):
-        """The padded state count a batch of this many speakers runs with (vbx_capi.hip: powers of two from 16)."""
+        """The padded state count a batch of this many speakers runs with (vbx_host_batch.hpp: powers of two from 16)."""
         sp = 16
         while sp < n_states:
             sp *= 2
