@@ -4,14 +4,15 @@ import json
 import sys
 
 for f in sys.argv[1:]:
-    d = json.loads(open(f).read().strip().splitlines()[-1])
+    txt = open(f).read().strip()
+    d = json.loads(txt) if txt.startswith('{\n') or '\n' not in txt else json.loads(txt.splitlines()[-1])   # (the full record: bench.py --full-out)
     r = d['roofline']
     print(f'{f}: {d["gemm"]} {d["value"]:.0f} rec-it/s  {d["ms_per_step"]:.4f} ms/step | {r["kernel"]} {r["avg_launch_us"]:.1f} us frac {r["frac"]:.3f} '
-          f'bound {r["bound"]} traffic {r["traffic"]} issue {r.get("simd_issue")}')
+          f'bound {r.get("bound_today", r["bound"])} traffic {r["traffic"]} issue {r.get("simd_issue")}')
     for key in ('f32_split', 'f32_exact', 'f64'):
         if key in d:
             o, ro = d[key], d[key]['roofline']
-            print(f'   {key:9s} {o["value"]:.0f} rec-it/s  {o["ms_per_step"]:.4f} ms/step | {ro["kernel"]} {ro["avg_launch_us"]:.1f} us frac {ro["frac"]:.3f} bound {ro["bound"]}'
+            print(f'   {key:9s} {o["value"]:.0f} rec-it/s  {o["ms_per_step"]:.4f} ms/step | {ro["kernel"]} {ro["avg_launch_us"]:.1f} us frac {ro["frac"]:.3f} bound {ro.get("bound_today", ro["bound"])}'
                   f' | kernels {o["kernels_avg_us"]}')
     if 'single_recording' in d:
         print('   single recording', round(d['single_recording']['ms_per_iteration'] * 1e3, 1), 'us per iteration')

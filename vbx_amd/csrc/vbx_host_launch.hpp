@@ -80,6 +80,8 @@ template <typename R> void launch_loglik(vbx_batch* b, double eps, bool raw) {
 // partials than the smaller block fetches in a few rounds (one recording of T = 200 000: mstep_fin 42 -> 30 us, iter_fin
 // 33 -> 23 us; at T = 50 000 mstep_fin is no faster with 1024 threads, iter_fin 9 -> 8 us).
 static int small_kernel_threads(const vbx_batch* b, int from_tiles) {
+    static const int forced = [] { const char* e = std::getenv("VBX_AMD_FIN_THREADS"); const int v = e ? atoi(e) : 0; return (v == 256 || v == 1024) ? v : 0; }();
+    if (forced && b->Sp <= 256) return forced;
     int maxtiles = 0;
     for (auto& rd : b->recs) maxtiles = std::max(maxtiles, rd.ntiles);
     return (maxtiles > from_tiles || b->Sp > 256) ? 1024 : 256;        // (iter_fin: a thread per speaker)
