@@ -77,15 +77,20 @@ def _write_report():
 REFERENCE_OFF = ('c5/fa0.3_fb64/it2', 'c5/fa0.4_fb64/it2')
 
 
+TRUTH_TOL = {'fp64': 5e-7, 'fp32': 1e-4, 'fp32-split': 1e-4}
+
+
 def check_against_truth(name, precision, d, n_iters):
-    """A path against the extended-precision referee: north_star's 1e-4 on gamma / pi / alpha / invL for the fp32 paths with no
-    exemption; the fp64 path at 5e-6 (its own bound everywhere else, T = 200 000 included: against the TRUTH the growth of the
-    reference's rounding with T does not enter)."""
+    """A path against the extended-precision referee.  The fp32 paths: north_star's 1e-4 on gamma / pi / alpha / invL, no
+    exemption (measured over the nine points, profiles/r05_c5_referee_table.md: gamma <= 4.7e-5 exact, <= 3.9e-5 split).
+    The fp64 path: 5e-7 -- ten times tighter than its bound against the reference elsewhere, because against the TRUTH the
+    reference's own rounding does not enter (measured: gamma <= 3.2e-8, pi <= 7e-10, ELBO <= 5e-12 relative: as close as the
+    referee's two formulations are to each other)."""
     _REPORT[f'{name}/{precision}'] = d
-    tol = TOL[precision]
+    tol = TRUTH_TOL[precision]
     assert d['n_iters'][0] == d['n_iters'][1] == n_iters, (name, precision, d)
     assert d['gamma'] <= tol and d['pi'] <= tol, (name, precision, d)
-    assert d['Li_rel'] <= (2e-8 if precision == 'fp64' else 1e-6), (name, precision, d)
+    assert d['Li_rel'] <= (1e-10 if precision == 'fp64' else 1e-6), (name, precision, d)
     assert d['alpha'] <= tol and d['invL_rel'] <= tol, (name, precision, d)
     assert d['gamma_colsum_rel'] <= (2e-4 if precision != 'fp64' else 4 * tol), (name, precision, d)
 
