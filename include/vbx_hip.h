@@ -175,7 +175,10 @@ int vbx_batch_kernel_times(vbx_batch* batch, double* ms, int64_t* launches);
 /* Number of HIP streams (sub-batches) this batch runs on: VBX_OPT_STREAMS in effect. */
 int vbx_batch_streams(const vbx_batch* b);
 /* VBX_GEMM_EXACT or VBX_GEMM_SPLIT: how the iterations of the last vbx_batch_run multiplied (VBX_OPT_GEMM asks, the
- * batch's precision and kernels decide: fp64 batches, S > 64 and the unfused kernels always answer VBX_GEMM_EXACT). */
+ * batch's precision and kernels decide: fp64 batches, S > 64 and the unfused kernels always answer VBX_GEMM_EXACT -- and so
+ * does a batch that holds a recording whose frames span more than 2^10 in magnitude, which one power-of-two scale per
+ * recording cannot carry at 22 bits: vbx_split.hpp.  In a batch on several streams the guard acts per sub-batch and the
+ * answer is VBX_GEMM_SPLIT only if every sub-batch multiplied that way). */
 int vbx_batch_gemm_in_effect(const vbx_batch* b);
 
 /* ---- one-shot: a single recording, host buffers in / out (= one reference VBx call) ---- */

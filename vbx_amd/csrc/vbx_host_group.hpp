@@ -342,8 +342,11 @@ int vbx_batch_streams(const vbx_batch* b) { return !b ? 0 : b->kids.empty() ? 1 
 
 int vbx_batch_gemm_in_effect(const vbx_batch* b) {
     if (!b) return VBX_GEMM_EXACT;
-    const vbx_batch* leaf = b->kids.empty() ? b : b->kids[0];
-    return leaf->split_now ? VBX_GEMM_SPLIT : VBX_GEMM_EXACT;
+    if (b->kids.empty()) return b->split_now ? VBX_GEMM_SPLIT : VBX_GEMM_EXACT;
+    // a stream group: the range guard of the split mode (prepare_split) acts per sub-batch; "split" = every one of them
+    for (const vbx_batch* k : b->kids)
+        if (!k->split_now) return VBX_GEMM_EXACT;
+    return VBX_GEMM_SPLIT;
 }
 
 int vbx_batch_kernel_times(vbx_batch* b, double* ms, int64_t* launches) {
