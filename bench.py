@@ -674,6 +674,14 @@ def main():
             'gamma_checks': {'row_sum_max_dev': float(np.abs(res0['gamma'].sum(1) - 1).max()),
                              'elbo_last': float(res0['Li'][-1])},
         }
+        # what one recording keeps resident in HBM: rho, in split mode also its two f16-pair copies
+        # (4 bytes per element each, made once per upload by rho_absmax + rho_split: two more passes over rho inside the first
+        # run, under VBX_K_PREP); b and the caller's gamma [T][Sp]; per chunk the partial sums and the three operators
+        Tp, Sp_ = -(-args.T // 128) * 128, 16 if args.S <= 16 else 32 if args.S <= 32 else 64
+        chunks = Tp // 128
+        out['hbm_resident_bytes_per_recording'] = {
+            'rho': Tp * args.D * esize, 'rho_f16_pair_copies': (2 * Tp * args.D * 4) if head_prec == 'fp32-split' else 0,
+            'b_and_gamma': 2 * Tp * Sp_ * esize, 'partials_and_operators': chunks * (Sp_ * args.D + 3 * Sp_ * Sp_ + 4 * Sp_) * esize}
         step_s = med / K
         e4 = esize / 4
         survey_bytes = args.batch * (8 * args.T * args.D + 28 * args.T * args.S) * e4
