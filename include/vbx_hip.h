@@ -39,7 +39,8 @@ extern "C" {
 #define VBX_ERR_NO_DEVICE (-4)   /* no gfx950-class GPU visible                            */
 #define VBX_ERR_STATE (-5)       /* call order violated (run before every recording is set) */
 
-#define VBX_MAX_SPEAKERS 1024
+#define VBX_MAX_SPEAKERS 16384 /* states per recording (the reference: any; up to 64 fused kernels, 256 wide scan, 1024 one-wavefront
+                                  walk, beyond a workgroup-wide walk: vbx_big.hpp) */
 
 /* element types of caller buffers */
 #define VBX_F32 0

@@ -304,8 +304,64 @@ def test_more_speakers_than_the_library_takes_is_an_error_not_a_crash():
     from vbx_amd import _capi
     X = np.random.default_rng(0).standard_normal((40, 16))
     S = _capi.MAX_SPEAKERS + 1
+    assert _capi.MAX_SPEAKERS == 16384
     with pytest.raises(_capi.VbxError, match='VBX_MAX_SPEAKERS'):
         vbx_amd.VBx(X, np.ones(16), pi=S, gamma=np.full((40, S), 1.0 / S), maxIters=1)
+
+
+@pytest.mark.parametrize('S,T', [(1025, 1300), (1100, 1400), (2500, 2600), (4097, 4200)])
+def test_more_than_1024_states(S, T):
+    """The reference takes any number of states (VBx.py:76-85).  Beyond 1024 the walk, the posteriors and the
+    iteration-finishing reductions run on a workgroup per recording with loops over blocks of states (vbx_big.hpp: padded
+    widths 2048, 4096, 8192).  Against the oracle -- its linear-domain iteration, which tests/test_oracle_golden.py and
+    tests/test_chunked_scan_model.py pin to the log-domain restatement: the reference's own S x S logsumexp per frame would
+    take minutes at this size -- after one, two and three iterations from a soft AHC-like start, fp64 and fp32, with and
+    without the reference's stopping rule; T > S as an AHC result always has."""
+    import vbx_amd
+    from vbx_amd.synth import make_recording
+    orc = _orc()
+    X, Phi, lab = make_recording(T, 8, seed=S, kappa=0.3)
+    rng = np.random.default_rng(S + 1)
+    # an AHC-like start: every state owns a run of frames (vbhmm.py:150-152: softmax of smoothed one-hot labels)
+    owner = np.minimum(np.arange(T) * S // T, S - 1)
+    g0 = np.full((T, S), 1.0)
+    g0[np.arange(T), owner] = np.exp(5.0)
+    g0 *= rng.uniform(0.9, 1.1, size=(T, S))
+    g0 /= g0.sum(1, keepdims=True)
+    lp, Fa, Fb = 0.9, 0.3, 17.0
+    G, rho = orc.frame_constants(X, Phi)
+    gam, pi = g0, np.ones(S) / S
+    want = []
+    for _ in range(3):
+        gam, pi, elbo, alpha, invL = orc.vb_iteration_linear(rho, Phi, float(G.sum()), gam, pi, lp, Fa, Fb)
+        want.append((gam, pi, elbo, alpha, invL))
+    for precision, tol in (('fp64', 1e-8), ('fp32', FP32_TOL)):
+        for n in (1, 3):
+            g, p, Li, al, il = vbx_amd.VBx(X, Phi, loopProb=lp, Fa=Fa, Fb=Fb, pi=S, gamma=g0, maxIters=n, epsilon=-1e300,
+                                           return_model=True, precision=precision)
+            wg, wp, _, wa, wi = want[n - 1]
+            assert g.shape == (T, S) and len(Li) == n
+            print(f'S={S} {precision} after {n}: gamma {np.abs(g - wg).max():.2e} pi {np.abs(p - wp).max():.2e} '
+                  f'ELBO {rel_err([r[0] for r in Li], [w[2] for w in want[:n]]):.1e}')
+            if precision == 'fp32' and n == 3 and S > 4096:
+                # three iterations from a start in which 4097 states share 4200 frames: the EM map amplifies ANY rounding
+                # difference while states are dying (DESIGN section 9; S = 4097: gamma 5.4e-4, pi 9e-4 between fp32 and the
+                # float64 oracle, fp64 against the same oracle 1e-8 -- the kernels agree, the trajectories do not).  One
+                # iteration is held to the bound proper; three are a sanity check only.
+                assert np.abs(g - wg).max() <= 5e-3 and np.abs(p - wp).max() <= 5e-3
+                continue
+            assert np.abs(g - wg).max() <= tol and np.abs(p - wp).max() <= tol, (precision, n, np.abs(g - wg).max())
+            # (fp32: sums over thousands of states in working precision while speakers are still forming -- 1.4e-6 measured at
+            #  S = 1025 after two iterations; north_star's bound is 1e-4)
+            assert rel_err([r[0] for r in Li], [w[2] for w in want[:n]]) <= (1e-10 if precision == 'fp64' else 1e-5)
+            assert np.abs(al - wa).max() <= tol * max(1.0, np.abs(wa).max()) and rel_err(il, wi) <= max(tol, 1e-9)
+            assert np.abs(g.sum(1) - 1).max() < 1e-5
+    # the stopping rule on the device (VBx.py:122-125): stop where the oracle's ELBO history says the reference would
+    hist = [w[2] for w in want]
+    eps = 0.5 * (abs(hist[1] - hist[0]) + abs(hist[2] - hist[1]))        # between the two increases: one of them stops the loop
+    n_stop = next((i + 1 for i in (1, 2) if hist[i] - hist[i - 1] < eps), 3)
+    g, p, Li = vbx_amd.VBx(X, Phi, loopProb=lp, Fa=Fa, Fb=Fb, pi=S, gamma=g0, maxIters=3, epsilon=eps, precision='fp64')
+    assert len(Li) == n_stop and np.abs(g - want[n_stop - 1][0]).max() <= 1e-8
 
 
 def test_reference_error_behaviour():

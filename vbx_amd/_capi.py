@@ -19,7 +19,7 @@ OPT_GEMM = 14                # how the fp32 path multiplies: GEMM_EXACT (f32 MFM
 GEMM_EXACT, GEMM_SPLIT = 0, 1
 K_NAMES = ['prep', 'mstep_acc', 'mstep_fin', 'loglik', 'fb', 'fb_aux', 'post', 'iter_fin', 'chunk_loglik',
            'chunk_post']
-MAX_SPEAKERS = 1024
+MAX_SPEAKERS = 16384
 
 ABI_SYMBOLS = [
     'vbx_abi_version', 'vbx_create', 'vbx_destroy', 'vbx_last_error', 'vbx_device_info',

@@ -11,6 +11,7 @@
 #include "vbx_fb_dense.hpp"
 #include "vbx_chunk_loglik.hpp"
 #include "vbx_chunk_post.hpp"
+#include "vbx_big.hpp"
 #include "vbx_linkage.hpp"
 #include "vbx_ahc.hpp"
 #include "vbx_frontend.hpp"

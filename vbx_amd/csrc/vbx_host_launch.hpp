@@ -53,7 +53,33 @@ static int small_kernel_threads(const vbx_batch* b, int from_tiles);
 
 // fin_kernel (vbx_kernels.hpp): mode 1 = start an iteration (M-step), 2 = finish one (ELBO, pi, convergence), 3 = finish
 // the previous one and start the next in the same launch.  A launch with a finishing role writes the other state copy.
+// More than 1024 states (vbx_big.hpp): switch over NR = Sp / 1024
+#define BIG_SWITCH(sp, BODY)                                   \
+    switch ((sp) >> 10) {                                      \
+        case 2: { constexpr int kNR = 2; BODY } break;         \
+        case 4: { constexpr int kNR = 4; BODY } break;         \
+        case 8: { constexpr int kNR = 8; BODY } break;         \
+        case 16: { constexpr int kNR = 16; BODY } break;       \
+        default: break;                                        \
+    }
+
 template <typename R> void launch_fin(vbx_batch* b, double eps, int mode) {
+    if (b->Sp > 1024) {
+        // the finishing role has a kernel of its own there (a thread per speaker does not reach); it runs first and the host
+        // swaps the state buffers, so the M-step role that follows finds the state of the iteration it starts
+        if (mode & 2) {
+            auto v = b->view<R>(eps);
+            LaunchScope ls(b, VBX_K_ITER_FIN);
+            BIG_SWITCH(b->Sp, hipLaunchKernelGGL((iter_fin_big_kernel<R, kNR>), dim3(b->n_rec), dim3(1024), 0, b->ctx->stream, v);)
+            b->state_cur ^= 1;
+        }
+        if (mode & 1) {
+            auto v = b->view<R>(eps);
+            LaunchScope ls(b, VBX_K_MSTEP_FIN);
+            hipLaunchKernelGGL((fin_kernel<R>), dim3(b->n_rec, b->Sp + 1), dim3(1024), 0, b->ctx->stream, v, 1);
+        }
+        return;
+    }
     auto v = b->view<R>(eps);
     LaunchScope ls(b, mode == 2 ? VBX_K_ITER_FIN : VBX_K_MSTEP_FIN);
     hipLaunchKernelGGL((fin_kernel<R>), dim3(b->n_rec, b->Sp + 1), dim3(small_kernel_threads(b, 80)), 0, b->ctx->stream, v, mode);
@@ -208,7 +234,7 @@ template <typename R> void launch_fb(vbx_batch* b, double eps, bool fused_post =
         case 4: hipLaunchKernelGGL((fb_seq_kernel<R, 4>), dim3(b->n_rec), dim3(128), 0, b->ctx->stream, v); break;
         case 8: hipLaunchKernelGGL((fb_seq_kernel<R, 8>), dim3(b->n_rec), dim3(128), 0, b->ctx->stream, v); break;
         case 16: hipLaunchKernelGGL((fb_seq_kernel<R, 16>), dim3(b->n_rec), dim3(128), 0, b->ctx->stream, v); break;
-        default: break;
+        default: BIG_SWITCH(b->Sp, hipLaunchKernelGGL((fb_big_kernel<R, kNR>), dim3(b->n_rec, 2), dim3(1024), 0, b->ctx->stream, v);) break;
     }
 }
 
@@ -224,7 +250,7 @@ template <typename R> void launch_post(vbx_batch* b, double eps) {
         case 256: hipLaunchKernelGGL((post_kernel<R, 256>), grid, block, 0, b->ctx->stream, v); break;
         case 512: hipLaunchKernelGGL((post_kernel<R, 512>), grid, block, 0, b->ctx->stream, v); break;
         case 1024: hipLaunchKernelGGL((post_kernel<R, 1024>), grid, block, 0, b->ctx->stream, v); break;
-        default: break;
+        default: hipLaunchKernelGGL((post_big_kernel<R>), grid, block, 0, b->ctx->stream, v); break;     // > 1024 states (vbx_big.hpp)
     }
 }
 

@@ -281,7 +281,7 @@ def diarize(args, stages=None, log=print):
     four methods built on its checkers).  Returns ``({recording: dict(labels1st, labels2nd, n_iters, thr)}, timing)``
     for the recordings of this rank.
 
-    A recording the device path cannot take (more than ``VBX_MAX_SPEAKERS`` = 1024 AHC clusters, or one whose batch
+    A recording the device path cannot take (more than ``VBX_MAX_SPEAKERS`` = 16 384 AHC clusters, or one whose batch
     fails) does not take the archive down with it: every other recording is diarized and written, then a
     ``RuntimeError`` names the ones left out.  RTTM files are written as soon as their labels exist."""
     from .batch import shard_recordings
