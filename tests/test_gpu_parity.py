@@ -156,6 +156,24 @@ def test_module_level_forward_backward(fb_cases):
     np.testing.assert_allclose(tll, c['tll'], rtol=1e-11)
 
 
+def test_module_level_forward_backward_with_more_than_1024_states():
+    """``forward_backward(lls, tr, ip)`` (VBx.py:146) with the transition matrix VBx() builds and 1500 states: the workgroup-wide
+    walk of vbx_big.hpp through the step-level API, posteriors, total log-likelihood and the log-domain lattices against the
+    oracle's S x S logsumexp recursion."""
+    import vbx_amd
+    rng = np.random.default_rng(5)
+    T, S, lp = 60, 1500, 0.85
+    lls = rng.normal(0.0, 3.0, size=(T, S))
+    pi = rng.dirichlet(np.ones(S))
+    tr = np.eye(S) * lp + (1 - lp) * pi
+    post, tll, lfw, lbw = vbx_amd.forward_backward(lls, tr, pi)
+    wpost, wtll, wlfw, wlbw = _orc().forward_backward(lls, tr, pi)
+    np.testing.assert_allclose(post, wpost, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(tll, wtll, rtol=1e-11)
+    np.testing.assert_allclose(lfw, wlfw, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(lbw, wlbw, rtol=0, atol=1e-8)
+
+
 @pytest.mark.parametrize('precision,tol', [('fp64', 1e-9), ('fp32', 2e-5)])
 def test_forward_backward_with_arbitrary_transition_matrices(fb_dense_cases, precision, tol):
     """vbx_amd.forward_backward takes any transition matrix, like VBx.py:146-175 (dense kernel, vbx_fb_dense.hpp):
