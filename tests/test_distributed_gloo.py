@@ -54,8 +54,14 @@ def _worker(rank, world, port, outdir):
         res = VBx_batch_distributed(_recordings(), maxIters=4, epsilon=-np.inf, Fa=0.3, Fb=17.0,
                                     run_shard=_oracle_shard, return_model=True, gather='all')
         np.random.seed(7)
+        tiny = VBx_batch_distributed(_recordings(), maxIters=4, epsilon=-np.inf, Fa=0.3, Fb=17.0, run_shard=_oracle_shard,
+                                     return_model=True, gather='all', gather_chunk_bytes=1)   # one recording per round, ragged
+        for x, y in zip(tiny, res):                              # round counts over the ranks (3 and 2): same results
+            assert all(np.array_equal(np.asarray(u), np.asarray(v)) for u, v in zip(x, y))
+        np.random.seed(7)
         at_root = VBx_batch_distributed(_recordings(), maxIters=4, epsilon=-np.inf, Fa=0.3, Fb=17.0,
-                                        run_shard=_oracle_shard, return_model=True, gather='root')   # one gather to rank 0
+                                        run_shard=_oracle_shard, return_model=True, gather='root',
+                                        gather_chunk_bytes=20000)   # gathers to rank 0, a few recordings per round
         np.random.seed(7)
         default = VBx_batch_distributed(_recordings(), maxIters=4, epsilon=-np.inf, Fa=0.3, Fb=17.0,
                                         run_shard=_oracle_shard, return_model=True)       # default (True): every rank, all

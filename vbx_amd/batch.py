@@ -204,7 +204,7 @@ def _as_tuple(res, return_model, warn=True):
 
 
 def VBx_batch_distributed(recordings, maxIters=10, epsilon=1e-4, precision=None, return_model=False,
-                          run_shard=None, gather=True, **defaults):
+                          run_shard=None, gather=True, gather_chunk_bytes=64 << 20, **defaults):
     """Shard ``recordings`` over the ranks of the initialised ``torch.distributed`` group.
 
     Every rank passes the same list; rank r computes the recordings assigned to it (LPT on T x S) on its own GPU.  There
@@ -219,6 +219,8 @@ def VBx_batch_distributed(recordings, maxIters=10, epsilon=1e-4, precision=None,
                              its own results and ``None`` for the rest -- the responsibilities travel once, to the rank
                              that writes them out (what ``vbx_amd.vbhmm`` and ``bench.py`` want)
       gather=False           nothing is exchanged: every rank returns its own results, ``None`` elsewhere
+
+    Gathered results travel in rounds of at most ``gather_chunk_bytes`` (64 MB) per rank.
 
     The reference's 'auxiliary function has decreased' warning (VBx.py:123-124) is printed by the rank that ran the
     recording, once.
@@ -250,12 +252,28 @@ def VBx_batch_distributed(recordings, maxIters=10, epsilon=1e-4, precision=None,
     local = {b: res for b, res in zip(mine, local)}
     merged = dict(local)
     if gather and world > 1:
-        if gather in (True, 'all'):
-            parts = [None] * world
-            dist.all_gather_object(parts, local)
-        else:
-            parts = [None] * world if rank == 0 else None
-            dist.gather_object(local, parts, dst=0)
-        for p in parts or []:
-            merged.update(p)
+        # The results travel in rounds of at most ``gather_chunk_bytes`` per rank (the responsibilities are 8 T S bytes per
+        # recording: a corpus in ONE pickled object would double every rank's footprint and serialise for seconds); every
+        # rank takes part in the same number of rounds -- the largest any rank needs, agreed on first.
+        rounds, cur, size = [], {}, 0
+        for b_, res in local.items():
+            nbytes = sum(getattr(v, 'nbytes', 64) for v in res.values())
+            if cur and size + nbytes > gather_chunk_bytes:
+                rounds.append(cur)
+                cur, size = {}, 0
+            cur[b_] = res
+            size += nbytes
+        rounds.append(cur)
+        counts = [None] * world
+        dist.all_gather_object(counts, len(rounds))
+        for r in range(max(counts)):
+            payload = rounds[r] if r < len(rounds) else {}
+            if gather in (True, 'all'):
+                parts = [None] * world
+                dist.all_gather_object(parts, payload)
+            else:
+                parts = [None] * world if rank == 0 else None
+                dist.gather_object(payload, parts, dst=0)
+            for p in parts or []:
+                merged.update(p)
     return [(_as_tuple(merged[b], return_model, warn=b in local) if b in merged else None) for b in range(len(recordings))]
