@@ -32,5 +32,33 @@ def main():
         print(json.dumps(out))
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and len(sys.argv) == 1:
     main()
+
+
+def batch_call():
+    """The headline batch as ONE call with host arrays in and out (VBx_batch: allocation, H2D of 64 x (X, gamma0), the
+    iterations, the gamma write-out, D2H of 64 x gamma): the PCIe-inclusive rate beside bench.py's HBM-resident one."""
+    from vbx_amd.batch import VBx_batch
+    from vbx_amd.synth import make_recording
+    recs = []
+    for b in range(64):
+        X, Phi, _ = make_recording(10000, 30, seed=b, kappa=0.05, dtype=np.float32)
+        g = np.random.default_rng(10_000 + b).gamma(1.0, size=(10000, 30)).astype(np.float32)
+        g /= g.sum(1, keepdims=True)
+        recs.append(dict(X=X, Phi=Phi, pi=30, gamma=g))
+    for precision in ('fp32-split', 'fp32', 'fp64'):
+        for iters in (10, 40):
+            kw = dict(maxIters=iters, epsilon=-1e300, loopProb=0.99, Fa=0.3, Fb=17.0, precision=precision)
+            VBx_batch(recs, **kw)
+            t = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                VBx_batch(recs, **kw)
+                t.append(time.perf_counter() - t0)
+            print(json.dumps({'batch': 64, 'T': 10000, 'S': 30, 'precision': precision, 'iterations': iters, 'call_ms': 1e3 * min(t),
+                              'recording_iterations_per_s_call_level': 64 * iters / min(t)}))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'batch':
+    batch_call()

@@ -88,6 +88,17 @@ __global__ __launch_bounds__(256) void qinit_kernel(const int* __restrict__ labe
     gamma[idx] = s >= S ? (R)0 : (s == labels[t] ? (R)hi : (R)lo);
 }
 
+// out[t][s] = (double)gamma[t][s], s < S: the responsibilities a caller asks for (VBx.py:126: gamma[T][S] float64) unpadded and
+// widened on the device, so that ONE copy lands them in the caller's array (vbx_batch_get_result).
+template <typename R>
+__global__ __launch_bounds__(256) void unpack_gamma_kernel(const R* __restrict__ gamma, double* __restrict__ out, long long T,
+                                                            int S, int Sp) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= T * S) return;
+    const long long t = idx / S;
+    out[idx] = (double)gamma[t * Sp + (idx - t * S)];
+}
+
 // Largest and second largest responsibility of every frame; ties go to the lower index (what a stable argsort of -q
 // gives; numpy's default argsort leaves the order of ties unspecified).  second = -1 when S == 1.
 template <typename R>
