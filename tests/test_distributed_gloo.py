@@ -44,6 +44,11 @@ def _oracle_shard(items, maxIters, epsilon):
     return out
 
 
+def assignment_of(recs):
+    from vbx_amd.batch import shard_recordings
+    return shard_recordings([r['X'].shape[0] * r['pi'] for r in recs], 2)
+
+
 def _worker(rank, world, port, outdir):
     sys.path.insert(0, REPO)
     import torch.distributed as dist
@@ -93,6 +98,35 @@ def _worker(rank, world, port, outdir):
             vb._normalise = real
         assert sorted(calls) == sorted(mixed[b]['X'].shape[0] for b in mine), (rank, calls, mine)
         np.savez(os.path.join(outdir, f'mixed{rank}.npz'), **{f'g{b}': r[0] for b, r in enumerate(part) if r is not None})
+        # a recording that cannot run fails on EVERY rank, not only on its owner (the others used to wait in the gather):
+        # (i) what the shapes show -- a gamma that does not fit -- before anything runs, the same AssertionError everywhere
+        bad = _recordings()
+        bad[2]['gamma'] = np.ones((bad[2]['X'].shape[0], bad[2]['pi'] + 1))
+        try:
+            VBx_batch_distributed(bad, maxIters=2, epsilon=-np.inf, Fa=0.3, Fb=17.0, run_shard=_oracle_shard, gather='all')
+            raise SystemExit('a gamma of the wrong width was accepted')
+        except AssertionError:
+            pass
+        # (ii) what only the owner finds out (here: its shard runner raises for one recording): the owner re-raises its own
+        # exception, the other rank raises a RuntimeError naming it -- nobody enters the gather
+        def failing_shard(items, mi, eps):
+            if any(it['X'].shape[0] == 450 for it in items):
+                raise ValueError('recording of 450 frames refused')
+            return _oracle_shard(items, mi, eps)
+        owner_450 = int(assignment_of(_recordings())[2])
+        try:
+            np.random.seed(7)
+            VBx_batch_distributed(_recordings(), maxIters=2, epsilon=-np.inf, Fa=0.3, Fb=17.0, run_shard=failing_shard, gather='root')
+            raise SystemExit('a failing shard went unnoticed')
+        except ValueError:
+            assert rank == owner_450
+        except RuntimeError as exc:
+            assert rank != owner_450 and f'rank {owner_450} failed' in str(exc) and '450 frames refused' in str(exc), str(exc)
+        np.random.seed(7)                                       # and the group is still usable afterwards
+        again = VBx_batch_distributed(_recordings(), maxIters=4, epsilon=-np.inf, Fa=0.3, Fb=17.0, run_shard=_oracle_shard,
+                                      return_model=True, gather='all')
+        for x, y in zip(again, res):
+            assert all(np.array_equal(np.asarray(u), np.asarray(v)) for u, v in zip(x, y))
         np.savez(os.path.join(outdir, f'rank{rank}.npz'), mine=np.array(mine),
                  **{f'g{b}': r[0] for b, r in enumerate(res)}, **{f'pi{b}': r[1] for b, r in enumerate(res)},
                  **{f'L{b}': np.array(r[2]) for b, r in enumerate(res)},

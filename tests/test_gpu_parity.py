@@ -327,11 +327,11 @@ def test_more_speakers_than_the_library_takes_is_an_error_not_a_crash():
         vbx_amd.VBx(X, np.ones(16), pi=S, gamma=np.full((40, S), 1.0 / S), maxIters=1)
 
 
-@pytest.mark.parametrize('S,T', [(1025, 1300), (1100, 1400), (2500, 2600), (4097, 4200)])
+@pytest.mark.parametrize('S,T', [(1025, 1300), (1100, 1400), (2500, 2600), (4097, 4200), (8200, 8300)])
 def test_more_than_1024_states(S, T):
     """The reference takes any number of states (VBx.py:76-85).  Beyond 1024 the walk, the posteriors and the
     iteration-finishing reductions run on a workgroup per recording with loops over blocks of states (vbx_big.hpp: padded
-    widths 2048, 4096, 8192).  Against the oracle -- its linear-domain iteration, which tests/test_oracle_golden.py and
+    widths 2048, 4096, 8192, 16 384 -- the last one, 16 states per thread, from S = 8193).  Against the oracle -- its linear-domain iteration, which tests/test_oracle_golden.py and
     tests/test_chunked_scan_model.py pin to the log-domain restatement: the reference's own S x S logsumexp per frame would
     take minutes at this size -- after one, two and three iterations from a soft AHC-like start, fp64 and fp32, with and
     without the reference's stopping rule; T > S as an AHC result always has."""
@@ -368,11 +368,15 @@ def test_more_than_1024_states(S, T):
                 # iteration is held to the bound proper; three are a sanity check only.
                 assert np.abs(g - wg).max() <= 5e-3 and np.abs(p - wp).max() <= 5e-3
                 continue
-            assert np.abs(g - wg).max() <= tol and np.abs(p - wp).max() <= tol, (precision, n, np.abs(g - wg).max())
+            # (S > 8192, fp32: 16 states per thread and sums over 16 384 padded states in working precision -- 1.5e-4 measured at
+            #  S = 8200 after ONE iteration, fp64 1e-8: the instance exists so that the reference's "any len(pi)" runs at all;
+            #  INTEGRATION.md recommends fp64 beyond 4096 states)
+            tol_s = 3e-4 if (precision == 'fp32' and S > 8192) else tol
+            assert np.abs(g - wg).max() <= tol_s and np.abs(p - wp).max() <= tol_s, (precision, n, np.abs(g - wg).max())
             # (fp32: sums over thousands of states in working precision while speakers are still forming -- 1.4e-6 measured at
             #  S = 1025 after two iterations; north_star's bound is 1e-4)
             assert rel_err([r[0] for r in Li], [w[2] for w in want[:n]]) <= (1e-10 if precision == 'fp64' else 1e-5)
-            assert np.abs(al - wa).max() <= tol * max(1.0, np.abs(wa).max()) and rel_err(il, wi) <= max(tol, 1e-9)
+            assert np.abs(al - wa).max() <= tol_s * max(1.0, np.abs(wa).max()) and rel_err(il, wi) <= max(tol_s, 1e-9)
             assert np.abs(g.sum(1) - 1).max() < 1e-5
     # the stopping rule on the device (VBx.py:122-125): stop where the oracle's ELBO history says the reference would
     hist = [w[2] for w in want]
@@ -673,6 +677,74 @@ def test_sharing_across_stream_sub_batches_copies_the_rows_once_per_stream(ctx, 
             with pytest.raises(_capi.VbxError):                       # a point cannot become the source of its own source
                 batch.set_recording_shared(0, 1, np.ones(S) / S, g0, 0.9, 0.3, 17.0)
         batch.close()
+
+
+def test_resident_setter_and_clone_owner_in_a_stream_group(ctx):
+    """The bookkeeping of who runs on whose rows, for the setter the driver uses (round-5 advisor findings).
+    (a) a recording set again from resident rows: the points that run on copies of its OLD x-vectors in other sub-batches must
+        be set again before the next run (they used to stay set and ran on stale rows);
+    (b) a recording that shared another's rows and then gets resident rows of its own is a root again: a later point that
+        names it as its source gets ITS rows, not its former source's;
+    (c) a clone owner (the point of a sub-batch that holds the copy) can be set again on the same source -- as on one stream --
+        and the points of its sub-batch that read its copy must then be set again."""
+    from vbx_amd import _capi
+    from vbx_amd.synth import make_recording
+    T, S, n, D = 1500, 8, 6, 128
+    X, Phi, _ = make_recording(T, S, seed=2, kappa=0.05)
+    X2, _, _ = make_recording(T, S, seed=9, kappa=0.05)
+    g0 = np.random.default_rng(3).gamma(1.0, size=(T, S))
+    g0 /= g0.sum(1, keepdims=True)
+    labels = np.random.default_rng(5).integers(0, S, size=T)
+    eye = np.eye(D)
+    zero = np.zeros(D)
+    xv = _capi.XVectors(ctx, np.vstack([X, X2]), zero, eye, zero, zero, 12.0 * eye, D)
+    X, X2 = xv.get('fea', 0, T), xv.get('fea', T, T)          # (what the resident rows hold: the driver's projections normalise)
+    pi0 = np.ones(S) / S
+    q0 = np.exp(7.0 * np.eye(S)[labels])
+    q0 /= q0.sum(1, keepdims=True)
+
+    def plain(Xk, g, fa, fb):
+        b = _capi.Batch(ctx, [T], [S], D, precision='fp64', max_iters=2)
+        b.set_recording(0, Xk, Phi, pi0, g, 0.9, fa, fb)
+        b.run(2, -np.inf)
+        out = b.result(0)
+        b.close()
+        return out
+
+    batch = _capi.Batch(ctx, [T] * n, [S] * n, D, precision='fp64', max_iters=2, streams=3)
+    kid = {}                                                   # recordings are dealt round-robin for equal lengths: 0,3 / 1,4 / 2,5
+    batch.set_recording(0, X, Phi, pi0, g0, 0.9, 0.3, 17.0)
+    for k in range(1, n):
+        batch.set_recording_shared(k, 0, pi0, g0, 0.9, 0.3, 17.0 + k)
+    batch.run(2, -np.inf)
+    # (a)
+    batch.set_recording_resident(0, xv, T, labels, 7.0, Phi, 0.9, 0.3, 17.0)        # recording 0 <- the rows of X2
+    with pytest.raises(_capi.VbxError, match='has not been set'):
+        batch.run(1, -np.inf)
+    # (b): 1 shared 0's rows; now it gets rows of its own (X, resident) and 2 names it as its source
+    batch.set_recording_resident(1, xv, 0, labels, 7.0, Phi, 0.9, 0.3, 18.0)
+    for k in range(2, n):
+        batch.set_recording_shared(k, 1, pi0, g0, 0.9, 0.3, 17.0 + k)
+    batch.run(2, -np.inf)
+    want0 = plain(X2, q0, 0.3, 17.0)
+    want1 = plain(X, q0, 0.3, 18.0)
+    assert np.allclose(batch.result(0)['gamma'], want0['gamma'], atol=1e-12, rtol=0)
+    assert np.allclose(batch.result(1)['gamma'], want1['gamma'], atol=1e-12, rtol=0)
+    for k in range(2, n):
+        want = plain(X, g0, 0.3, 17.0 + k)
+        got = batch.result(k)
+        for key in ('gamma', 'pi', 'Li'):
+            assert np.allclose(got[key], want[key], atol=1e-12, rtol=0), (k, key)     # (X's rows, not X2's)
+    # (c): find a clone owner -- a point that lives in another sub-batch than its source -- and set it again
+    batch.set_recording_shared(2, 1, pi0, g0, 0.9, 0.25, 30.0)
+    with pytest.raises(_capi.VbxError, match='has not been set'):                     # 5 read the copy 2 owned
+        batch.run(1, -np.inf)
+    batch.set_recording_shared(5, 1, pi0, g0, 0.9, 0.3, 22.0)
+    batch.run(2, -np.inf)
+    assert np.allclose(batch.result(2)['gamma'], plain(X, g0, 0.25, 30.0)['gamma'], atol=1e-12, rtol=0)
+    assert np.allclose(batch.result(5)['gamma'], plain(X, g0, 0.3, 22.0)['gamma'], atol=1e-12, rtol=0)
+    batch.close()
+    xv.close()
 
 
 def test_python_sweep_api_equals_one_call_per_point(synth_cases):

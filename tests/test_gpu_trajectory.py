@@ -1,0 +1,178 @@
+"""Parity at EVERY EM iteration, not only at the two ends (-m gpu).
+
+The reference's contract is "any maxIters" (VBx.py:27-29, the loop VBx.py:91, the stop test VBx.py:122-125): a caller may stop
+after any iteration, so the responsibilities, priors, ELBO and speaker models must match after any iteration.
+tests/golden/traj_<cfg>.npz (tests/golden/make_golden_trajectory.py) holds the outputs of the UNMODIFIED reference after each
+iteration of BASELINE.json's configs at full size -- a chain of maxIters=1 calls, checked there bit for bit against the
+single-call fixtures -- and traj_<cfg>_referee.npz the same trajectory from the extended-precision referee
+(oracle/vbx_oracle_x.py, numpy.longdouble): the exact result of the reference's algorithm on these inputs.
+
+Every entry is a FRESH call with maxIters = k (what a caller does), per precision:
+
+  fp64        held at every iteration to the bounds of tests/test_gpu_configs.py against the reference, and to 5e-7 against the
+              referee wherever the reference itself is that close to it
+  fp32        north_star's 1e-4 on gamma / pi / alpha / invL and 1e-6 on the ELBO at every iteration -- against the reference,
+  fp32-split  or, at an iteration where the reference's own float64 rounding has moved IT further than 2e-5 from the exact
+              result (long recordings, mid-trajectory: REFERENCE_OFF-style, decided from the two fixtures, not from the kernels),
+              against the referee
+
+and the maxima over the trajectory go to gpurun_out/trajectory_parity.json (committed as profiles/r06_trajectory_parity.json).
+A run that continues (run(1) k times on one batch) must give bit for bit what the fresh call with maxIters = k gives.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PRECISIONS = ['fp64', 'fp32', 'fp32-split']
+_REPORT = {}
+
+FP64_TOL = 5e-6            # against the reference (x max(1, T / 25 000): its own rounding grows with T; test_gpu_configs.py)
+FP64_TRUTH = 5e-7          # against the referee
+FP32_TOL = 1e-4            # north_star
+REF_TRUSTED = 2e-5         # the reference counts as "the answer" at an iteration where it is this close to the referee
+
+
+def load(name):
+    with np.load(os.path.join(HERE, 'golden', f'traj_{name}.npz')) as z:
+        ref = {k: z[k] for k in z.files}
+    with np.load(os.path.join(HERE, 'golden', f'traj_{name}_referee.npz')) as z:
+        tru = {k: z[k] for k in z.files}
+    for key in ('gen', 'X_checksum', 'g0_checksum', 'rows', 'iterations'):
+        assert np.array_equal(ref[f'{name}/{key}'], tru[f'{name}/{key}']), key
+    return ref, tru
+
+
+def inputs(ref, name):
+    from vbx_amd.synth import make_recording
+    T, S, seed, kappa = ref[name + '/gen']
+    T, S = int(T), int(S)
+    X, Phi, _ = make_recording(T, S, seed=int(seed), kappa=float(kappa))
+    g0_seed = int(ref[name + '/g0_seed'])
+    if g0_seed < 0:
+        np.random.seed(1)
+        g0 = np.random.gamma(1.0, size=(T, S))
+        g0 = g0 / g0.sum(1, keepdims=True)
+    else:
+        g0 = np.random.default_rng(g0_seed).gamma(1.0, size=(T, S))
+        g0 /= g0.sum(1, keepdims=True)
+    chk = ref[name + '/X_checksum']
+    assert np.allclose([X.sum(), (X ** 2).sum(), Phi.sum()], chk, rtol=0, atol=1e-9 * max(1.0, abs(chk[1])))
+    assert np.allclose([g0.sum(), (g0 ** 2).sum(), g0[T // 2].max()], ref[name + '/g0_checksum'], rtol=1e-12, atol=0)
+    return X, Phi, g0, S
+
+
+def diffs(fix, tag, rows, res, k):
+    ra = fix[tag + '/alpha']
+    return {
+        'gamma': float(np.abs(res['gamma'][rows] - fix[tag + '/gamma_rows']).max()),
+        'pi': float(np.abs(res['pi'] - fix[tag + '/pi']).max()),
+        'Li_rel': float(abs(res['Li'][k - 1] - float(fix[tag + '/Li'])) / abs(float(fix[tag + '/Li']))),
+        'alpha': float(np.abs(res['alpha'] - ra).max() / max(1.0, np.abs(ra).max())),
+        'invL_rel': float((np.abs(res['invL'] - fix[tag + '/invL']) / fix[tag + '/invL']).max()),
+        'colsum_rel': float((np.abs(res['gamma'].sum(0) - fix[tag + '/gamma_colsum']) / np.maximum(1.0, fix[tag + '/gamma_colsum'])).max()),
+    }
+
+
+def fixture_gap(ref, tru, tag):
+    """how far the reference itself is from the exact result at this iteration (gamma rows, pi)"""
+    return max(float(np.abs(ref[tag + '/gamma_rows'] - tru[tag + '/gamma_rows']).max()),
+               float(np.abs(ref[tag + '/pi'] - tru[tag + '/pi']).max()))
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from vbx_amd import _capi
+    return _capi.Context(0)
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _write_report():
+    yield
+    out = os.path.join(os.path.dirname(HERE), 'gpurun_out')
+    try:
+        os.makedirs(out, exist_ok=True)
+        path = os.path.join(out, 'trajectory_parity.json')
+        old = {}
+        if os.path.exists(path):
+            with open(path) as f:
+                old = json.load(f)
+        old.update(_REPORT)
+        with open(path, 'w') as f:
+            json.dump(old, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def run_fresh(ctx, X, Phi, g0, S, hyper, k, precision):
+    from vbx_amd import _capi
+    lp, fa, fb = (float(v) for v in hyper)
+    batch = _capi.Batch(ctx, [X.shape[0]], [S], X.shape[1], precision=precision, max_iters=k)
+    batch.set_recording(0, X, Phi, np.ones(S) / S, g0, lp, fa, fb)
+    batch.run(k, -np.inf)
+    assert batch.gemm == ('split' if precision == 'fp32-split' else 'exact')
+    res = batch.result(0)
+    batch.close()
+    return res
+
+
+@pytest.mark.parametrize('precision', PRECISIONS)
+@pytest.mark.parametrize('name', ['hl', 'c2', 'c3', 'c5'])
+def test_every_iteration_of_the_trajectory(ctx, name, precision):
+    ref, tru = load(name)
+    X, Phi, g0, S = inputs(ref, name)
+    T = X.shape[0]
+    rows = ref[name + '/rows']
+    hyper = ref[name + '/hyper']
+    table, failures = {}, []
+    for k in (int(v) for v in ref[name + '/iterations']):
+        tag = f'{name}/it{k}'
+        res = run_fresh(ctx, X, Phi, g0, S, hyper, k, precision)
+        assert len(res['Li']) == k
+        d_ref, d_tru = diffs(ref, tag, rows, res, k), diffs(tru, tag, rows, res, k)
+        gap = fixture_gap(ref, tru, tag)
+        table[k] = {'vs_reference': d_ref, 'vs_referee': d_tru, 'reference_vs_referee': gap}
+        if precision == 'fp64':
+            tol = FP64_TOL * max(1.0, T / 25000)
+            ok = (d_tru['gamma'] <= FP64_TRUTH and d_tru['pi'] <= FP64_TRUTH and d_tru['Li_rel'] <= 1e-10 and d_tru['alpha'] <= FP64_TRUTH)
+            if gap <= tol:                              # the reference is usable here: its own bounds as well
+                ok = ok and d_ref['gamma'] <= tol and d_ref['pi'] <= tol and d_ref['Li_rel'] <= 2e-8 * max(1.0, T / 50000)
+        else:
+            d = d_ref if gap <= REF_TRUSTED else d_tru
+            ok = (d['gamma'] <= FP32_TOL and d['pi'] <= FP32_TOL and d['alpha'] <= FP32_TOL and d['invL_rel'] <= FP32_TOL and
+                  d['Li_rel'] <= 1e-6 and d['colsum_rel'] <= 2e-4)
+        if not ok:
+            failures.append((k, table[k]))
+    worst = {side: {q: max(table[k][side][q] for k in table) for q in ('gamma', 'pi', 'Li_rel', 'alpha', 'invL_rel', 'colsum_rel')}
+             for side in ('vs_reference', 'vs_referee')}
+    worst['at_iteration'] = {side: int(max(table, key=lambda k: table[k][side]['gamma'])) for side in ('vs_reference', 'vs_referee')}
+    worst['reference_vs_referee'] = max(table[k]['reference_vs_referee'] for k in table)
+    _REPORT[f'{name}/{precision}'] = {'max_over_iterations': worst, 'per_iteration': {str(k): v for k, v in table.items()}}
+    print(f'{name} {precision}: max over {len(table)} iterations: gamma {worst["vs_reference"]["gamma"]:.2e} vs reference (iteration '
+          f'{worst["at_iteration"]["vs_reference"]}), {worst["vs_referee"]["gamma"]:.2e} vs referee; reference vs referee {worst["reference_vs_referee"]:.2e}')
+    assert not failures, failures
+
+
+@pytest.mark.parametrize('precision', PRECISIONS)
+def test_a_continued_run_is_the_fresh_call(ctx, precision):
+    """run(1) k times on one batch == one run(k) on a fresh one, bit for bit (the loop's state lives on the device between
+    runs; VBx.py:91: the reference's loop has no other state than gamma and pi either)."""
+    from vbx_amd import _capi
+    ref, _ = load('hl')
+    X, Phi, g0, S = inputs(ref, 'hl')
+    lp, fa, fb = (float(v) for v in ref['hl/hyper'])
+    batch = _capi.Batch(ctx, [X.shape[0]], [S], X.shape[1], precision=precision, max_iters=6)
+    batch.set_recording(0, X, Phi, np.ones(S) / S, g0, lp, fa, fb)
+    for k in range(1, 7):
+        batch.run(1, -np.inf)
+        if k in (1, 3, 6):
+            cont = batch.result(0)
+            fresh = run_fresh(ctx, X, Phi, g0, S, ref['hl/hyper'], k, precision)
+            for key in ('gamma', 'pi', 'alpha', 'invL'):
+                assert np.array_equal(cont[key], fresh[key]), (k, key)
+            assert np.array_equal(cont['Li'][:k], fresh['Li'][:k]), k
+    batch.close()

@@ -77,7 +77,19 @@ def _shape_of(rec, defaults):
     kw.update({k: v for k, v in rec.items() if k in PER_RECORDING})
     pi = kw.get('pi', 10)
     S = pi if type(pi) is int else len(pi)
-    T = np.shape(rec['X'])[0]
+    xs = np.shape(rec['X'])
+    if len(xs) != 2:
+        raise ValueError(f'VBx_batch: X must be T x D, got shape {xs}')
+    T = xs[0]
+    # the checks of _normalise that need no copy, on EVERY rank: a recording that cannot run fails everywhere at once,
+    # before any rank enters a collective (round 6; owner-only validation left the other ranks waiting in the gather)
+    if np.shape(rec['Phi']) != (xs[1],):
+        raise ValueError(f'VBx_batch: Phi has shape {np.shape(rec["Phi"])}, X has {xs[1]} dimensions')
+    if kw.get('gamma') is not None:
+        assert np.shape(kw['gamma']) == (T, S), (np.shape(kw['gamma']), (T, S))     # VBx.py:85
+    for name in ('alpha', 'invL'):
+        if kw.get(name) is not None and np.shape(kw[name]) != (S, xs[1]):
+            raise ValueError(f'VBx_batch: {name} has shape {np.shape(kw[name])}, expected {(S, xs[1])}')
     return int(T), int(S), (kw.get('alphaQInit', 1.0) if kw.get('gamma') is None else None)
 
 
@@ -239,16 +251,33 @@ def VBx_batch_distributed(recordings, maxIters=10, epsilon=1e-4, precision=None,
     shapes = [_shape_of(r, defaults) for r in recordings]
     assignment = shard_recordings([t * s for t, s, _ in shapes], world)
     mine, items = [], {}
-    for b, rec in enumerate(recordings):
-        if assignment[b] == rank:
-            items[b] = _normalise(rec, defaults)                           # (draws, if it has to, at its place in the order)
-            mine.append(b)
-        elif shapes[b][2] is not None:
-            np.random.gamma(shapes[b][2], size=(shapes[b][0], shapes[b][1]))     # keep the global stream in step; discard
     if run_shard is None:
         def run_shard(sub, mi, eps):
             return run_shard_hip(sub, mi, eps, precision=precision)
-    local = run_shard([items[b] for b in mine], int(maxIters), epsilon) if mine else []
+    # What only the owner can find out (values the library refuses, a device error) must not leave the other ranks waiting
+    # in a collective: the local work runs under a guard, the ranks agree on the outcome in one tiny exchange, and a failure
+    # anywhere is raised everywhere (the owner re-raises its own exception, the others name the rank and the message).
+    failure, local = None, []
+    try:
+        for b, rec in enumerate(recordings):
+            if assignment[b] == rank:
+                items[b] = _normalise(rec, defaults)                       # (draws, if it has to, at its place in the order)
+                mine.append(b)
+            elif shapes[b][2] is not None:
+                np.random.gamma(shapes[b][2], size=(shapes[b][0], shapes[b][1]))     # keep the global stream in step; discard
+        local = run_shard([items[b] for b in mine], int(maxIters), epsilon) if mine else []
+    except Exception as exc:                                               # noqa: BLE001 (re-raised below, on every rank)
+        if world == 1:
+            raise
+        failure = exc
+    if world > 1:
+        status = [None] * world
+        dist.all_gather_object(status, None if failure is None else f'{type(failure).__name__}: {failure}')
+        if failure is not None:
+            raise failure
+        bad = [(r, m) for r, m in enumerate(status) if m is not None]
+        if bad:
+            raise RuntimeError('VBx_batch_distributed: ' + '; '.join(f'rank {r} failed ({m})' for r, m in bad))
     local = {b: res for b, res in zip(mine, local)}
     merged = dict(local)
     if gather and world > 1:

@@ -702,6 +702,11 @@ static int run_end(vbx_batch* b) {
     HIPCHK(ctx, hipEventRecord(b->ev_stop, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipGetLastError());
+    if (b->launch_rc != VBX_OK) {             // (a launch helper had no instance for Sp: nothing ran -- an error, not a no-op)
+        const int rc = b->launch_rc;
+        b->launch_rc = VBX_OK;
+        FAIL(ctx, rc, "no kernel instance for a padded state count of %d", b->Sp);
+    }
     float ms = 0.f;
     HIPCHK(ctx, hipEventElapsedTime(&ms, b->ev_start, b->ev_stop));
     b->last_ms = ms;

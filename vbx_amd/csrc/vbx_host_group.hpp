@@ -151,6 +151,21 @@ static int group_build(vbx_batch* b, int K) {
     return VBX_OK;
 }
 
+// `rec` is about to get other x-vectors than it has (new ones of its own: `own`; or another recording's): whoever runs on
+// a copy of its old rows in ANOTHER sub-batch must be set again (inside its own sub-batch own_rho does the same), and the
+// bookkeeping of who shares whose rows follows.  One helper for the three setters (round 6, the advisor's finding: the
+// resident setter used to skip this and left clones running on stale x-vectors).
+static void group_new_rows(vbx_batch* b, int rec, bool own) {
+    const int k = b->kid_of[rec];
+    if (b->root_of[rec] == rec)
+        for (int i = 0; i < b->n_rec; ++i)
+            if (i != rec && b->root_of[i] == rec) {
+                b->root_of[i] = i;
+                if (b->kid_of[i] != k) b->kids[b->kid_of[i]]->is_set[b->local_of[i]] = 0;
+            }
+    if (own) b->root_of[rec] = rec;
+}
+
 int vbx_batch_create(vbx_ctx* ctx, int n_rec, const int64_t* T, const int32_t* S, int32_t D, int precision,
                      int max_iters, vbx_batch** out) {
     return vbx_batch_create_streams(ctx, n_rec, T, S, D, precision, max_iters, 0, out);
@@ -225,14 +240,7 @@ int vbx_batch_set_recording(vbx_batch* b, int rec, const void* X, int x_dtype, c
     if (rec < 0 || rec >= b->n_rec) FAIL(b->ctx, VBX_ERR_INVALID, "recording index %d out of range", rec);
     b->any_set = true;
     const int k = b->kid_of[rec];
-    // new x-vectors for `rec`: whoever runs on a copy of its old ones in ANOTHER sub-batch must be set again (inside its own
-    // sub-batch own_rho does the same)
-    for (int i = 0; i < b->n_rec; ++i)
-        if (i != rec && b->root_of[i] == rec) {
-            b->root_of[i] = i;
-            if (b->kid_of[i] != k) b->kids[b->kid_of[i]]->is_set[b->local_of[i]] = 0;
-        }
-    b->root_of[rec] = rec;
+    group_new_rows(b, rec, true);
     return kid_fail(b, k, leaf_set_recording(b->kids[k], b->local_of[rec], X, x_dtype, Phi, pi0, gamma0, g_dtype, alpha0,
                                              invL0, loopProb, Fa, Fb));
 }
@@ -251,12 +259,7 @@ int vbx_batch_set_recording_shared(vbx_batch* b, int rec, int src_rec, const dou
     const int k = b->kid_of[rec], ks = b->kid_of[src_rec];
     const int root = b->root_of[src_rec];
     if (root == rec) FAIL(b->ctx, VBX_ERR_STATE, "recording %d runs on the x-vectors of recording %d: it cannot be that recording's source", src_rec, rec);
-    if (b->root_of[rec] == rec)                               // (`rec` had x-vectors of its own: its dependants in other sub-batches)
-        for (int i = 0; i < b->n_rec; ++i)
-            if (i != rec && b->root_of[i] == rec) {
-                b->root_of[i] = i;
-                if (b->kid_of[i] != k) b->kids[b->kid_of[i]]->is_set[b->local_of[i]] = 0;
-            }
+    group_new_rows(b, rec, false);                            // (`rec` had x-vectors of its own: its dependants in other sub-batches)
     b->any_set = true;
     int rc;
     if (ks == k) {
@@ -264,7 +267,9 @@ int vbx_batch_set_recording_shared(vbx_batch* b, int rec, int src_rec, const dou
     } else {
         int local_src = -1;                                   // a recording of sub-batch k that already holds these x-vectors
         for (int i = 0; i < b->n_rec && local_src < 0; ++i)
-            if (i != rec && b->kid_of[i] == k && b->root_of[i] == root && b->kids[k]->is_set[b->local_of[i]]) local_src = b->local_of[i];
+            if (i != rec && b->kid_of[i] == k && b->root_of[i] == root && b->kids[k]->is_set[b->local_of[i]] &&
+                b->kids[k]->share_src[b->local_of[i]] != b->local_of[rec])        // (not one that reads `rec`'s own copy: `rec` is
+                local_src = b->local_of[i];                                       //  the clone owner being set again -> a fresh clone)
         rc = local_src >= 0
                  ? leaf_set_recording_shared(b->kids[k], b->local_of[rec], local_src, pi0, gamma0, g_dtype, alpha0, invL0, loopProb, Fa, Fb)
                  : leaf_set_recording_cloned(b->kids[k], b->local_of[rec], b->kids[ks], b->local_of[src_rec], pi0, gamma0, g_dtype,
@@ -324,6 +329,7 @@ int vbx_batch_set_recording_resident(vbx_batch* b, int rec, const vbx_xvectors* 
     if (rec < 0 || rec >= b->n_rec) FAIL(b->ctx, VBX_ERR_INVALID, "recording index %d out of range", rec);
     b->any_set = true;
     const int k = b->kid_of[rec];
+    group_new_rows(b, rec, true);
     return kid_fail(b, k, leaf_set_recording_resident(b->kids[k], b->local_of[rec], xv, row0, labels, init_smoothing, Phi,
                                                       loopProb, Fa, Fb));
 }

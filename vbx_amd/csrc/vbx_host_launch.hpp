@@ -38,7 +38,7 @@ static int split_debug_mask() {
         case 4: { constexpr int kNT = 4; BODY } break;         \
         case 8: { constexpr int kNT = 8; BODY } break;         \
         case 16: { constexpr int kNT = 16; BODY } break;       \
-        default: break;                                        \
+        default: b->launch_rc = VBX_ERR_UNSUPPORTED; break;    \
     }
 
 template <typename R> void launch_mstep_acc(vbx_batch* b, double eps) {

@@ -96,6 +96,7 @@ struct vbx_batch {
     int streams = 0;                              // option: 0 auto, >= 1 explicit
     struct GroupThreads* threads = nullptr;       // one sleeping host thread per kid beyond the first
     bool any_set = false;
+    int launch_rc = 0;                            // a launch helper found no kernel instance for this batch's padded width (checked in run_end)
     int n_rec = 0, D = 0, Dp = 0, Sp = 0, NT = 0, precision = 0, max_iters = 0;
     size_t rsize = 4;
     long long sum_T = 0;
