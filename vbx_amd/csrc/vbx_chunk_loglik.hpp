@@ -193,6 +193,9 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? (SPLIT && SP == 
         R biasv[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) biasv[n] = bt.bias[(long long)par * bt.vec_stride + (long long)rec * SP + 16 * n + i];
+        R falo[NT];                                    // Fa * (what the bias lost when it was rounded to R): BatchView::bias_lo
+#pragma unroll
+        for (int n = 0; n < NT; ++n) falo[n] = Fa * bt.bias_lo[(long long)par * bt.vec_stride + (long long)rec * SP + 16 * n + i];
         // (a full chunk -- all but the last one of a recording -- stores without per-row conditions: each of them is a
         //  branch around the store)
         auto epilogue = [&](auto full_tag) {
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? (SPLIT && SP == 
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
                         const int s = 16 * n + i;
-                        v[n] = (s < rd.S) ? Fa * (SPLIT ? acc[m][n][r] * cscale[n] + biasv[n] : acc[m][n][r] + biasv[n]) : neg_inf<R>();
+                        v[n] = (s < rd.S) ? Fa * (SPLIT ? acc[m][n][r] * cscale[n] + biasv[n] : acc[m][n][r] + biasv[n]) + falo[n] : neg_inf<R>();
                         mx = vmax(mx, v[n]);
                     }
                     mx = allreduce_max<16>(mx);

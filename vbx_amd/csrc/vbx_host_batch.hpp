@@ -164,7 +164,7 @@ static int leaf_create(vbx_ctx* ctx, int n_rec, const int64_t* T, const int32_t*
     ALLOC(dmalloc_bytes(ctx, &b->d_mrow, (size_t)b->sum_T * rs));
     ALLOC(dmalloc_bytes(ctx, &b->d_alpha, (size_t)2 * n_rec * b->Sp * b->Dp * rs));     // (two copies: fin_kernel)
     ALLOC(dmalloc_bytes(ctx, &b->d_invL, (size_t)2 * n_rec * b->Sp * b->Dp * rs));
-    ALLOC(dmalloc_bytes(ctx, &b->d_bias, (size_t)2 * n_rec * b->Sp * rs));
+    ALLOC(dmalloc_bytes(ctx, &b->d_bias, (size_t)4 * n_rec * b->Sp * rs));              // (two copies of bias, then two of bias_lo)
     ALLOC(dmalloc_bytes(ctx, &b->d_mpart, (size_t)b->ntiles_total * b->Sp * b->Dp * rs));
     ALLOC(dmalloc_bytes(ctx, &b->d_npart, (size_t)b->ntiles_total * b->Sp * rs));
     ALLOC(dmalloc(ctx, &b->d_emodel, (size_t)2 * n_rec * b->Sp));

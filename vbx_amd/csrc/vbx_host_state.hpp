@@ -188,7 +188,7 @@ struct vbx_batch {
         v.phi = d_phi;
         v.rho = (R*)d_rho; v.gamma = (R*)d_gamma; v.bmat = (R*)d_bmat; v.mrow = (R*)d_mrow;
         v.ahat = (R*)d_ahat; v.bhat = (R*)d_bhat; v.alpha = (R*)d_alpha; v.invL = (R*)d_invL;
-        v.bias = (R*)d_bias; v.emodel = d_emodel; v.pi = d_pi; v.mpart = (R*)d_mpart;
+        v.bias = (R*)d_bias; v.bias_lo = (R*)d_bias + (size_t)2 * n_rec * Sp; v.emodel = d_emodel; v.pi = d_pi; v.mpart = (R*)d_mpart;
         v.npart = (R*)d_npart; v.epart = d_epart; v.Li = d_Li; v.epsilon = epsilon;
         v.ip = d_ip ? d_ip : d_pi; v.fw_scale = (R*)d_fw_scale; v.bw_scale = (R*)d_bw_scale;
         v.oph = fused_now && half_ops_now ? (R*)d_oph : nullptr; v.ophexp = d_ophexp;

@@ -71,6 +71,10 @@ template <typename R> struct BatchView {
     R* alpha;              // [n_rec][Sp][Dp]
     R* invL;
     R* bias;               // [n_rec][Sp]   -0.5 * sum_d (invL + alpha^2) Phi
+    R* bias_lo;            // [n_rec][Sp]   what rounding that f64 sum to R lost (fp32 paths; zero in fp64).  Round 6: a speaker's
+                           // bias enters EVERY frame's log-likelihood, so its rounding error (2^-24 |bias|) is not noise that
+                           // averages out over T but a systematic shift of the speaker's mass -- 20 x every other f32 rounding
+                           // of an iteration together at the iterations where the EM map amplifies (tests/test_gpu_trajectory.py)
     double* emodel;        // [n_rec][Sp]   sum_d (log invL - invL - alpha^2 + 1)
     double* pi;            // [n_rec][Sp]
     const double* ip;      // [n_rec][Sp]   initial-state probabilities; aliases pi in VBx() (VBx.py:99)
@@ -432,7 +436,10 @@ __global__ __launch_bounds__(1024) void fin_kernel(BatchView<R> bt, int mode) {
     esum = block_sum(esum, lds);
     if (threadIdx.x == 0) {
         const long long vi = (long long)(k & 1) * bt.vec_stride + (long long)rec * Sp + s;
-        bt.bias[vi] = (R)(-0.5 * bsum);
+        const double bv = -0.5 * bsum;
+        const R bhi = (R)bv;
+        bt.bias[vi] = bhi;
+        bt.bias_lo[vi] = (R)(bv - (double)bhi);
         bt.emodel[vi] = esum;
     }
 }
@@ -517,6 +524,9 @@ __global__ __launch_bounds__(256) void loglik_kernel(BatchView<R> bt, R* __restr
     R biasv[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) biasv[n] = bt.bias[(long long)par * bt.vec_stride + (long long)rec * Sp + s0 + 16 * n + i];
+    R falo[NT];                                        // Fa * (the part of the bias its R rounding lost): BatchView::bias_lo
+#pragma unroll
+    for (int n = 0; n < NT; ++n) falo[n] = Fa * bt.bias_lo[(long long)par * bt.vec_stride + (long long)rec * Sp + s0 + 16 * n + i];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -527,7 +537,7 @@ __global__ __launch_bounds__(256) void loglik_kernel(BatchView<R> bt, R* __restr
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const int s = s0 + 16 * n + i;
-                v[n] = (s < rd.S) ? Fa * (acc[m][n][r] + biasv[n]) : neg_inf<R>();
+                v[n] = (s < rd.S) ? Fa * (acc[m][n][r] + biasv[n]) + falo[n] : neg_inf<R>();
                 mx = vmax(mx, v[n]);
             }
             mx = allreduce_max<16>(mx);
