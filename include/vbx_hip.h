@@ -23,13 +23,14 @@
 #ifndef VBX_HIP_H
 #define VBX_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define VBX_ABI_VERSION 6
+#define VBX_ABI_VERSION 7
 
 /* error codes */
 #define VBX_OK 0
@@ -82,6 +83,11 @@ extern "C" {
                                    (x 2^e = hi + lo, three products, f32 accumulation: 2^-22 per product; rho kept in HBM
                                    as such pairs in MFMA fragment order -- vbx_amd/csrc/vbx_split.hpp).  fp32 batches on
                                    the fused kernels (S <= 64) only; ignored elsewhere.  env VBX_AMD_GEMM=exact|split   */
+#define VBX_OPT_ASYNC_UPLOAD 15 /* 1: vbx_batch_set_recording / _shared only ENQUEUE the upload (no synchronize per recording):
+                                   the caller's X and gamma0 must stay valid until the next vbx_batch_run or
+                                   vbx_batch_sync_uploads returns.  0 (default): every setter returns with the caller's
+                                   buffers free, as in ABI <= 6.  What a batch call saves: 64 recordings of T = 10 000 go up in
+                                   ONE synchronize instead of 64 (ABI 7) */
 #define VBX_GEMM_EXACT 0
 #define VBX_GEMM_SPLIT 1
 #define VBX_OPT_FUSE 5          /* per-chunk fused kernels when the lattices fit in LDS: 0 none, 1 chunk_post,
@@ -167,6 +173,32 @@ int vbx_batch_run(vbx_batch* batch, int max_iters, double epsilon);
 int vbx_batch_get_result(vbx_batch* batch, int b, double* gamma, double* pi, double* Li, int li_cap,
                          int* n_iters, int* warned, double* alpha, double* invL);
 
+/* Wait for the uploads enqueued under VBX_OPT_ASYNC_UPLOAD (vbx_batch_run does the same when it begins).  ABI 7. */
+int vbx_batch_sync_uploads(vbx_batch* batch);
+
+/* Results of MANY recordings with one synchronize per stream: every item is what vbx_batch_get_result takes for recording
+ * `rec` (any pointer may be NULL), n_iters / warned are filled in.  The copies into `gamma`, `alpha`, `invL` are plain DMA when
+ * those point into memory from vbx_host_alloc (pinned), staged and blocking otherwise.  Replaces the per-recording loop a
+ * batched caller of the reference would write around VBx.py:126's return.  ABI 7. */
+typedef struct {
+    int32_t rec;
+    double* gamma;   /* [T][S] or NULL */
+    double* pi;      /* [S] or NULL */
+    double* Li;      /* [li_cap] or NULL */
+    int32_t li_cap;
+    int32_t n_iters; /* out */
+    int32_t warned;  /* out */
+    double* alpha;   /* [S][D] or NULL */
+    double* invL;    /* [S][D] or NULL */
+} vbx_fetch;
+int vbx_batch_get_results(vbx_batch* batch, int n, vbx_fetch* items);
+
+/* Pinned (page-locked) host memory from a process-wide pool: the destination of choice for vbx_batch_get_results and a fast
+ * source for vbx_batch_set_recording.  A freed block goes back to the pool (at most 2 GB are kept).  A failure's message is
+ * vbx_last_error(NULL).  ABI 7. */
+int vbx_host_alloc(size_t bytes, void** out);
+int vbx_host_free(void* p);
+
 /* Wall time of the last vbx_batch_run measured with HIP events on the batch's stream
  * (ms), and the number of iterations that were launched. */
 int vbx_batch_last_run_ms(vbx_batch* batch, double* total_ms, int* iters_launched);
@@ -175,6 +207,10 @@ int vbx_batch_last_run_ms(vbx_batch* batch, double* total_ms, int* iters_launche
 int vbx_batch_kernel_times(vbx_batch* batch, double* ms, int64_t* launches);
 /* Number of HIP streams (sub-batches) this batch runs on: VBX_OPT_STREAMS in effect. */
 int vbx_batch_streams(const vbx_batch* b);
+/* The stream (sub-batch, 0 .. vbx_batch_streams - 1) recording b was dealt to; -1: no such recording.  vbx_batch_set_recording may
+ * be called from different host threads for recordings of DIFFERENT streams (each stream has its own device arena): that is
+ * how a batch call keeps the host link busy.  ABI 7. */
+int vbx_batch_stream_of(const vbx_batch* b, int rec);
 /* VBX_GEMM_EXACT or VBX_GEMM_SPLIT: how the iterations of the last vbx_batch_run multiplied (VBX_OPT_GEMM asks, the
  * batch's precision and kernels decide: fp64 batches, S > 64 and the unfused kernels always answer VBX_GEMM_EXACT -- and so
  * does a batch that holds a recording whose frames span more than 2^10 in magnitude, which one power-of-two scale per

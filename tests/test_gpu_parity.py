@@ -747,6 +747,70 @@ def test_resident_setter_and_clone_owner_in_a_stream_group(ctx):
     xv.close()
 
 
+@pytest.mark.parametrize('precision', ['fp64', 'fp32-split'])
+def test_enqueued_uploads_and_bulk_results_equal_the_call_by_call_path(ctx, precision):
+    """The call boundary of a batch (ABI 7): setters that only enqueue (VBX_OPT_ASYNC_UPLOAD: one synchronize when the run
+    begins instead of one per recording; the initial responsibilities are padded on the device) and vbx_batch_get_results
+    (one call, pinned destination arrays from vbx_host_alloc) give bit for bit what the synchronous setters and one
+    vbx_batch_get_result per recording give -- on one stream, on a stream group, for float32 and float64 inputs, with more
+    speakers than feature dimensions (the staging block cannot hold the responsibilities: host packing as before), with a
+    speaker model handed in, and when a recording is set twice before anything has been waited for."""
+    from vbx_amd import _capi
+    from vbx_amd.synth import make_recording
+    rng = np.random.default_rng(11)
+
+    def recordings(n, D, shapes):
+        out = []
+        for k in range(n):
+            T, S = shapes[k % len(shapes)]
+            X, Phi, _ = make_recording(T, S, D=D, seed=70 + k, kappa=0.05, dtype=np.float32 if k % 2 else np.float64)
+            g = rng.gamma(1.0, size=(T, S)).astype(np.float32 if k % 3 == 0 else np.float64)
+            g /= g.sum(1, keepdims=True)
+            out.append((X, Phi, g, 0.9 + 0.01 * (k % 5)))
+        return out
+
+    def run(recs, D, streams, asynchronous, bulk, model=None):
+        batch = _capi.Batch(ctx, [r[0].shape[0] for r in recs], [r[2].shape[1] for r in recs], D, precision=precision, max_iters=3,
+                            streams=streams)
+        if asynchronous:
+            batch.set_async_upload(True)
+        for j, (X, Phi, g, lp) in enumerate(recs):
+            S = g.shape[1]
+            if asynchronous and j == 1:                          # set twice in a row: the second upload wins
+                batch.set_recording(j, X[::-1].copy(), Phi, np.ones(S) / S, g, lp, 0.3, 17.0)
+            kw = dict(alpha0=model[0], invL0=model[1]) if (model is not None and j == 0) else {}
+            batch.set_recording(j, X, Phi, np.ones(S) / S, g, lp, 0.3, 17.0, **kw)
+        batch.run(3, -np.inf)
+        out = batch.results() if bulk else [batch.result(j) for j in range(len(recs))]
+        if bulk:
+            part = batch.results([len(recs) - 1, 0], want_gamma=False, want_model=False, pinned=False)
+            assert np.array_equal(part[0]['pi'], out[-1]['pi']) and np.array_equal(part[1]['Li'], out[0]['Li'])
+            assert part[0]['gamma'] is None and part[0]['alpha'] is None
+        batch.close()
+        return out
+
+    cases = [(recordings(5, 32, [(700, 6), (300, 3), (1100, 9)]), 32, 1, None),
+             (recordings(26, 64, [(7000, 12), (6500, 20)]), 64, 0, None),          # 26 recordings, 1430 chunks: two or three streams
+             (recordings(3, 16, [(400, 24), (260, 30)]), 16, 1, None)]             # S > D: responsibilities do not fit the staging block
+    X0, Phi0, g0, _ = cases[0][0][0]
+    al = rng.normal(size=(6, 32))
+    il = rng.uniform(0.2, 0.9, size=(6, 32))
+    cases.append((cases[0][0], 32, 1, (al, il)))
+    for recs, D, streams, model in cases:
+        want = run(recs, D, streams, False, False, model)
+        got = run(recs, D, streams, True, True, model)
+        for j, (w, g) in enumerate(zip(want, got)):
+            assert w['n_iters'] == g['n_iters'] == 3 and w['warned'] == g['warned']
+            for key in ('gamma', 'pi', 'Li', 'alpha', 'invL'):
+                assert np.array_equal(w[key], g[key]), (D, streams, j, key)
+    # pinned arrays are ordinary numpy arrays for the caller: writable, sliceable, alive after the batch is gone
+    g = got[0]['gamma']
+    g[0, 0] = 0.5
+    assert g[0, 0] == 0.5 and g[::2].shape[0] == (g.shape[0] + 1) // 2
+    blocks = _capi.pinned_arrays([(3, 4), (5,)])
+    assert blocks[0].shape == (3, 4) and blocks[1].shape == (5,) and blocks[0].ctypes.data % 64 == 0
+
+
 def test_python_sweep_api_equals_one_call_per_point(synth_cases):
     """vbx_amd.batch.VBx_sweep == [VBx(X, Phi, **point) ...]: same tuples, same global-RNG draws in list order."""
     import vbx_amd

@@ -22,7 +22,7 @@ def test_library_builds_and_exports_the_declared_abi():
     path = build.build()
     assert os.path.exists(path)
     lib = _capi.load()
-    assert lib.vbx_abi_version() == 6
+    assert lib.vbx_abi_version() == 7
     syms = declared_symbols()
     assert set(syms) == set(_capi.ABI_SYMBOLS), set(syms) ^ set(_capi.ABI_SYMBOLS)
     exported = subprocess.run(['nm', '-D', '--defined-only', path], capture_output=True, text=True).stdout

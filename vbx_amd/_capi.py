@@ -17,6 +17,7 @@ OPT_FB_ALGO, OPT_CHECK_EVERY, OPT_PROFILE, OPT_CHUNK_FRAMES, OPT_FUSE, OPT_SCAN_
 OPT_TWO_LEVEL_FROM, OPT_STREAMS, OPT_SPLIT_TILES, OPT_SCAN_GROUP2, OPT_THREE_LEVEL_FROM = 8, 10, 11, 12, 13
 OPT_GEMM = 14                # how the fp32 path multiplies: GEMM_EXACT (f32 MFMA) | GEMM_SPLIT (f16 operand pairs, vbx_split.hpp)
 GEMM_EXACT, GEMM_SPLIT = 0, 1
+OPT_ASYNC_UPLOAD = 15        # setters only enqueue; one synchronize when the next run begins (Batch.set_async_upload)
 K_NAMES = ['prep', 'mstep_acc', 'mstep_fin', 'loglik', 'fb', 'fb_aux', 'post', 'iter_fin', 'chunk_loglik',
            'chunk_post']
 MAX_SPEAKERS = 16384
@@ -33,6 +34,7 @@ ABI_SYMBOLS = [
     'vbx_xvectors_project', 'vbx_xvectors_get', 'vbx_xvectors_destroy', 'vbx_cos_similarity_resident',
     'vbx_batch_set_recording_resident', 'vbx_batch_get_labels', 'vbx_batch_set_recording_shared',
     'vbx_batch_gemm_in_effect',
+    'vbx_batch_stream_of', 'vbx_batch_sync_uploads', 'vbx_batch_get_results', 'vbx_host_alloc', 'vbx_host_free',
 ]
 
 
@@ -110,6 +112,11 @@ def load():
     lib.vbx_cos_similarity_resident.argtypes = [vp, vp, i64, i64, C.POINTER(vp)]
     lib.vbx_batch_set_recording_resident.argtypes = [vp, C.c_int, vp, i64, vp, dbl, vp, dbl, dbl, dbl]
     lib.vbx_batch_get_labels.argtypes = [vp, C.c_int, vp, vp]
+    lib.vbx_batch_sync_uploads.argtypes = [vp]
+    lib.vbx_batch_stream_of.argtypes = [vp, C.c_int]
+    lib.vbx_batch_get_results.argtypes = [vp, C.c_int, vp]
+    lib.vbx_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    lib.vbx_host_free.argtypes = [vp]
     lib.vbx_batch_set_recording_shared.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, dbl, dbl, dbl]
     for name in ABI_SYMBOLS:
         fn = getattr(lib, name)          # AttributeError here = the .so does not export the ABI
@@ -119,6 +126,48 @@ def load():
             fn.restype = C.c_int
     _lib = lib
     return lib
+
+
+class Fetch(C.Structure):
+    """vbx_fetch (include/vbx_hip.h): one recording's result pointers for vbx_batch_get_results."""
+    _fields_ = [('rec', C.c_int32), ('gamma', C.c_void_p), ('pi', C.c_void_p), ('Li', C.c_void_p), ('li_cap', C.c_int32),
+                ('n_iters', C.c_int32), ('warned', C.c_int32), ('alpha', C.c_void_p), ('invL', C.c_void_p)]
+
+
+class _PinnedBlock:
+    """A block of pinned host memory from the library's pool (vbx_host_alloc); goes back to the pool with the last array on it."""
+
+    def __init__(self, nbytes):
+        p = C.c_void_p()
+        rc = load().vbx_host_alloc(int(nbytes), C.byref(p))
+        if rc != 0:
+            raise VbxError(f'vbx_host_alloc({nbytes}) failed ({rc}): ' + (load().vbx_last_error(None) or b'').decode())
+        self.ptr, self.nbytes = p.value, int(nbytes)
+
+    def __del__(self):
+        if sys.is_finalizing() or not getattr(self, 'ptr', None):
+            return
+        try:
+            load().vbx_host_free(self.ptr)
+        except Exception:
+            pass
+        self.ptr = None
+
+
+def pinned_arrays(shapes, dtype=np.float64):
+    """float64 arrays of the given shapes on ONE block of pinned host memory (the destination of choice for results: a
+    copy out of HBM into such an array is a plain DMA; into ordinary memory it is staged and three to ten times slower).
+    The block returns to the library's pool when the last of the arrays (or a view of one) is gone."""
+    item = np.dtype(dtype).itemsize
+    sizes = [int(np.prod(s)) * item for s in shapes]
+    offs = np.concatenate([[0], np.cumsum([(n + 63) // 64 * 64 for n in sizes])])
+    block = _PinnedBlock(max(int(offs[-1]), 64))
+    raw = (C.c_char * block.nbytes).from_address(block.ptr)
+    raw._vbx_owner = block                              # np.frombuffer keeps `raw` alive, `raw` keeps the block
+    out = []
+    for s, n, o in zip(shapes, sizes, offs):
+        out.append(np.frombuffer(raw, dtype=dtype, count=n // item, offset=int(o)).reshape(s))
+    return out
 
 
 def _ptr(a):
@@ -365,6 +414,8 @@ class Batch:
         ctx.check(self._lib.vbx_batch_create_streams(ctx._h, self.n, Ta, Sa, self.D, self.precision, self.max_iters,
                                                      int(streams or 0), C.byref(h)), 'vbx_batch_create_streams')
         self._h = h
+        self._held = []                                    # arrays an asynchronous upload still reads (set_async_upload)
+        self._async = False
         def choice(var, value, table):
             if value not in table:
                 raise ValueError(f'{var}={value!r}: expected one of {", ".join(map(repr, table))}')
@@ -409,6 +460,22 @@ class Batch:
     def set_option(self, option: int, value: int):
         self.ctx.check(self._lib.vbx_batch_set_option(self._h, int(option), int(value)), 'vbx_batch_set_option')
 
+    def set_async_upload(self, on=True):
+        """Uploads without a synchronize per recording (VBX_OPT_ASYNC_UPLOAD): set_recording only enqueues; the arrays it was
+        given are kept alive here until the next run() / sync_uploads()."""
+        self.set_option(OPT_ASYNC_UPLOAD, 1 if on else 0)
+        self._async = bool(on)
+        if not on:
+            self._held.clear()
+
+    def stream_of(self, b) -> int:
+        """The stream (sub-batch) recording b was dealt to: recordings of different streams may be set from different threads."""
+        return int(self._lib.vbx_batch_stream_of(self._h, int(b)))
+
+    def sync_uploads(self):
+        self.ctx.check(self._lib.vbx_batch_sync_uploads(self._h), 'vbx_batch_sync_uploads')
+        self._held.clear()
+
     def set_recording(self, b, X, Phi, pi0, gamma0, loopProb, Fa, Fb, alpha0=None, invL0=None):
         X = np.ascontiguousarray(X)
         if X.dtype != np.float32:
@@ -423,6 +490,8 @@ class Batch:
             self._h, int(b), _ptr(X), VBX_F32 if X.dtype == np.float32 else VBX_F64, _ptr(Phi), _ptr(pi0),
             _ptr(gamma0), VBX_F32 if gamma0.dtype == np.float32 else VBX_F64, _ptr(alpha0), _ptr(invL0),
             float(loopProb), float(Fa), float(Fb)), 'vbx_batch_set_recording')
+        if self._async:
+            self._held.append((X, gamma0))
 
     def set_recording_shared(self, b, src, pi0, gamma0, loopProb, Fa, Fb, alpha0=None, invL0=None):
         """Recording b on the x-vectors (rho, Phi) of recording ``src`` of this batch, set before: one point of an
@@ -436,6 +505,8 @@ class Batch:
         self.ctx.check(self._lib.vbx_batch_set_recording_shared(
             self._h, int(b), int(src), _ptr(pi0), _ptr(gamma0), VBX_F32 if gamma0.dtype == np.float32 else VBX_F64,
             _ptr(alpha0), _ptr(invL0), float(loopProb), float(Fa), float(Fb)), 'vbx_batch_set_recording_shared')
+        if self._async:
+            self._held.append((gamma0,))
 
     def set_recording_resident(self, b, xv: 'XVectors', row0, labels, init_smoothing, Phi, loopProb, Fa, Fb):
         """Recording b from resident rows of ``xv.fea`` and the AHC labels: initial responsibilities
@@ -465,7 +536,10 @@ class Batch:
         eps = float(epsilon)
         if not np.isfinite(eps):
             eps = -1e300 if eps < 0 else 1e300
-        self.ctx.check(self._lib.vbx_batch_run(self._h, int(iters), eps), 'vbx_batch_run')
+        try:
+            self.ctx.check(self._lib.vbx_batch_run(self._h, int(iters), eps), 'vbx_batch_run')
+        finally:
+            self._held.clear()                             # (the run begins by waiting for the uploads)
 
     def last_run_ms(self):
         ms, it = C.c_double(), C.c_int()
@@ -503,6 +577,44 @@ class Batch:
         n = min(n_iters.value, self.max_iters)
         return {'gamma': gamma, 'pi': pi, 'Li': Li[:n].copy(), 'n_iters': n_iters.value,
                 'warned': bool(warned.value), 'alpha': alpha, 'invL': invL}
+
+    def results(self, recs=None, want_gamma=True, want_model=True, pinned=True):
+        """``[result(b) for b in recs]`` (default: every recording) with ONE synchronize per stream (vbx_batch_get_results) and,
+        with ``pinned``, the arrays of all recordings on one block of pinned host memory: the responsibilities leave HBM as
+        plain DMA instead of through the runtime's staging buffers (64 recordings of T = 10 000: 25-37 ms -> a few)."""
+        recs = list(range(self.n)) if recs is None else [int(b) for b in recs]
+        # gamma on a pinned block of its own per recording (a caller that keeps one recording's responsibilities keeps that block,
+        # not the batch's); the small arrays of all recordings share one block and are handed out as ordinary copies
+        small, per = [], 4 if want_model else 2
+        for b in recs:
+            S, D = self.S[b], self.D
+            small += [(S,), (max(self.max_iters, 1),)] + ([(S, D), (S, D)] if want_model else [])
+        small = pinned_arrays(small) if pinned else [np.empty(s) for s in small]
+        arrays = []
+        for k, b in enumerate(recs):
+            T, S = self.T[b], self.S[b]
+            g = (pinned_arrays([(T, S)])[0] if pinned else np.empty((T, S))) if want_gamma else None
+            arrays.append([g] + small[per * k: per * k + per])
+        items = (Fetch * len(recs))()
+        for k, b in enumerate(recs):
+            g, p, L = arrays[k][:3]
+            L[:] = 0.0
+            items[k].rec = b
+            items[k].gamma = g.ctypes.data if want_gamma else None
+            items[k].pi = p.ctypes.data
+            items[k].Li = L.ctypes.data
+            items[k].li_cap = len(L)
+            items[k].alpha = arrays[k][3].ctypes.data if want_model else None
+            items[k].invL = arrays[k][4].ctypes.data if want_model else None
+        self.ctx.check(self._lib.vbx_batch_get_results(self._h, len(recs), items), 'vbx_batch_get_results')
+        out = []
+        for k, b in enumerate(recs):
+            g, p, L = arrays[k][:3]
+            n = min(items[k].n_iters, self.max_iters)
+            out.append({'gamma': g, 'pi': p.copy(), 'Li': L[:n].copy(), 'n_iters': int(items[k].n_iters),
+                        'warned': bool(items[k].warned), 'alpha': arrays[k][3].copy() if want_model else None,
+                        'invL': arrays[k][4].copy() if want_model else None})
+        return out
 
     def close(self):
         if getattr(self, '_h', None):

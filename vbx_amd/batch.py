@@ -118,13 +118,30 @@ def run_shard_hip(items, maxIters, epsilon, precision=None, device=None):
         batch = _capi.Batch(ctx, [items[k]['X'].shape[0] for k in idx], [len(items[k]['pi']) for k in idx], D,
                             precision='fp64' if 'fp64' in prec else prec.pop(), max_iters=maxIters)
         try:
+            # uploads are only enqueued (one synchronize when the run begins, not one per recording) and the results of the
+            # whole batch come back in one call into pinned host memory: what a batch call pays around its iterations
+            batch.set_async_upload(True)
+
+            def upload(pairs):
+                for j, k in pairs:
+                    it = items[k]
+                    batch.set_recording(j, it['X'], it['Phi'], it['pi'], it['gamma'], it['loopProb'], it['Fa'],
+                                        it['Fb'], alpha0=it['alpha'], invL0=it['invL'])
+            by_stream = {}
             for j, k in enumerate(idx):
-                it = items[k]
-                batch.set_recording(j, it['X'], it['Phi'], it['pi'], it['gamma'], it['loopProb'], it['Fa'],
-                                    it['Fb'], alpha0=it['alpha'], invL0=it['invL'])
+                by_stream.setdefault(batch.stream_of(j), []).append((j, k))
+            if len(by_stream) > 1:
+                # one host thread per stream of the batch (the library releases the GIL in its calls; every stream has its own
+                # staging block and device arena): the copies of the sub-batches share the host link instead of queueing up
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(max_workers=len(by_stream)) as pool:
+                    for f in [pool.submit(upload, pairs) for pairs in by_stream.values()]:
+                        f.result()
+            else:
+                upload(list(enumerate(idx)))
             batch.run(maxIters, epsilon)
-            for j, k in enumerate(idx):
-                results[k] = batch.result(j)
+            for k, res in zip(idx, batch.results()):
+                results[k] = res
         finally:
             batch.close()
     return results

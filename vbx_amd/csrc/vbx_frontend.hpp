@@ -99,6 +99,54 @@ __global__ __launch_bounds__(256) void unpack_gamma_kernel(const R* __restrict__
     out[idx] = (double)gamma[t * Sp + (idx - t * S)];
 }
 
+// gamma[t][s] = (R)src[t][s] for s < S, 0 for the padded speakers: the caller's initial responsibilities (VBx.py:79-85) padded
+// and converted on the device from the rows as they were uploaded (round 6: the host loop that did this cost a third of an upload)
+template <typename R, typename SRC>
+__global__ __launch_bounds__(256) void pad_gamma_kernel(const SRC* __restrict__ src, R* __restrict__ gamma, long long T, int S, int Sp) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= T * Sp) return;
+    const long long t = idx / Sp;
+    const int s = (int)(idx - t * Sp);
+    gamma[idx] = s < S ? (R)src[t * S + s] : (R)0;
+}
+
+// The small per-recording arguments of the recordings set since the last synchronize, from the batch's pinned host block
+// (per recording {Phi[Dp], sqrt Phi[Dp], pi0[Sp], flags[2]}) to where the kernels read them: one launch instead of two copies
+// per recording.  flags[0] != 0: Phi is in the slot; flags[1] != 0: pi0 is.
+__global__ __launch_bounds__(256) void scatter_args_kernel(const double* __restrict__ h_args, int per, int Dp, int Sp,
+                                                           double* __restrict__ phi, double* __restrict__ pi) {
+    const int rec = blockIdx.x;
+    const double* a = h_args + (long long)rec * per;
+    const bool has_phi = a[2 * Dp + Sp] != 0.0, has_pi = a[2 * Dp + Sp + 1] != 0.0;
+    if (has_phi)
+        for (int d = threadIdx.x; d < Dp; d += 256) phi[(long long)rec * Dp + d] = a[d];
+    if (has_pi)
+        for (int s = threadIdx.x; s < Sp; s += 256) pi[(long long)rec * Sp + s] = a[2 * Dp + s];
+}
+
+// All speaker models of a batch (or the ones flagged) unpadded and widened into ONE block: out[rec][s][d] at rec * S_max * D
+template <typename R>
+__global__ __launch_bounds__(256) void unpack_models_kernel(const R* __restrict__ alpha, const R* __restrict__ invL, const int* __restrict__ copy_of,
+                                                            long long model_stride, double* __restrict__ out_alpha, double* __restrict__ out_invL,
+                                                            int n_rec, int Sp, int D, int Dp) {
+    const int rec = blockIdx.x;
+    const long long base = (long long)copy_of[rec] * model_stride + (long long)rec * Sp * Dp;
+    for (int idx = threadIdx.x; idx < Sp * D; idx += 256) {
+        const int s = idx / D, d = idx - s * D;
+        out_alpha[(long long)rec * Sp * D + idx] = (double)alpha[base + (long long)s * Dp + d];
+        out_invL[(long long)rec * Sp * D + idx] = (double)invL[base + (long long)s * Dp + d];
+    }
+}
+
+// out[s][d] = (double)model[s][d], s < S, d < D: alpha / invL as a caller gets them (VBx.py:126 return_model)
+template <typename R>
+__global__ __launch_bounds__(256) void unpack_model_kernel(const R* __restrict__ model, double* __restrict__ out, int S, int D, int Dp) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= S * D) return;
+    const int s = idx / D;
+    out[idx] = (double)model[(long long)s * Dp + (idx - s * D)];
+}
+
 // Largest and second largest responsibility of every frame; ties go to the lower index (what a stable argsort of -q
 // gives; numpy's default argsort leaves the order of ties unspecified).  second = -1 when S == 1.
 template <typename R>

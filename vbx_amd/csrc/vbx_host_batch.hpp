@@ -74,6 +74,8 @@ static int leaf_destroy(vbx_batch* b) {
                     b->d_rho_a, b->d_rho_b, b->d_alpha_frag, b->d_rho_e, b->d_rho_amax, b->d_alpha_e};
     (void)hipStreamSynchronize(b->ctx->stream);               // nothing of this batch may still be running when its
     for (void* p : ptrs) ctx_free(b->ctx, p);                 // blocks go back to the spare list
+    if (b->d_fetch) ctx_free(b->ctx, b->d_fetch);
+    if (b->h_args) (void)hipHostFree(b->h_args);
     if (b->ev_start) (void)hipEventDestroy(b->ev_start);
     if (b->ev_stop) (void)hipEventDestroy(b->ev_stop);
     for (auto& ep : b->ev_pool) {
@@ -200,6 +202,8 @@ static int leaf_create(vbx_ctx* ctx, int n_rec, const int64_t* T, const int32_t*
     return VBX_OK;
 }
 
+static int sync_uploads(vbx_batch* b);
+
 static int leaf_set_option(vbx_batch* b, int option, int64_t value) {
     if (!b) return VBX_ERR_INVALID;
     switch (option) {
@@ -252,8 +256,69 @@ static int leaf_set_option(vbx_batch* b, int option, int64_t value) {
 #endif
             b->gemm = (int)value;
             return VBX_OK;
+        case VBX_OPT_ASYNC_UPLOAD:
+            if (value != 0 && value != 1) FAIL(b->ctx, VBX_ERR_INVALID, "VBX_OPT_ASYNC_UPLOAD takes 0 or 1");
+            if (!value && b->async_upload)
+                if (int rc = sync_uploads(b); rc != VBX_OK) return rc;
+            b->async_upload = value != 0;
+            return VBX_OK;
         default: FAIL(b->ctx, VBX_ERR_INVALID, "unknown option %d", option);
     }
+}
+
+// Uploads (round 6).  A setter only ENQUEUES: the small per-recording arguments travel through a pinned host block of the
+// batch (so their copies are asynchronous and nothing on the host goes out of scope under them), x-vectors and initial
+// responsibilities are copied as the caller holds them and converted / padded on the device (prep_kernel, pad_gamma_kernel),
+// and sum_t G_t -- the one value that comes BACK from an upload -- stays in d_gtile until sync_uploads fetches it for all
+// recordings at once.  Without VBX_OPT_ASYNC_UPLOAD every setter ends with sync_uploads (the contract of ABI <= 6: the
+// caller's buffers are free when the call returns); with it the synchronize happens once, when the next run begins
+// (vbx_batch_run) or in vbx_batch_sync_uploads, and the caller's X / gamma0 must stay valid until then.
+static int ensure_host_args(vbx_batch* b) {
+    if (b->h_args) return VBX_OK;
+    const size_t per = (size_t)2 * b->Dp + b->Sp + 2;         // {Phi, sqrt Phi, pi0, flags: Phi is here, pi0 is here}
+    HIPCHK(b->ctx, hipHostMalloc((void**)&b->h_args, sizeof(double) * per * b->n_rec, hipHostMallocDefault));
+    std::memset(b->h_args, 0, sizeof(double) * per * b->n_rec);
+    b->gsum_pending.assign(b->n_rec, 0);
+    b->args_busy.assign(b->n_rec, 0);
+    return VBX_OK;
+}
+
+static int sync_uploads(vbx_batch* b) {
+    vbx_ctx* ctx = b->ctx;
+    bool pending = false;
+    for (char c : b->gsum_pending) pending = pending || c;
+    if (!b->uploads_in_flight && !pending) return VBX_OK;
+    if (b->h_args) {                                          // Phi / pi0 of the recordings set since: one launch (scatter_args_kernel)
+        const int per = 2 * b->Dp + b->Sp + 2;
+        hipLaunchKernelGGL(vbx::scatter_args_kernel, dim3(b->n_rec), dim3(256), 0, ctx->stream, (const double*)b->h_args, per, b->Dp, b->Sp,
+                           b->d_phi, b->d_pi);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    std::vector<double> gt;
+    if (pending) {
+        gt.resize(b->ntiles_total);
+        HIPCHK(ctx, hipMemcpyAsync(gt.data(), b->d_gtile, sizeof(double) * gt.size(), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipGetLastError());
+    for (int i = 0; i < b->n_rec && pending; ++i) {
+        if (!b->gsum_pending[i]) continue;
+        const RecDesc& rd = b->recs[i];
+        double gsum = 0.0;
+        for (int tl = 0; tl < rd.ntiles; ++tl) gsum += gt[rd.tile0 + tl];
+        b->recs[i].gsum = gsum;
+        b->gsum_pending[i] = 0;
+    }
+    for (int i = 0; i < b->n_rec; ++i)                        // recordings that read another one's rows: its sum G as well
+        if (b->share_src[i] != i) b->recs[i].gsum = b->recs[b->share_src[i]].gsum;
+    if (b->h_args) {
+        const size_t per = (size_t)2 * b->Dp + b->Sp + 2;
+        for (int i = 0; i < b->n_rec; ++i) b->h_args[(size_t)i * per + per - 2] = b->h_args[(size_t)i * per + per - 1] = 0.0;
+    }
+    std::fill(b->args_busy.begin(), b->args_busy.end(), 0);
+    b->uploads_in_flight = false;
+    b->recs_dirty = true;
+    return VBX_OK;
 }
 
 extern "C++" {
@@ -265,39 +330,69 @@ int set_recording_impl(vbx_batch* b, int rec, const void* X, int x_dtype, const 
     RecDesc& rd = b->recs[rec];
     const int D = b->D, Dp = b->Dp, Sp = b->Sp, S = rd.S;
     const long long T = rd.T;
-    // Phi, sqrt(Phi) (padded dims: 0)
-    std::vector<double> phi(Dp, 0.0), sphi(Dp, 0.0);
-    for (int d = 0; X && d < D; ++d) {
-        if (!(Phi[d] > 0.0)) FAIL(ctx, VBX_ERR_INVALID, "Phi[%d] must be positive", d);
-        phi[d] = Phi[d];
-        sphi[d] = std::sqrt(Phi[d]);
-    }
-    std::vector<double> gt;
+    if (int rc = ensure_host_args(b); rc != VBX_OK) return rc;
+    // (the pinned slot of this recording may still be the source of a copy in flight: the same recording set twice in a row)
+    if (b->args_busy[rec])
+        if (int rc = sync_uploads(b); rc != VBX_OK) return rc;
+    const size_t per = (size_t)2 * Dp + Sp + 2;
+    double* const phi = b->h_args + (size_t)rec * per;
+    double* const sphi = phi + Dp;
+    double* const pip = phi + 2 * Dp;
+    double* const flags = phi + 2 * Dp + Sp;                  // what sync_uploads' scatter_args_kernel takes from this slot
+    bool must_sync = !b->async_upload;
     if (X) {
-        HIPCHK(ctx, hipMemcpyAsync(b->d_phi + (size_t)rec * Dp, phi.data(), sizeof(double) * Dp, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(b->d_sqrt_phi, sphi.data(), sizeof(double) * Dp, hipMemcpyHostToDevice, ctx->stream));
-        // X -> staging -> rho, G
+        for (int d = 0; d < Dp; ++d) phi[d] = sphi[d] = 0.0;     // (padded dims: 0)
+        for (int d = 0; d < D; ++d) {
+            if (!(Phi[d] > 0.0)) FAIL(ctx, VBX_ERR_INVALID, "Phi[%d] must be positive", d);
+            phi[d] = Phi[d];
+            sphi[d] = std::sqrt(Phi[d]);
+        }
+        flags[0] = 1.0;                                       // (Phi goes to the device with the scatter of sync_uploads)
+        // X -> staging -> rho, G; prep_kernel reads sqrt(Phi) from the pinned slot itself
         const size_t xbytes = (size_t)T * D * (x_dtype == VBX_F64 ? 8 : 4);
         HIPCHK(ctx, hipMemcpyAsync(b->d_xstage, X, xbytes, hipMemcpyHostToDevice, ctx->stream));
-        if (x_dtype == VBX_F64) launch_prep<R, double>(b, rd); else launch_prep<R, float>(b, rd);
+        if (x_dtype == VBX_F64) launch_prep<R, double>(b, rd, sphi); else launch_prep<R, float>(b, rd, sphi);
         HIPCHK(ctx, hipGetLastError());
-        gt.resize(rd.ntiles);
-        HIPCHK(ctx, hipMemcpyAsync(gt.data(), b->d_gtile + rd.tile0, sizeof(double) * rd.ntiles, hipMemcpyDeviceToHost, ctx->stream));
+        b->gsum_pending[rec] = 1;
     } else {
         // shared rho: Phi (and with it sum_t G_t) of the recording this one shares its x-vectors with
         // (src == rec: a clone from another stream group's arena, leaf_set_recording_cloned has put Phi, rho and sum G in place)
         const int src = b->share_src[rec];
-        if (src != rec)
-            HIPCHK(ctx, hipMemcpyAsync(b->d_phi + (size_t)rec * Dp, b->d_phi + (size_t)src * Dp, sizeof(double) * Dp, hipMemcpyDeviceToDevice, ctx->stream));
+        flags[0] = 0.0;
+        if (src != rec) {
+            const double* sphi_src = b->h_args + (size_t)src * per;
+            if (sphi_src[per - 2] != 0.0) {                   // (the source's Phi is itself still on its way: take it from its slot)
+                std::memcpy(phi, sphi_src, sizeof(double) * 2 * Dp);
+                flags[0] = 1.0;
+            } else {
+                HIPCHK(ctx, hipMemcpyAsync(b->d_phi + (size_t)rec * Dp, b->d_phi + (size_t)src * Dp, sizeof(double) * Dp, hipMemcpyDeviceToDevice, ctx->stream));
+            }
+        }
+        if (src != rec) rd.gsum = b->recs[src].gsum;              // (if the source's is still on its way: sync_uploads copies it again)
+        b->gsum_pending[rec] = 0;
     }
-    // gamma0, pi0 (padded speakers: 0)
+    // gamma0 (padded speakers: 0): the rows as the caller holds them -> staging (free again: prep_kernel is ahead in the
+    // stream) -> padded and converted on the device
     std::vector<R> gp;
-    if (g_dtype == VBX_F64) pack_matrix<R, double>(gp, (const double*)gamma0, T, S, Sp, (R)0);
-    else pack_matrix<R, float>(gp, (const float*)gamma0, T, S, Sp, (R)0);
-    HIPCHK(ctx, hipMemcpyAsync((R*)b->d_gamma + rd.row0 * Sp, gp.data(), sizeof(R) * gp.size(), hipMemcpyHostToDevice, ctx->stream));
-    std::vector<double> pip(Sp, 0.0);
-    for (int s = 0; s < S; ++s) pip[s] = pi0[s];
-    HIPCHK(ctx, hipMemcpyAsync(b->d_pi + (size_t)rec * Sp, pip.data(), sizeof(double) * Sp, hipMemcpyHostToDevice, ctx->stream));
+    const size_t gbytes = (size_t)T * S * (g_dtype == VBX_F64 ? 8 : 4);
+    if (gbytes <= b->xstage_bytes) {
+        HIPCHK(ctx, hipMemcpyAsync(b->d_xstage, gamma0, gbytes, hipMemcpyHostToDevice, ctx->stream));
+        const unsigned blocks = (unsigned)(((size_t)T * Sp + 255) / 256);
+        if (g_dtype == VBX_F64)
+            hipLaunchKernelGGL((vbx::pad_gamma_kernel<R, double>), dim3(blocks), dim3(256), 0, ctx->stream, (const double*)b->d_xstage,
+                               (R*)b->d_gamma + rd.row0 * Sp, T, S, Sp);
+        else
+            hipLaunchKernelGGL((vbx::pad_gamma_kernel<R, float>), dim3(blocks), dim3(256), 0, ctx->stream, (const float*)b->d_xstage,
+                               (R*)b->d_gamma + rd.row0 * Sp, T, S, Sp);
+        HIPCHK(ctx, hipGetLastError());
+    } else {                                                   // (more speakers than feature dims: the staging block is too small)
+        if (g_dtype == VBX_F64) pack_matrix<R, double>(gp, (const double*)gamma0, T, S, Sp, (R)0);
+        else pack_matrix<R, float>(gp, (const float*)gamma0, T, S, Sp, (R)0);
+        HIPCHK(ctx, hipMemcpyAsync((R*)b->d_gamma + rd.row0 * Sp, gp.data(), sizeof(R) * gp.size(), hipMemcpyHostToDevice, ctx->stream));
+        must_sync = true;
+    }
+    for (int s = 0; s < Sp; ++s) pip[s] = s < S ? pi0[s] : 0.0;
+    flags[1] = 1.0;
     std::vector<R> ap, ip;
     rd.has_model = (alpha0 && invL0) ? 1 : 0;
     if (rd.has_model) {
@@ -310,20 +405,17 @@ int set_recording_impl(vbx_batch* b, int rec, const void* X, int x_dtype, const 
             }
         HIPCHK(ctx, hipMemcpyAsync((R*)b->d_alpha + (size_t)rec * Sp * Dp, ap.data(), sizeof(R) * ap.size(), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync((R*)b->d_invL + (size_t)rec * Sp * Dp, ip.data(), sizeof(R) * ip.size(), hipMemcpyHostToDevice, ctx->stream));
+        must_sync = true;
     }
-    RecState st;
-    std::memset(&st, 0, sizeof st);
-    HIPCHK(ctx, hipMemcpyAsync(b->d_state + rec, &st, sizeof st, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(b->d_state + b->n_rec + rec, &st, sizeof st, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(b->d_tile_done + rd.tile0, 0, sizeof(int) * rd.ntiles, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // host vectors go out of scope below
-    if (X) {
-        double gsum = 0.0;
-        for (double g : gt) gsum += g;
-        rd.gsum = gsum;
-    } else if (b->share_src[rec] != rec) {
-        rd.gsum = b->recs[b->share_src[rec]].gsum;
+    if (b->has_run) {                                         // (a fresh batch: leaf_create has zeroed the states and the flags)
+        HIPCHK(ctx, hipMemsetAsync(b->d_state + rec, 0, sizeof(RecState), ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(b->d_state + b->n_rec + rec, 0, sizeof(RecState), ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(b->d_tile_done + rd.tile0, 0, sizeof(int) * rd.ntiles, ctx->stream));
     }
+    b->args_busy[rec] = 1;
+    b->uploads_in_flight = true;
+    b->mirrors_valid = false;
+    if (must_sync) return sync_uploads(b);                     // (host vectors go out of scope below)
     return VBX_OK;
 }
 }  // namespace
@@ -377,6 +469,12 @@ int set_recording_resident_impl(vbx_batch* b, int rec, const double* d_fea, cons
     double gsum = 0.0;
     for (double g : gt) gsum += g;
     rd.gsum = gsum;
+    if (!b->gsum_pending.empty()) b->gsum_pending[rec] = 0;
+    if (b->h_args) {                                          // (nothing of an earlier upload of this recording may follow)
+        const size_t per = (size_t)2 * Dp + Sp + 2;
+        b->h_args[(size_t)rec * per + per - 2] = b->h_args[(size_t)rec * per + per - 1] = 0.0;
+    }
+    b->mirrors_valid = false;
     return VBX_OK;
 }
 
@@ -553,13 +651,17 @@ static int leaf_set_recording_cloned(vbx_batch* b, int rec, vbx_batch* from, int
     if (!(loopProb >= 0.0 && loopProb <= 1.0)) FAIL(ctx, VBX_ERR_INVALID, "loopProb=%g outside [0,1]", loopProb);
     if (!(Fa > 0.0) || !(Fb > 0.0)) FAIL(ctx, VBX_ERR_INVALID, "Fa and Fb must be positive");
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    // the source lives on another stream: its rows (and its sum G) must be complete before they are copied from
+    if (int rc = sync_uploads(from); rc != VBX_OK) {
+        ctx->err = from->ctx->err;
+        return rc;
+    }
     const RecDesc& sd = from->recs[from->share_src[src]];     // the rows `src` reads
     RecDesc& rd = b->recs[rec];
     rd.lp = loopProb;
     rd.Fa = Fa;
     rd.Fb = Fb;
     own_rho(b, rec);
-    // (the source's rows are complete: every set_recording ends with a synchronize of its stream)
     HIPCHK(ctx, hipMemcpyAsync((char*)b->d_rho + (size_t)rd.row0 * b->Dp * b->rsize, (const char*)from->d_rho + (size_t)sd.row0 * b->Dp * b->rsize,
                                (size_t)rd.T * b->Dp * b->rsize, hipMemcpyDeviceToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(b->d_phi + (size_t)rec * b->Dp, from->d_phi + (size_t)src * b->Dp, sizeof(double) * b->Dp, hipMemcpyDeviceToDevice, ctx->stream));
@@ -640,6 +742,9 @@ static int run_begin(vbx_batch* b, int max_iters) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc = choose_fb_algo(b, false);
     if (rc != VBX_OK) return rc;
+    if ((rc = sync_uploads(b)) != VBX_OK) return rc;          // (uploads enqueued with VBX_OPT_ASYNC_UPLOAD: sum G of every recording)
+    b->mirrors_valid = false;
+    b->has_run = true;
     rc = upload_recs(b);
     if (rc != VBX_OK) return rc;
     std::fill(b->k_ms, b->k_ms + VBX_K_COUNT, 0.0);
@@ -728,73 +833,141 @@ static int leaf_run(vbx_batch* b, int max_iters, double epsilon) {
     return run_end(b);
 }
 
+// Results (round 6).  The small ones -- state, priors, ELBO history of EVERY recording -- are fetched once after a run into host
+// mirrors (three copies per run instead of four round trips per recording); the responsibilities and the speaker models are
+// unpadded and widened on the device and copied straight into the caller's arrays.  fetch_enqueue only enqueues (its copies
+// are asynchronous when the destination is pinned memory: vbx_host_alloc), fetch_finish waits: vbx_batch_get_result is one
+// of each, vbx_batch_get_results enqueues a whole list before it waits once per stream.
+static int fetch_mirrors(vbx_batch* b) {
+    if (b->mirrors_valid) return VBX_OK;
+    vbx_ctx* ctx = b->ctx;
+    if (int rc = sync_uploads(b); rc != VBX_OK) return rc;   // (results asked for before any run: the priors are still on their way)
+    b->model_mirrors_valid = false;
+    b->h_state.resize(b->n_rec);
+    b->h_pi.resize((size_t)b->n_rec * b->Sp);
+    b->h_Li.resize((size_t)b->n_rec * std::max(b->max_iters, 1));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(b->h_state.data(), b->d_state + (size_t)b->state_cur * b->n_rec, sizeof(RecState) * b->n_rec, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(b->h_pi.data(), b->d_pi, sizeof(double) * b->h_pi.size(), hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(b->h_Li.data(), b->d_Li, sizeof(double) * b->h_Li.size(), hipMemcpyDeviceToHost));
+    b->mirrors_valid = true;
+    return VBX_OK;
+}
+
+// alpha / invL of every recording, unpadded and widened on the device, in two copies (instead of two launches and two copies per
+// recording): only when a caller asks for a model
+extern "C++" {
+namespace {
+template <typename R> int fetch_model_mirrors(vbx_batch* b) {
+    if (b->model_mirrors_valid) return VBX_OK;
+    vbx_ctx* ctx = b->ctx;
+    const size_t cells = (size_t)b->n_rec * b->Sp * b->D;
+    std::vector<int> copy_of(b->n_rec);
+    // the model of the last iteration that ran, n_iters - 1, lives in copy (n_iters - 1) & 1 (fin_kernel); before any
+    // iteration: copy 0, where a caller's alpha / invL went
+    for (int i = 0; i < b->n_rec; ++i) copy_of[i] = b->h_state[i].n_iters > 0 ? ((b->h_state[i].n_iters - 1) & 1) : 0;
+    int* d_copy = nullptr;
+    double* d_out = nullptr;
+    int rc = dmalloc(ctx, &d_copy, (size_t)b->n_rec);
+    if (rc == VBX_OK) rc = dmalloc(ctx, &d_out, 2 * cells);
+    if (rc != VBX_OK) {
+        ctx_free(ctx, d_copy);
+        return rc;
+    }
+    b->h_alpha.resize(cells);
+    b->h_invL.resize(cells);
+    hipError_t e = hipMemcpyAsync(d_copy, copy_of.data(), sizeof(int) * b->n_rec, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL((vbx::unpack_models_kernel<R>), dim3(b->n_rec), dim3(256), 0, ctx->stream, (const R*)b->d_alpha, (const R*)b->d_invL,
+                           (const int*)d_copy, (long long)b->n_rec * b->Sp * b->Dp, d_out, d_out + cells, b->n_rec, b->Sp, b->D, b->Dp);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(b->h_alpha.data(), d_out, sizeof(double) * cells, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(b->h_invL.data(), d_out + cells, sizeof(double) * cells, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    ctx_free(ctx, d_copy);
+    ctx_free(ctx, d_out);
+    if (e != hipSuccess) FAIL(ctx, VBX_ERR_HIP, "fetching the speaker models failed: %s", hipGetErrorString(e));
+    b->model_mirrors_valid = true;
+    return VBX_OK;
+}
+}  // namespace
+}  // extern "C++"
+
 extern "C++" {
 namespace {
 template <typename R>
-int get_result_impl(vbx_batch* b, int rec, double* gamma, double* pi, double* Li, int li_cap, int* n_iters,
-                    int* warned, double* alpha, double* invL) {
+int fetch_enqueue_impl(vbx_batch* b, int rec, double* gamma, double* pi, double* Li, int li_cap, int* n_iters,
+                       int* warned, double* alpha, double* invL) {
     vbx_ctx* ctx = b->ctx;
     const RecDesc& rd = b->recs[rec];
     const int Sp = b->Sp, Dp = b->Dp, S = rd.S, D = b->D;
-    RecState st;
-    HIPCHK(ctx, hipMemcpy(&st, b->d_state + (size_t)b->state_cur * b->n_rec + rec, sizeof st, hipMemcpyDeviceToHost));
+    if (int rc = fetch_mirrors(b); rc != VBX_OK) return rc;
+    const RecState& st = b->h_state[rec];
     if (n_iters) *n_iters = st.n_iters;
     if (warned) *warned = st.warned;
-    if (gamma) {
-        // unpadded and widened on the device, one copy into the caller's array (round 5: a padded copy into a host vector and
-        // a scalar loop over it were 0.64 ms per recording of T = 10 000 -- 41 ms of an 84 ms call for BASELINE config 4)
-        const size_t cells = (size_t)rd.T * S;
-        // (the upload staging block of the batch is free between uploads and large enough whenever D >= S: no allocation)
-        const bool own = b->xstage_bytes < sizeof(double) * cells;
-        double* d_out = own ? nullptr : (double*)b->d_xstage;
-        if (own) {
-            int rc = dmalloc(ctx, &d_out, cells);
-            if (rc != VBX_OK) return rc;
-        }
-        hipLaunchKernelGGL((vbx::unpack_gamma_kernel<R>), dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream,
-                           (const R*)b->d_gamma + rd.row0 * Sp, d_out, (long long)rd.T, S, Sp);
-        hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(gamma, d_out, sizeof(double) * cells, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (own) ctx_free(ctx, d_out);
-        if (e != hipSuccess) FAIL(ctx, VBX_ERR_HIP, "fetching the responsibilities failed: %s", hipGetErrorString(e));
-    }
-    if (pi) {
-        std::vector<double> p(Sp);
-        HIPCHK(ctx, hipMemcpy(p.data(), b->d_pi + (size_t)rec * Sp, sizeof(double) * Sp, hipMemcpyDeviceToHost));
-        for (int s = 0; s < S; ++s) pi[s] = p[s];
-    }
+    if (pi)
+        for (int s = 0; s < S; ++s) pi[s] = b->h_pi[(size_t)rec * Sp + s];
     if (Li && li_cap > 0) {
         const int n = std::min(std::min(st.n_iters, li_cap), b->max_iters);
-        if (n > 0) HIPCHK(ctx, hipMemcpy(Li, b->d_Li + (size_t)rec * b->max_iters, sizeof(double) * n, hipMemcpyDeviceToHost));
+        for (int k = 0; k < n; ++k) Li[k] = b->h_Li[(size_t)rec * b->max_iters + k];
+    }
+    // device staging for what is unpacked: the upload staging block of the batch is free between uploads; its three users
+    // below follow each other in the stream, so one block serves them all (a copy out of it is ahead of the next kernel into it)
+    const size_t cells = (size_t)rd.T * S;
+    const size_t need = sizeof(double) * (gamma ? cells : 0);
+    double* d_out = (double*)b->d_xstage;
+    if (need > b->xstage_bytes) {
+        // (more speakers than feature dimensions: a block of its own, kept for the rest of the batch's life)
+        if (b->fetch_bytes < need) {
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            if (b->d_fetch) ctx_free(ctx, b->d_fetch);
+            b->d_fetch = nullptr;
+            b->fetch_bytes = 0;
+            int rc = dmalloc_bytes(ctx, &b->d_fetch, need);
+            if (rc != VBX_OK) return rc;
+            b->fetch_bytes = need;
+        }
+        d_out = (double*)b->d_fetch;
+    }
+    if (gamma) {
+        hipLaunchKernelGGL((vbx::unpack_gamma_kernel<R>), dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const R*)b->d_gamma + rd.row0 * Sp, d_out, (long long)rd.T, S, Sp);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(gamma, d_out, sizeof(double) * cells, hipMemcpyDeviceToHost, ctx->stream));
     }
     if (alpha || invL) {
-        // the model of the last iteration that ran, n_iters - 1, lives in copy (n_iters - 1) & 1 (fin_kernel); before any
-        // iteration: copy 0, where a caller's alpha / invL went
-        const size_t copy = st.n_iters > 0 ? (size_t)((st.n_iters - 1) & 1) * b->n_rec * Sp * Dp : 0;
-        std::vector<R> a((size_t)Sp * Dp), il((size_t)Sp * Dp);
-        HIPCHK(ctx, hipMemcpy(a.data(), (R*)b->d_alpha + copy + (size_t)rec * Sp * Dp, sizeof(R) * a.size(), hipMemcpyDeviceToHost));
-        HIPCHK(ctx, hipMemcpy(il.data(), (R*)b->d_invL + copy + (size_t)rec * Sp * Dp, sizeof(R) * il.size(), hipMemcpyDeviceToHost));
-        for (int s = 0; s < S; ++s)
-            for (int d = 0; d < D; ++d) {
-                if (alpha) alpha[(size_t)s * D + d] = (double)a[(size_t)s * Dp + d];
-                if (invL) invL[(size_t)s * D + d] = (double)il[(size_t)s * Dp + d];
-            }
+        if (int rc = fetch_model_mirrors<R>(b); rc != VBX_OK) return rc;
+        for (int sp = 0; sp < S; ++sp) {
+            const size_t src = ((size_t)rec * Sp + sp) * D, dst = (size_t)sp * D;
+            if (alpha) std::memcpy(alpha + dst, b->h_alpha.data() + src, sizeof(double) * D);
+            if (invL) std::memcpy(invL + dst, b->h_invL.data() + src, sizeof(double) * D);
+        }
     }
     return VBX_OK;
 }
 }  // namespace
 }  // extern "C++"
 
-static int leaf_get_result(vbx_batch* b, int rec, double* gamma, double* pi, double* Li, int li_cap, int* n_iters,
-                         int* warned, double* alpha, double* invL) {
+static int leaf_fetch_enqueue(vbx_batch* b, int rec, double* gamma, double* pi, double* Li, int li_cap, int* n_iters,
+                              int* warned, double* alpha, double* invL) {
     if (!b) return VBX_ERR_INVALID;
     if (rec < 0 || rec >= b->n_rec) FAIL(b->ctx, VBX_ERR_INVALID, "recording index %d out of range", rec);
     HIPCHK(b->ctx, hipSetDevice(b->ctx->device));
-    HIPCHK(b->ctx, hipStreamSynchronize(b->ctx->stream));
     return b->precision == VBX_PREC_FP64
-               ? get_result_impl<double>(b, rec, gamma, pi, Li, li_cap, n_iters, warned, alpha, invL)
-               : get_result_impl<float>(b, rec, gamma, pi, Li, li_cap, n_iters, warned, alpha, invL);
+               ? fetch_enqueue_impl<double>(b, rec, gamma, pi, Li, li_cap, n_iters, warned, alpha, invL)
+               : fetch_enqueue_impl<float>(b, rec, gamma, pi, Li, li_cap, n_iters, warned, alpha, invL);
+}
+
+static int leaf_fetch_finish(vbx_batch* b) {
+    HIPCHK(b->ctx, hipStreamSynchronize(b->ctx->stream));
+    return VBX_OK;
+}
+
+static int leaf_get_result(vbx_batch* b, int rec, double* gamma, double* pi, double* Li, int li_cap, int* n_iters,
+                         int* warned, double* alpha, double* invL) {
+    const int rc = leaf_fetch_enqueue(b, rec, gamma, pi, Li, li_cap, n_iters, warned, alpha, invL);
+    return rc != VBX_OK ? rc : leaf_fetch_finish(b);
 }
 
 static int leaf_last_run_ms(vbx_batch* b, double* total_ms, int* iters_launched) {

@@ -96,13 +96,16 @@ static int group_build(vbx_batch* b, int K) {
     b->root_of.resize(n);
     for (int i = 0; i < n; ++i) b->root_of[i] = i;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    // the sub-batches take spare blocks of the parent ctx onto OTHER streams: whatever was queued on a block when it was put
+    // back (the lists promise ordering on the ctx's own stream only) must have finished
+    HIPCHK(ctx, hipDeviceSynchronize());
     for (int k = 0; k < K; ++k) {
         std::sort(members[k].begin(), members[k].end());
         vbx_ctx* kc = new vbx_ctx();                // the parent's device and stream, block lists of its own
         kc->device = ctx->device;
         kc->stream = ctx->stream;
         kc->prop = ctx->prop;
-        kc->recycle = false;
+        kc->pool = ctx;                             // blocks come from and go back to the parent's lists
         if (k > 0) {
             kc->stream = nullptr;
             for (auto& gs : ctx->group_streams)
@@ -238,9 +241,14 @@ int vbx_batch_set_recording(vbx_batch* b, int rec, const void* X, int x_dtype, c
     if (b->kids.empty())
         return leaf_set_recording(b, rec, X, x_dtype, Phi, pi0, gamma0, g_dtype, alpha0, invL0, loopProb, Fa, Fb);
     if (rec < 0 || rec >= b->n_rec) FAIL(b->ctx, VBX_ERR_INVALID, "recording index %d out of range", rec);
-    b->any_set = true;
     const int k = b->kid_of[rec];
-    group_new_rows(b, rec, true);
+    {
+        // (recordings of DIFFERENT sub-batches may be set from different host threads -- each has its own stream and arena, and
+        //  a batch call uploads three times as fast that way, vbx_amd/batch.py -- so the bookkeeping they share is guarded)
+        std::lock_guard<std::mutex> lock(b->group_mutex);
+        b->any_set = true;
+        group_new_rows(b, rec, true);
+    }
     return kid_fail(b, k, leaf_set_recording(b->kids[k], b->local_of[rec], X, x_dtype, Phi, pi0, gamma0, g_dtype, alpha0,
                                              invL0, loopProb, Fa, Fb));
 }
@@ -322,6 +330,96 @@ int vbx_batch_get_result(vbx_batch* b, int rec, double* gamma, double* pi, doubl
     return kid_fail(b, k, leaf_get_result(b->kids[k], b->local_of[rec], gamma, pi, Li, li_cap, n_iters, warned, alpha, invL));
 }
 
+int vbx_batch_sync_uploads(vbx_batch* b) {
+    if (!b) return VBX_ERR_INVALID;
+    if (b->kids.empty()) return sync_uploads(b);
+    for (size_t k = 0; k < b->kids.size(); ++k) {
+        const int rc = kid_fail(b, (int)k, sync_uploads(b->kids[k]));
+        if (rc != VBX_OK) return rc;
+    }
+    return VBX_OK;
+}
+
+int vbx_batch_get_results(vbx_batch* b, int n, vbx_fetch* items) {
+    if (!b) return VBX_ERR_INVALID;
+    if (n < 0 || (n > 0 && !items)) FAIL(b->ctx, VBX_ERR_INVALID, "vbx_batch_get_results: bad argument");
+    const bool group = !b->kids.empty();
+    std::vector<char> touched(group ? b->kids.size() : 1, 0);
+    int rc = VBX_OK;
+    for (int i = 0; i < n && rc == VBX_OK; ++i) {
+        vbx_fetch& f = items[i];
+        if (f.rec < 0 || f.rec >= b->n_rec) FAIL(b->ctx, VBX_ERR_INVALID, "recording index %d out of range", f.rec);
+        const int k = group ? b->kid_of[f.rec] : 0;
+        vbx_batch* leaf = group ? b->kids[k] : b;
+        rc = leaf_fetch_enqueue(leaf, group ? b->local_of[f.rec] : f.rec, f.gamma, f.pi, f.Li, f.li_cap, &f.n_iters, &f.warned, f.alpha, f.invL);
+        if (group) rc = kid_fail(b, k, rc);
+        touched[k] = 1;
+    }
+    for (size_t k = 0; k < touched.size(); ++k) {              // (also after a failure: nothing may be in flight into the
+        if (!touched[k]) continue;                             //  caller's arrays when this returns)
+        const int rf = group ? kid_fail(b, (int)k, leaf_fetch_finish(b->kids[k])) : leaf_fetch_finish(b);
+        if (rc == VBX_OK) rc = rf;
+    }
+    return rc;
+}
+
+// Pinned host memory for results (and inputs): a copy into or out of such a block is a plain DMA at the link's rate and is
+// asynchronous -- a copy into pageable memory goes through the runtime's staging buffers at a fraction of it and blocks.
+// Process-wide pool (a block may outlive the ctx it was first used with: the Python wrapper frees it from a finaliser).
+namespace {
+struct HostPool {
+    std::mutex m;
+    std::vector<std::pair<void*, size_t>> spare;
+    std::unordered_map<void*, size_t> live;
+    size_t spare_bytes = 0;
+};
+HostPool& host_pool() { static HostPool* p = new HostPool(); return *p; }     // (never destroyed: finalisers may run at exit)
+}  // namespace
+
+int vbx_host_alloc(size_t bytes, void** out) {
+    if (!out) return VBX_ERR_INVALID;
+    *out = nullptr;
+    bytes = std::max<size_t>(bytes, 64);
+    HostPool& hp = host_pool();
+    std::lock_guard<std::mutex> lock(hp.m);
+    int best = -1;
+    for (int i = 0; i < (int)hp.spare.size(); ++i)
+        if (hp.spare[i].second >= bytes && hp.spare[i].second <= 2 * bytes + 4096 && (best < 0 || hp.spare[i].second < hp.spare[best].second)) best = i;
+    if (best >= 0) {
+        *out = hp.spare[best].first;
+        hp.live[*out] = hp.spare[best].second;
+        hp.spare_bytes -= hp.spare[best].second;
+        hp.spare.erase(hp.spare.begin() + best);
+        return VBX_OK;
+    }
+    void* p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocPortable);
+    if (e != hipSuccess) {
+        g_create_error = std::string("vbx_host_alloc: hipHostMalloc failed: ") + hipGetErrorString(e);
+        return VBX_ERR_HIP;
+    }
+    hp.live[p] = bytes;
+    *out = p;
+    return VBX_OK;
+}
+
+int vbx_host_free(void* p) {
+    if (!p) return VBX_OK;
+    HostPool& hp = host_pool();
+    std::lock_guard<std::mutex> lock(hp.m);
+    auto it = hp.live.find(p);
+    if (it == hp.live.end()) return VBX_ERR_INVALID;
+    const size_t bytes = it->second;
+    hp.live.erase(it);
+    if (hp.spare_bytes + bytes > ((size_t)2 << 30) || hp.spare.size() >= 512) {
+        (void)hipHostFree(p);
+        return VBX_OK;
+    }
+    hp.spare.emplace_back(p, bytes);
+    hp.spare_bytes += bytes;
+    return VBX_OK;
+}
+
 int vbx_batch_set_recording_resident(vbx_batch* b, int rec, const vbx_xvectors* xv, int64_t row0, const int32_t* labels,
                                      double init_smoothing, const double* Phi, double loopProb, double Fa, double Fb) {
     if (!b) return VBX_ERR_INVALID;
@@ -345,6 +443,11 @@ int vbx_batch_get_labels(vbx_batch* b, int rec, int32_t* first, int32_t* second)
 int vbx_batch_last_run_ms(vbx_batch* b, double* total_ms, int* iters_launched) { return leaf_last_run_ms(b, total_ms, iters_launched); }
 
 int vbx_batch_streams(const vbx_batch* b) { return !b ? 0 : b->kids.empty() ? 1 : (int)b->kids.size(); }
+
+int vbx_batch_stream_of(const vbx_batch* b, int rec) {
+    if (!b || rec < 0 || rec >= b->n_rec) return -1;
+    return b->kids.empty() ? 0 : b->kid_of[rec];
+}
 
 int vbx_batch_gemm_in_effect(const vbx_batch* b) {
     if (!b) return VBX_GEMM_EXACT;

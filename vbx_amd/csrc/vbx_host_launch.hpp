@@ -294,11 +294,11 @@ template <typename R> void launch_iteration(vbx_batch* b, double eps) {
 }
 
 template <typename R, typename XT>
-void launch_prep(vbx_batch* b, const RecDesc& rd) {
+void launch_prep(vbx_batch* b, const RecDesc& rd, const double* sqrt_phi) {
     LaunchScope ls(b, VBX_K_PREP);
     R* rho = (R*)b->d_rho + rd.row0 * b->Dp;
     hipLaunchKernelGGL((prep_kernel<R, XT>), dim3(rd.ntiles), dim3(256), 0, b->ctx->stream,
-                       (const XT*)b->d_xstage, (const double*)b->d_sqrt_phi, rho, b->d_gtile + rd.tile0, rd.T,
+                       (const XT*)b->d_xstage, sqrt_phi, rho, b->d_gtile + rd.tile0, rd.T,
                        b->D, b->Dp);
 }
 
@@ -317,7 +317,8 @@ int ctx_alloc(vbx_ctx* ctx, void** p, size_t bytes) {
 }
 
 // A block of at least `bytes` bytes: the smallest spare one that fits (and is at most twice too large), else a new one.
-static int ctx_alloc_raw(vbx_ctx* ctx, void** p, size_t bytes) {
+static int ctx_alloc_raw(vbx_ctx* user, void** p, size_t bytes) {
+    vbx_ctx* ctx = user->pool ? user->pool : user;
     std::lock_guard<std::mutex> lock(ctx->alloc_mutex);
     bytes = std::max<size_t>(bytes, 16);
     if (ctx->recycle) {
@@ -334,20 +335,22 @@ static int ctx_alloc_raw(vbx_ctx* ctx, void** p, size_t bytes) {
             return VBX_OK;
         }
     }
-    HIPCHK(ctx, hipMalloc(p, bytes));
+    HIPCHK(user, hipMalloc(p, bytes));
     ctx->live[*p] = bytes;
     return VBX_OK;
 }
 
 // Back to the spare list.  Work queued on the ctx stream that still touches the block stays ordered before its next
-// use (every user of the list runs on that stream or has waited for it); beyond 4 GB / 256 spares the block is freed.
-void ctx_free(vbx_ctx* ctx, void* p) {
+// use (every user of the list runs on that stream or has waited for it); beyond 16 GB / 1024 spares the block is freed
+// (a batch of 64 recordings on three streams is 1.5 GB in 170 blocks).
+void ctx_free(vbx_ctx* user, void* p) {
     if (!p) return;
+    vbx_ctx* ctx = user->pool ? user->pool : user;
     std::lock_guard<std::mutex> lock(ctx->alloc_mutex);
     auto it = ctx->live.find(p);
     const size_t bytes = it == ctx->live.end() ? 0 : it->second;
     if (it != ctx->live.end()) ctx->live.erase(it);
-    if (!ctx->recycle || bytes == 0 || ctx->spare_bytes + bytes > ((size_t)4 << 30) || ctx->spare.size() >= 256) {
+    if (!ctx->recycle || bytes == 0 || ctx->spare_bytes + bytes > ((size_t)16 << 30) || ctx->spare.size() >= 1024) {
         (void)hipFree(p);
         return;
     }

@@ -39,7 +39,10 @@ struct vbx_ctx {
     // group ended up on the same queue (measured: 204 k -> 183 k recording-iterations/s for the second batch of a
     // process).
     std::vector<std::pair<hipStream_t, bool>> group_streams;   // (stream, in use)
-    bool recycle = true;                                       // false for the private ctx of a stream-group kid
+    bool recycle = true;
+    vbx_ctx* pool = nullptr;                                   // the private ctx of a stream-group kid: the ctx whose block lists it
+                                                               // allocates from and frees into (round 6: a kid's blocks used to be
+                                                               // hipFree'd one by one when its batch closed -- 8 ms per batch of 64)
     std::mutex alloc_mutex;                                    // the block lists: a scores object may be closed by whichever
 };                                                             // thread the interpreter's garbage collector runs on
 
@@ -96,6 +99,22 @@ struct vbx_batch {
     int streams = 0;                              // option: 0 auto, >= 1 explicit
     struct GroupThreads* threads = nullptr;       // one sleeping host thread per kid beyond the first
     bool any_set = false;
+    std::mutex group_mutex;                       // the bookkeeping of a stream group that setters on different sub-batches share
+    // uploads without a synchronize per recording (VBX_OPT_ASYNC_UPLOAD, round 6): the small per-recording arguments go through
+    // a pinned host block of the batch, sum_t G_t is fetched for all recordings at once when the next run begins
+    bool async_upload = false;
+    double* h_args = nullptr;                     // pinned: per recording {Phi[Dp], sqrt Phi[Dp], pi0[Sp]}
+    std::vector<char> gsum_pending;               // recording -> its sum_t G_t still lies in d_gtile
+    std::vector<char> args_busy;                  // recording -> its slot of h_args may be the source of a copy in flight
+    bool has_run = false;                         // an iteration has been launched since the batch was created
+    bool uploads_in_flight = false;               // something was enqueued by a setter since the last synchronize
+    // host mirrors of the small results, fetched once per run (vbx_batch_get_result then needs no device round trip for them)
+    std::vector<RecState> h_state;
+    std::vector<double> h_pi, h_Li;
+    bool mirrors_valid = false, model_mirrors_valid = false;
+    std::vector<double> h_alpha, h_invL;          // [n_rec][Sp][D] (fetch_model_mirrors)
+    void* d_fetch = nullptr;                      // device staging of a result fetch that the upload staging block cannot hold
+    size_t fetch_bytes = 0;
     int launch_rc = 0;                            // a launch helper found no kernel instance for this batch's padded width (checked in run_end)
     int n_rec = 0, D = 0, Dp = 0, Sp = 0, NT = 0, precision = 0, max_iters = 0;
     size_t rsize = 4;

@@ -48,7 +48,8 @@ int fb_step_impl(vbx_batch* b, int64_t T, int32_t S, const double* lls, double* 
     }
     if (tll) *tll = st.tll;
     if (gamma) {
-        rc = get_result_impl<R>(b, 0, gamma, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr);
+        b->mirrors_valid = false;
+        rc = leaf_get_result(b, 0, gamma, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr);
         if (rc != VBX_OK) return rc;
     }
     if (entered) {

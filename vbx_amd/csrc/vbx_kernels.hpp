@@ -147,6 +147,12 @@ __global__ __launch_bounds__(256) void prep_kernel(const XT* __restrict__ X, con
                                                    R* __restrict__ rho, double* __restrict__ gtile,
                                                    int T, int D, int Dp) {
     __shared__ double lds[16];
+    // sqrt(Phi) may live in pinned HOST memory (the batch's argument block: no copy, no staging -- set_recording_impl): every
+    // workgroup fetches it once, over the link, instead of once per element
+    constexpr int kStage = 512;
+    __shared__ double sphi[kStage];
+    for (int d = threadIdx.x; d < min(Dp, kStage); d += 256) sphi[d] = sqrt_phi[d];
+    __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int t0 = blockIdx.x * kTileFrames;
     double gacc = 0.0;
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const XT* __restrict__ X, con
         for (int d = lane; d < Dp; d += 64) {
             const double x = (ok && d < D) ? (double)X[(long long)t * D + d] : 0.0;
             ss += x * x;
-            if (ok) rho[(long long)t * Dp + d] = (R)(x * sqrt_phi[d]);
+            if (ok) rho[(long long)t * Dp + d] = (R)(x * (d < kStage ? sphi[d] : sqrt_phi[d]));
         }
         ss = allreduce_sum<64>(ss);
         if (ok) gacc += -0.5 * (ss + (double)D * 1.8378770664093454836);   // log(2 pi)
