@@ -92,8 +92,8 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? (SPLIT && SP == 
             const h8* __restrict__ ra = reinterpret_cast<const h8*>(bt.rho_a) + (long long)rtile * (kTileFrames * Dp / 4)
                                         + (long long)(2 * wave) * KK * 128 + lane;
             const h8* __restrict__ af = reinterpret_cast<const h8*>(bt.alpha_frag)
-                                        + ((long long)par * bt.n_rec + rec) * (SP * Dp / 4);
-            h8* const afl = reinterpret_cast<h8*>(lds);    // [n][kk of the slice: 4][hi | lo][lane]
+                                        + ((long long)par * bt.n_rec + rec) * (SP * Dp * 3 / 8);
+            h8* const afl = reinterpret_cast<h8*>(lds);    // [n][kk of the slice: 2][hi | lo | lo2][lane]
             const int e_rho = bt.rho_e[rd.rho_rec];
 #pragma unroll
             for (int n = 0; n < NT; ++n)
@@ -107,25 +107,28 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? (SPLIT && SP == 
                 }
             };
             load_a(0, 0);
+            // (three terms of alpha per K-block: two K-blocks per staging round keep the slice inside the region b will take)
+            constexpr int KS = 2;
 #pragma unroll 1
-            for (int kk0 = 0; kk0 < KK; kk0 += 4) {
-                const int nk = min(4, KK - kk0);
+            for (int kk0 = 0; kk0 < KK; kk0 += KS) {
+                const int nk = min(KS, KK - kk0);
                 if (kk0 > 0) __syncthreads();
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
-                    for (int q = tid; q < nk * 128; q += 256) afl[n * 512 + q] = af[((long long)n * KK + kk0) * 128 + q];
+                    for (int q = tid; q < nk * 192; q += 256) afl[n * (KS * 192) + q] = af[((long long)n * KK + kk0) * 192 + q];
                 __syncthreads();
 #pragma unroll
-                for (int kl = 0; kl < 4; ++kl) {
+                for (int kl = 0; kl < KS; ++kl) {
                     if (kl < nk) {
                         const int kk = kk0 + kl;
-                        if (kk + 1 < KK) load_a((kl + 1) & 1, kk + 1);
+                        if (kk + 1 < KK) load_a((kk + 1) & 1, kk + 1);
 #pragma unroll
                         for (int n = 0; n < NT; ++n) {
-                            const h8 bh = afl[(n * 4 + kl) * 128 + lane], bl = afl[(n * 4 + kl) * 128 + 64 + lane];
+                            const h8* bf = afl + (n * KS + kl) * 192 + lane;
+                            const h8 bh = bf[0], bl = bf[64], bl2 = bf[128];
 #pragma unroll
                             for (int m = 0; m < 2; ++m)
-                                acc[m][n] = mfma_split(a[kl & 1][m][0], a[kl & 1][m][1], bh, bl, acc[m][n]);
+                                acc[m][n] = mfma_split3(a[kk & 1][m][0], a[kk & 1][m][1], bh, bl, bl2, acc[m][n]);
                         }
                     }
                 }

@@ -336,10 +336,10 @@ __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(v - (float)hi);
 }
 
-// offsets in halfs inside one recording's alpha fragments [Sp / 16][Dp / 32][hi | lo][64 lanes][8]
+// offsets in halfs inside one recording's alpha fragments [Sp / 16][Dp / 32][hi | lo | lo2][64 lanes][8]
 __device__ __forceinline__ long long alpha_frag_offset(int s, int d, int hl, int Dp) {
     const int n = s >> 4, j = s & 15, kk = d >> 5, g = (d & 31) >> 3, e = d & 7;
-    return ((((long long)n * (Dp >> 5) + kk) * 2 + hl) * 64 + 16 * g + j) * 8 + e;
+    return ((((long long)n * (Dp >> 5) + kk) * 3 + hl) * 64 + 16 * g + j) * 8 + e;
 }
 
 }  // namespace vbx

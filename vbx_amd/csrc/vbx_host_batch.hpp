@@ -686,12 +686,12 @@ static int prepare_split(vbx_batch* b) {
         const size_t tile_bytes = (size_t)kTileFrames * b->Dp * 4;
         int rc = dmalloc_bytes(ctx, &b->d_rho_a, (size_t)b->ntiles_total * tile_bytes);
         if (rc == VBX_OK) rc = dmalloc_bytes(ctx, &b->d_rho_b, (size_t)b->ntiles_total * tile_bytes);
-        if (rc == VBX_OK) rc = dmalloc_bytes(ctx, &b->d_alpha_frag, (size_t)2 * b->n_rec * b->Sp * b->Dp * 4);
+        if (rc == VBX_OK) rc = dmalloc_bytes(ctx, &b->d_alpha_frag, (size_t)2 * b->n_rec * b->Sp * b->Dp * 6);
         if (rc == VBX_OK) rc = dmalloc(ctx, &b->d_rho_e, (size_t)b->n_rec);
         if (rc == VBX_OK) rc = dmalloc(ctx, &b->d_rho_amax, (size_t)2 * b->n_rec);
         if (rc == VBX_OK) rc = dmalloc(ctx, &b->d_alpha_e, (size_t)2 * b->n_rec * b->Sp);
         if (rc != VBX_OK) return rc;
-        HIPCHK(ctx, hipMemsetAsync(b->d_alpha_frag, 0, (size_t)2 * b->n_rec * b->Sp * b->Dp * 4, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(b->d_alpha_frag, 0, (size_t)2 * b->n_rec * b->Sp * b->Dp * 6, ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(b->d_alpha_e, 0, sizeof(int) * 2 * b->n_rec * b->Sp, ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(b->d_rho_e, 0, sizeof(int) * b->n_rec, ctx->stream));
         b->split_dirty.assign(b->n_rec, 1);

@@ -124,7 +124,7 @@ template <typename R> struct BatchView {
     const _Float16* rho_a;     // [tiles][kTileFrames x Dp x 2]  A operand of rho alpha^T   (chunk_loglik)
     const _Float16* rho_b;     // [tiles][kTileFrames x Dp x 2]  B operand of gamma^T rho   (chunk_post)
     const int* rho_e;          // [n_rec]  the copies hold rho 2^rho_e (indexed by RecDesc::rho_rec)
-    _Float16* alpha_frag;      // [2][n_rec][Sp x Dp x 2]  alpha 2^alpha_e of the two model copies, B operand of rho alpha^T
+    _Float16* alpha_frag;      // [2][n_rec][Sp x Dp x 3]  alpha 2^alpha_e of the two model copies as THREE f16 terms, B operand of rho alpha^T
     int* alpha_e;              // [2][n_rec][Sp]
 };
 
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(1024) void fin_kernel(BatchView<R> bt, int mode) {
     __shared__ double lds[16];
     __shared__ double sh[1024];
     __shared__ int done_sh;
-    __shared__ float arow[kSplitMaxDp];                     // split GEMMs: the speaker's alpha row (f32, as stored)
+    __shared__ double arow[kSplitMaxDp];                    // split GEMMs: the speaker's alpha row, in full precision
     __shared__ float amax_sh[16];
     const int rec = blockIdx.x, Sp = bt.Sp, Dp = bt.Dp;
     const RecState st_in = bt.state[rec];
@@ -397,25 +397,34 @@ __global__ __launch_bounds__(1024) void fin_kernel(BatchView<R> bt, int mode) {
         __syncthreads();
         if (slice == 0 && dok) {
             const double phi = bt.phi[(long long)rec * Dp + d];
-            double il, al;
+            double il, al, il_full = 0.0;
             if (given) {
                 il = (double)bt.invL[sd + d];
                 al = (double)bt.alpha[sd + d];
             } else {
                 for (int q = 1; q < nsl; ++q) C += sh[threadIdx.x + 128 * q];
                 il = 1.0 / (1.0 + fafb * N * phi);
+                il_full = il;
                 al = fafb * il * C;
                 const R ilr = (R)il, alr = (R)al;      // the values every later kernel sees
                 bt.invL[sd + d] = ilr;
                 bt.alpha[sd + d] = alr;
-                il = (double)ilr;
+                // alpha: what the product multiplies with (the model array's rounding is part of the iteration).  invL enters the
+                // iteration through the bias only, so the bias takes it in full precision: its f32 rounding is a per-speaker
+                // constant in every frame's log-likelihood -- 1.3e-6 of gamma after three iterations at T = 200 000 (round 6)
                 al = (double)alr;
             }
-            bsum += (il + al * al) * phi;
-            if (s < rd.S && d < bt.D) esum += log(il) - il - al * al + 1.0;
             if (bt.alpha_frag) {
-                arow[d] = (float)al;
-                amax = fmaxf(amax, fabsf((float)al));
+                // split GEMMs (round 6): the product runs on THREE f16 terms of the alpha computed here in f64 -- 33 bits -- not
+                // on the f32 value of the model arrays, and the bias and the model term of the ELBO (second loop below) are taken
+                // from the very value those terms add up to.  A speaker's alpha multiplies every frame of the recording, so its
+                // representation error is not noise: at T = 200 000 two 11-bit terms of the f32 value were 1.9e-4 of gamma at the
+                // iterations where the EM map amplifies, the f32 value itself 2.4e-5 (tests/test_gpu_trajectory.py)
+                arow[d] = given ? al : fafb * il_full * C;
+                amax = fmaxf(amax, fabsf((float)arow[d]));
+            } else {
+                bsum += (il + al * al) * phi;
+                if (s < rd.S && d < bt.D) esum += log(il) - il - al * al + 1.0;
             }
         }
         __syncthreads();
@@ -429,12 +438,23 @@ __global__ __launch_bounds__(1024) void fin_kernel(BatchView<R> bt, int mode) {
         float m = 0.0f;
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, amax_sh[w]);
         const int e2 = split_exponent(m);
-        _Float16* __restrict__ fr = bt.alpha_frag + ((long long)(k & 1) * bt.n_rec + rec) * Sp * Dp * 2;
+        _Float16* __restrict__ fr = bt.alpha_frag + ((long long)(k & 1) * bt.n_rec + rec) * Sp * Dp * 3;
         for (int d = threadIdx.x; d < Dp; d += blockDim.x) {
-            _Float16 hi, lo;
-            split_f16(__builtin_amdgcn_ldexpf(arow[d], e2), hi, lo);
+            const double x = __builtin_amdgcn_ldexp(arow[d], e2);
+            const _Float16 hi = (_Float16)(float)x;
+            const double r1 = x - (double)(float)hi;
+            const _Float16 lo = (_Float16)(float)r1;
+            const double r2 = r1 - (double)(float)lo;
+            const _Float16 lo2 = (_Float16)(float)r2;
             fr[alpha_frag_offset(s, d, 0, Dp)] = hi;
             fr[alpha_frag_offset(s, d, 1, Dp)] = lo;
+            fr[alpha_frag_offset(s, d, 2, Dp)] = lo2;
+            // the alpha the product really uses, and with it the bias (VBx.py:97) and the model term of the ELBO (VBx.py:100)
+            const double al = __builtin_amdgcn_ldexp(((double)(float)hi + (double)(float)lo) + (double)(float)lo2, -e2);
+            const double phi = bt.phi[(long long)rec * Dp + d];
+            const double il = given ? (double)bt.invL[sd + d] : 1.0 / (1.0 + fafb * N * phi);
+            bsum += (il + al * al) * phi;
+            if (s < rd.S && d < bt.D) esum += log(il) - il - al * al + 1.0;
         }
         if (threadIdx.x == 0) bt.alpha_e[(long long)(k & 1) * bt.vec_stride + (long long)rec * Sp + s] = e2;
     }

@@ -34,6 +34,14 @@ __device__ __forceinline__ f4 mfma_h(h8 a, h8 b, f4 c) { return __builtin_amdgcn
 #ifndef VBX_SPLIT_LOLO
 #define VBX_SPLIT_LOLO 0
 #endif
+// rho alpha^T: the B operand (alpha) carries a third term -- alpha multiplies every frame, its representation error is
+// systematic (fin_kernel) -- while the A operand's error is independent from frame to frame and averages out
+__device__ __forceinline__ f4 mfma_split3(h8 ah, h8 al, h8 bh, h8 bl, h8 bl2, f4 c) {
+    c = mfma_h(ah, bl2, c);
+    c = mfma_h(ah, bl, c);
+    c = mfma_h(al, bh, c);
+    return mfma_h(ah, bh, c);
+}
 __device__ __forceinline__ f4 mfma_split(h8 ah, h8 al, h8 bh, h8 bl, f4 c) {
 #if VBX_SPLIT_LOLO
     c = mfma_h(al, bl, c);
