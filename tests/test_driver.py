@@ -383,6 +383,7 @@ def test_device_linkage_is_the_host_linkage_bit_for_bit(kind, monkeypatch):
     SciPy's linkage bit for bit, see below): same merges, same numbering, same distances to the last bit -- random cosine
     similarities, similarities with massive exact ties (few distinct integer-valued x-vectors), the example recording."""
     from vbx_amd import _capi
+    monkeypatch.setenv('VBX_AMD_EXPERIMENT', '1')
     monkeypatch.setenv('VBX_AMD_LINKAGE_DEVICE', 'chain')
     ctx = _capi.default_context()
     rng = np.random.default_rng(11)
@@ -437,6 +438,7 @@ def test_device_linkage_in_rounds_of_reciprocal_pairs(kind, monkeypatch):
         xs = [xv, np.concatenate([xv, xv[::-1] * 1.0001 + 1e-3 * rng.standard_normal(xv.shape)])]    # 1025, 2050
     for x in xs:
         n = len(x)
+        monkeypatch.setenv('VBX_AMD_EXPERIMENT', '1')
         monkeypatch.setenv('VBX_AMD_LINKAGE_DEVICE', 'rounds')
         sc = _capi.Scores.cos_similarity(ctx, x)
         cond = sc.get_condensed(n, -1.0)

@@ -136,6 +136,7 @@ def test_chunked_scan_survives_extreme_dynamic_range(ctx):
 
 @pytest.mark.parametrize('algo', ['sequential', 'chunked'])
 def test_vbx_same_answer_with_either_scan(synth_cases, monkeypatch, algo):
+    monkeypatch.setenv('VBX_AMD_EXPERIMENT', '1')
     monkeypatch.setenv('VBX_AMD_FB_ALGO', algo)
     for name in ('soft_T600_S12', 'soft_T1000_S30', 'soft_T700_S50', 'easy_T500_S10', 'two_frames_S4',
                  'loop1_T250_S5', 'early_stop_T450_S9'):
@@ -544,6 +545,7 @@ def test_long_recordings_c3_c5_properties_and_path_agreement(ctx, monkeypatch, T
     g0 /= g0.sum(1, keepdims=True)
     out = {}
     for precision, fuse in (('fp64', 2), ('fp32', 2), ('fp32', 0)):
+        monkeypatch.setenv('VBX_AMD_EXPERIMENT', '1')
         monkeypatch.setenv('VBX_AMD_FUSE', str(fuse))
         batch = _capi.Batch(ctx, [T], [S], 128, precision=precision, max_iters=iters)
         batch.set_recording(0, X, Phi, np.ones(S) / S, g0, lp, 0.3, 17.0)

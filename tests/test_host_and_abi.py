@@ -185,7 +185,7 @@ def test_bench_last_line_is_compact_and_complete():
     assert set(c['cpu_baseline']) == {'value', 'unit', 'cores', 'kind', 'sample'} and c['cpu_baseline']['kind'] == 'port'
     assert set(full['configs']) <= set(c['configs']) and 'f32_split' in c['configs'] and 'f64' in c['configs']
     for name, d in c['configs'].items():
-        assert set(d) <= {'value', 'ms', 'frac', 'bound'} and d['value'] is not None, name
+        assert set(d) <= {'value', 'ms', 'frac', 'bound_today'} and d['value'] is not None, name
     # a record three times the size still fits: entries are dropped from the end and the line says so
     big = dict(full, configs={f'{k}_{i}': v for k, v in full['configs'].items() for i in range(6)})
     line = bench.compact_record(big)

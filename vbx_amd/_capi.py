@@ -170,6 +170,12 @@ def pinned_arrays(shapes, dtype=np.float64):
     return out
 
 
+def experiment_env(name):
+    """An environment variable that exists for A/B measurements only (second table): read only when
+    VBX_AMD_EXPERIMENT=1, so that a stray variable in a production environment cannot change what the library runs."""
+    return os.environ.get(name) if os.environ.get('VBX_AMD_EXPERIMENT') == '1' else None
+
+
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
@@ -420,21 +426,21 @@ class Batch:
             if value not in table:
                 raise ValueError(f'{var}={value!r}: expected one of {", ".join(map(repr, table))}')
             return table[value]
-        algo = os.environ.get('VBX_AMD_FB_ALGO')          # 'sequential' | 'chunked' (default: auto)
+        algo = experiment_env('VBX_AMD_FB_ALGO')          # 'sequential' | 'chunked' (default: auto)
         if algo:
             self.set_option(OPT_FB_ALGO, choice('VBX_AMD_FB_ALGO', algo, {'auto': FB_AUTO, 'sequential': FB_SEQUENTIAL,
                                                                           'chunked': FB_CHUNKED}))
-        if os.environ.get('VBX_AMD_TWO_LEVEL_FROM') is not None:
-            self.set_option(OPT_TWO_LEVEL_FROM, int(os.environ['VBX_AMD_TWO_LEVEL_FROM']))
-        group = os.environ.get('VBX_AMD_SCAN_GROUP')      # chunks per group of the two-level boundary walk
+        if experiment_env('VBX_AMD_TWO_LEVEL_FROM') is not None:
+            self.set_option(OPT_TWO_LEVEL_FROM, int(experiment_env('VBX_AMD_TWO_LEVEL_FROM')))
+        group = experiment_env('VBX_AMD_SCAN_GROUP')      # chunks per group of the two-level boundary walk
         if group is not None:
             self.set_option(OPT_SCAN_GROUP, int(group))
-        group2 = os.environ.get('VBX_AMD_SCAN_GROUP2')    # level-2 groups of the three-level walk (0 auto, 1 off)
+        group2 = experiment_env('VBX_AMD_SCAN_GROUP2')    # level-2 groups of the three-level walk (0 auto, 1 off)
         if group2 is not None:
             self.set_option(OPT_SCAN_GROUP2, int(group2))
-        if os.environ.get('VBX_AMD_THREE_LEVEL_FROM') is not None:
-            self.set_option(OPT_THREE_LEVEL_FROM, int(os.environ['VBX_AMD_THREE_LEVEL_FROM']))
-        split = os.environ.get('VBX_AMD_SPLIT_TILES')     # 1 / 2: half-tile re-runs on / off (0: the library's choice)
+        if experiment_env('VBX_AMD_THREE_LEVEL_FROM') is not None:
+            self.set_option(OPT_THREE_LEVEL_FROM, int(experiment_env('VBX_AMD_THREE_LEVEL_FROM')))
+        split = experiment_env('VBX_AMD_SPLIT_TILES')     # 1 / 2: half-tile re-runs on / off (0: the library's choice)
         if split is not None:
             self.set_option(OPT_SPLIT_TILES, int(split))
         # VBX_OPT_GEMM: the precision argument decides where it names a mode ('fp32-split'); VBX_AMD_GEMM = exact | split
@@ -446,7 +452,7 @@ class Batch:
             gemm = 'split'
         if gemm:
             self.set_option(OPT_GEMM, {'exact': GEMM_EXACT, 'split': GEMM_SPLIT}[gemm])
-        fuse = os.environ.get('VBX_AMD_FUSE')             # '0' keeps every stage in its own kernel
+        fuse = experiment_env('VBX_AMD_FUSE')             # '0' keeps every stage in its own kernel
         if fuse is not None:
             self.set_option(OPT_FUSE, int(fuse))
 

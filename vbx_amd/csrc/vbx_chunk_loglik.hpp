@@ -23,7 +23,7 @@ template <typename R, int SP> struct ChunkLoglikCfg {
 };
 
 #ifndef VBX_SPLIT_LOGLIK_WAVES
-#define VBX_SPLIT_LOGLIK_WAVES 7
+#define VBX_SPLIT_LOGLIK_WAVES 6
 #endif
 // SPLIT (fp32 only): the product on v_mfma_f32_16x16x32_f16 with f16 operand pairs (vbx_split.hpp) -- rho from its
 // fragment-ordered copy rho_a, alpha from the fragments fin_kernel wrote.

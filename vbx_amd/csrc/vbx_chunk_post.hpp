@@ -70,7 +70,12 @@ template <typename R, int SP> struct ChunkPostCfg {
 
 // REPLAY: write gamma only (see above).  SPLIT (fp32 only): gamma^T rho on v_mfma_f32_16x16x32_f16 with f16 operand pairs
 // (vbx_split.hpp) -- rho from its fragment-ordered copy rho_b, gamma split where it is computed.
-template <typename R, int SP, bool REPLAY, bool SPLIT = false>
+// FOLD (round 6, small batches): the last level of the boundary walk -- the steps INSIDE a group of chunks, a launch of its own
+// otherwise (scan2_kernel level 3) -- runs here: the workgroup stages the operators of its group that lie before and behind its
+// chunk (at most kTileFrames / SP of them: the region r1 is free until the re-run starts), wave 0 walks forward from the group's
+// left edge, wave 1 backward from its right edge, with the very arithmetic of scan2 (walk_step).  One dependent launch fewer
+// per iteration where an iteration IS its launches (one recording of T = 10 000: 51.7 us in six launches).
+template <typename R, int SP, bool REPLAY, bool SPLIT = false, bool FOLD = false>
 __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post_kernel(BatchView<R> bt) {
     static_assert(!SPLIT || (sizeof(R) == 4 && !REPLAY), "the split GEMM is a mode of the fp32 iteration");
     using M = Mfma16<R>;
@@ -150,7 +155,33 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
             bnd_v[r] = 0;
             ope[r] = 0;
         }
-        if (is_fwd || is_bwd) {
+        // FOLD: the operators between the group's edges and this chunk, requested now, stored to r1 behind the b tile's loads
+        constexpr int kFoldOps = kTileFrames / SP;         // operators r1 can hold
+        constexpr int VPO = SP * SP / 4, NVF = FOLD ? SP / 8 : 1;
+        __shared__ int fexp[FOLD ? kTileFrames : 1];
+        __shared__ R fvec[FOLD ? 2 : 1][SP];
+        __shared__ R fwl[FOLD ? 2 : 1][SP];
+        R4 ftmp[NVF];
+        int fe = 0, nf = 0, nb = 0, ga = 0, gb = 0;
+        if constexpr (FOLD) {
+            const int G = bt.sgroup, cb0 = bt.recs[rec].tile0, K = bt.recs[rec].ntiles;
+            const int jpos = (tile - cb0) % G;
+            ga = tile - jpos;
+            gb = min(ga + G, cb0 + K);
+            nf = jpos;                                     // forward steps: operators ga .. tile - 1
+            nb = gb - 1 - tile;                            // backward steps: operators gb - 1 .. tile + 1
+            const int nops = nf + nb;                      // <= G - 1 <= kFoldOps (the host folds only then)
+            auto op_of = [&](int slot) { return slot < nf ? ga + slot : gb - 1 - (slot - nf); };
+#pragma unroll
+            for (int u = 0; u < NVF; ++u) {
+                const int v = u * 256 + tid, slot = v / VPO, e = v % VPO;
+                ftmp[u] = reinterpret_cast<const R4*>(bt.op + (long long)op_of(slot < nops ? slot : 0) * SP * SP)[e];
+            }
+            if (tid < kTileFrames) {
+                const int slot = tid / SP;
+                fe = bt.opexp[(long long)op_of(slot < nops ? slot : 0) * SP + tid % SP];
+            }
+        } else if (is_fwd || is_bwd) {
             const R* __restrict__ bnd = (is_fwd ? bt.fbound : bt.gbound) + (long long)tile * SP + so;
             load_pack<NREG>(bnd_v, bnd);
         }
@@ -179,7 +210,40 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
             const double pj = (REPLAY ? bt.pi_prev : bt.pi)[(long long)rec * SP + tid];
             c_l[tid] = (tid < n_spk) ? (R)((1.0 - lp_d) * pj + 1e-8) : (R)0;
         }
+        if constexpr (FOLD) {
+#pragma unroll
+            for (int u = 0; u < NVF; ++u) {
+                const int v = u * 256 + tid;
+                if (v / VPO < nf + nb) reinterpret_cast<R4*>(r1)[v] = ftmp[u];
+            }
+            if (tid < kTileFrames) fexp[tid] = fe;
+        }
         __syncthreads();
+        if constexpr (FOLD) {
+            constexpr int HL = 64 / SP, NI = SP / HL;
+            const int j = lane / HL, h = lane % HL;
+            if (wave == 0) {                               // forward from the vector entering the group's first chunk
+                R y = bt.fbound[(long long)ga * SP + j];
+                for (int q = 0; q < nf; ++q) {
+                    R opv[NI];
+                    int ej;
+                    walk_fetch<R, SP, 0>(opv, ej, r1 + q * SP * SP, fexp + q * SP, j, h);
+                    y = walk_step<R, SP, 0>(y, opv, ej, fwl[0], j, h, n_spk);
+                }
+                if (h == 0) fvec[0][j] = y;
+            } else if (wave == 1) {                        // backward from the vector at the end of the group's last chunk
+                R y = bt.gbound[(long long)(gb - 1) * SP + j];
+                for (int q = 0; q < nb; ++q) {
+                    R opv[NI];
+                    int ej;
+                    walk_fetch<R, SP, 1>(opv, ej, r1 + (nf + q) * SP * SP, fexp + (nf + q) * SP, j, h);
+                    y = walk_step<R, SP, 1>(y, opv, ej, fwl[1], j, h, n_spk);
+                }
+                if (h == 0) fvec[1][j] = y;
+            }
+            __syncthreads();                               // (also: r1 is free again before a chain writes to it)
+            if (is_fwd || is_bwd) load_pack<NREG>(bnd_v, fvec[is_fwd ? 0 : 1] + so);
+        }
         VBX_STAMP();
 
         // ---- re-run: wave 0 forward, wave 1 backward (VBx.py:167-171 in the linear domain) ----------------------

@@ -291,12 +291,12 @@ int vbx_scores_linkage_average(vbx_scores* sc, int64_t T, double* Z) {
     //           at T = 1025) and is the reference the rounds are tested against
     // The chain runs in stages of n/4 merges with a compaction of the live rows and columns in between; below kStageMin
     // clusters the rest runs in one stage (there a merge costs its four round trips, not the bytes of a row).
-    static const long long kStageMin = [] { const char* e = getenv("VBX_AMD_LINKAGE_STAGE_MIN"); const long long v = e ? atoll(e) : 0; return v >= 64 ? v : 4096LL; }();
-    static const bool staged = [] { const char* e = getenv("VBX_AMD_LINKAGE_STAGES"); return !(e && e[0] == '0'); }();
-    const char* dev_mode = getenv("VBX_AMD_LINKAGE_DEVICE");           // (read per call: tests compare the two in one process)
+    static const long long kStageMin = [] { const char* e = experiment_env("VBX_AMD_LINKAGE_STAGE_MIN"); const long long v = e ? atoll(e) : 0; return v >= 64 ? v : 4096LL; }();
+    static const bool staged = [] { const char* e = experiment_env("VBX_AMD_LINKAGE_STAGES"); return !(e && e[0] == '0'); }();
+    const char* dev_mode = experiment_env("VBX_AMD_LINKAGE_DEVICE");           // (read per call: tests compare the two in one process)
     const bool rounds_on = !(dev_mode && std::strcmp(dev_mode, "chain") == 0);
-    static const long long kRoundsFrom = [] { const char* e = getenv("VBX_AMD_LINKAGE_ROUNDS_FROM"); const long long v = e ? atoll(e) : 0; return v >= 4 ? v : 256LL; }();
-    static const long long kRoundsStop = [] { const char* e = getenv("VBX_AMD_LINKAGE_ROUNDS_STOP"); const long long v = e ? atoll(e) : 0; return v >= 2 ? v : 48LL; }();
+    static const long long kRoundsFrom = [] { const char* e = experiment_env("VBX_AMD_LINKAGE_ROUNDS_FROM"); const long long v = e ? atoll(e) : 0; return v >= 4 ? v : 256LL; }();
+    static const long long kRoundsStop = [] { const char* e = experiment_env("VBX_AMD_LINKAGE_ROUNDS_STOP"); const long long v = e ? atoll(e) : 0; return v >= 2 ? v : 48LL; }();
     int *d_size = nullptr, *d_size2 = nullptr, *d_chain = nullptr, *d_orig = nullptr, *d_orig2 = nullptr, *d_old = nullptr,
         *d_newidx = nullptr, *d_state = nullptr, *d_nn = nullptr, *d_role = nullptr;
     double *d_alt = nullptr, *d_cmp = nullptr, *d_nnd = nullptr;

@@ -27,7 +27,7 @@ struct LaunchScope {   // brackets one kernel launch with events when profiling 
 
 // (debugging aid: VBX_AMD_SPLIT_MASK = 1 / 2 keeps the split GEMM to chunk_loglik / chunk_post only)
 static int split_debug_mask() {
-    static const int m = [] { const char* e = std::getenv("VBX_AMD_SPLIT_MASK"); return e ? atoi(e) : 3; }();
+    static const int m = [] { const char* e = experiment_env("VBX_AMD_SPLIT_MASK"); return e ? atoi(e) : 3; }();
     return m;
 }
 
@@ -106,7 +106,7 @@ template <typename R> void launch_loglik(vbx_batch* b, double eps, bool raw) {
 // partials than the smaller block fetches in a few rounds (one recording of T = 200 000: mstep_fin 42 -> 30 us, iter_fin
 // 33 -> 23 us; at T = 50 000 mstep_fin is no faster with 1024 threads, iter_fin 9 -> 8 us).
 static int small_kernel_threads(const vbx_batch* b, int from_tiles) {
-    static const int forced = [] { const char* e = std::getenv("VBX_AMD_FIN_THREADS"); const int v = e ? atoi(e) : 0; return (v == 256 || v == 1024) ? v : 0; }();
+    static const int forced = [] { const char* e = experiment_env("VBX_AMD_FIN_THREADS"); const int v = e ? atoi(e) : 0; return (v == 256 || v == 1024) ? v : 0; }();
     if (forced && b->Sp <= 256) return forced;
     int maxtiles = 0;
     for (auto& rd : b->recs) maxtiles = std::max(maxtiles, rd.ntiles);
@@ -114,11 +114,35 @@ static int small_kernel_threads(const vbx_batch* b, int from_tiles) {
 }
 
 // chunk_post over the tiles of the batch; REPLAY: the instance that only writes the responsibilities
+// Does chunk_post walk the last level of the boundary walk itself (FOLD, vbx_chunk_post.hpp)?  Where an iteration is its launches:
+// a grouped walk, the group's operators fit the free LDS region, and the batch does not fill the chip (beyond that the extra
+// mat-vecs per workgroup cost more than the launch they replace).  VBX_AMD_FOLD_WALK=0 / 1 forces it off / on (A/B runs).
+template <int SP> bool fold_walk_wanted(const vbx_batch* b) {
+    static const int forced = [] { const char* e = experiment_env("VBX_AMD_FOLD_WALK"); return (e && *e) ? (e[0] == '0' ? 0 : 1) : -1; }();
+    if (SP > 32 || b->sgroup <= 1 || b->spt != 1 || b->sgroup - 1 > kTileFrames / SP) return false;
+    if (forced >= 0) return forced == 1;
+    return b->ntiles_total <= 2048;
+}
+
 template <typename R, int SP, bool REPLAY> void launch_chunk_post(vbx_batch* b, const BatchView<R>& v) {
     if constexpr (ChunkPostCfg<R, SP>::kFits) {
+        constexpr bool kCanFold = SP <= 32;                  // (a group has at least four chunks: three operators in r1)
+        const bool fold = kCanFold && b->fold_now;
         if constexpr (std::is_same<R, float>::value && !REPLAY) {
             if (v.rho_b && (split_debug_mask() & 2)) {       // gamma^T rho on the f16 matrix cores (vbx_split.hpp)
+                if constexpr (kCanFold) {
+                    if (fold) {
+                        hipLaunchKernelGGL((chunk_post_kernel<R, SP, false, true, true>), dim3(b->nblocks_chunk), dim3(256), 0, b->ctx->stream, v);
+                        return;
+                    }
+                }
                 hipLaunchKernelGGL((chunk_post_kernel<R, SP, false, true>), dim3(b->nblocks_chunk), dim3(256), 0, b->ctx->stream, v);
+                return;
+            }
+        }
+        if constexpr (kCanFold) {
+            if (fold) {
+                hipLaunchKernelGGL((chunk_post_kernel<R, SP, REPLAY, false, true>), dim3(b->nblocks_chunk), dim3(256), 0, b->ctx->stream, v);
                 return;
             }
         }
@@ -147,6 +171,9 @@ template <typename R, int SP> void launch_scan(vbx_batch* b, const BatchView<R>&
         LaunchScope ls(b, VBX_K_FB);
         hipLaunchKernelGGL((scan1_kernel<R, SP>), dim3(b->ntiles_total), dim3(SP * SP / 4), 0, st, v);
     }
+    bool fold = false;
+    if constexpr (ChunkPostCfg<R, SP>::kFits) fold = fused_post && fold_walk_wanted<SP>(b);
+    b->fold_now = fold;                          // (the gamma write-out after the run replays with the same choice)
     {
         LaunchScope ls(b, VBX_K_FB_AUX);
         if (b->sgroup > 1 && b->sgroup2 > 1) {   // very long recordings: groups of groups on top
@@ -154,11 +181,11 @@ template <typename R, int SP> void launch_scan(vbx_batch* b, const BatchView<R>&
             hipLaunchKernelGGL((scan_compose_kernel<R, SP>), dim3(b->nsup2_total), dim3(256), 0, st, v, 2);
             hipLaunchKernelGGL((scan2_kernel<R, SP>), dim3(b->n_rec, 2), dim3(256), 0, st, v, 4);
             hipLaunchKernelGGL((scan2_kernel<R, SP>), dim3(b->nsup2_total, 2), dim3(256), 0, st, v, 5);
-            hipLaunchKernelGGL((scan2_kernel<R, SP>), dim3(b->nsup_total, 2), dim3(256), 0, st, v, 3);
+            if (!fold) hipLaunchKernelGGL((scan2_kernel<R, SP>), dim3(b->nsup_total, 2), dim3(256), 0, st, v, 3);
         } else if (b->sgroup > 1) {     // long recordings: group operators, boundaries at the group edges, then inside the groups
             hipLaunchKernelGGL((scan_compose_kernel<R, SP>), dim3(b->nsup_total), dim3(256), 0, st, v, 1);
             hipLaunchKernelGGL((scan2_kernel<R, SP>), dim3(b->n_rec, 2), dim3(256), 0, st, v, 2);
-            hipLaunchKernelGGL((scan2_kernel<R, SP>), dim3(b->nsup_total, 2), dim3(256), 0, st, v, 3);
+            if (!fold) hipLaunchKernelGGL((scan2_kernel<R, SP>), dim3(b->nsup_total, 2), dim3(256), 0, st, v, 3);
         } else {
             hipLaunchKernelGGL((scan2_kernel<R, SP>), dim3(b->n_rec, 2), dim3(256), 0, st, v, 0);
         }

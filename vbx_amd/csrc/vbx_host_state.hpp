@@ -8,6 +8,13 @@ thread_local std::string g_create_error;
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// Environment variables that exist for A/B measurements only (second table): read only when
+// VBX_AMD_EXPERIMENT=1, so that a stray variable in a production environment cannot change what the library runs.
+inline const char* experiment_env(const char* name) {
+    const char* on = std::getenv("VBX_AMD_EXPERIMENT");
+    return (on && on[0] == '1') ? std::getenv(name) : nullptr;
+}
+
 }  // namespace
 
 // A process gets four hardware compute queues by default; a fifth HIP stream shares one with another, and two busy
@@ -137,6 +144,7 @@ struct vbx_batch {
     bool mpart_valid = false;                     // mpart/npart hold gamma^T rho of the current gamma (fused path)
     bool gamma_stale = false;                     // fused iterations have run since gamma was last written (run_end replays)
     bool fused_now = false;                       // in effect for the launches being issued: the fused per-chunk kernels
+    bool fold_now = false;                        // ... and chunk_post walks the last level of the boundary walk itself (FOLD)
     bool half_ops_now = false;                    // ... and chunk_loglik builds the half-tile operators chunk_post splits its re-run with
     void* d_gamma0 = nullptr;
     double* d_pi_prev = nullptr;

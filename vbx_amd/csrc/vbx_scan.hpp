@@ -128,6 +128,48 @@ template <typename R, int SP> struct Scan2Cfg {
     static constexpr int NBUF = (2 * RB * kOpBytes <= kBudget) ? 2 : 1;
 };
 
+// One step of the boundary walk on ONE wavefront, shared by scan2_kernel and by the folded walk of chunk_post_kernel (which must
+// give the very same bits): y <- F y (dir 0: weights y_i 2^(E_i) shifted by the largest exponent on the support of y) or
+// y <- F^T y (dir 1: outputs rescaled by the largest exponent).  lane = (row j, part h), HL = 64 / SP lanes share a row and
+// split the columns; `opl` the operator in LDS (column-major as stored), `ex` its SP column exponents, `wl` SP scratch words
+// of the wave.  NI operator entries per lane are fetched by the caller (scan2 fetches them a step ahead).
+template <typename R, int SP, int dir>
+__device__ __forceinline__ void walk_fetch(R (&opv)[SP / (64 / SP)], int& ej, const R* opl, const int* ex, int j, int h) {
+    constexpr int HL = 64 / SP, NI = SP / HL;
+#pragma unroll
+    for (int ii = 0; ii < NI; ++ii)                   // fwd: row j of columns h*NI..; bwd: column j, rows h*NI..
+        opv[ii] = dir == 0 ? opl[(h * NI + ii) * SP + j] : opl[j * SP + h * NI + ii];
+    ej = ex[j];
+}
+template <typename R, int SP, int dir>
+__device__ __forceinline__ R walk_step(R y, const R (&opv)[SP / (64 / SP)], int ej, R* wl, int j, int h, int S) {
+    constexpr int HL = 64 / SP, NI = SP / HL;
+    R w = y;
+    if (dir == 0) {                       // weights y_i 2^{E_i}, shifted by the largest on the support
+        const bool pos = y > (R)0;
+        const int tj = pos ? ej + exponent_of(y) : -(1 << 28);
+        const int top = allreduce_max<64>(tj);
+        w = pos ? scale2(y, ej - top) : (R)0;
+    }
+    if (h == 0) wl[j] = w;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    R acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int ii = 0; ii < NI; ++ii) acc[ii & 3] += wl[h * NI + ii] * opv[ii];
+    R tot = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    tot = column_sum<HL>(tot);
+    if (dir == 1) {                       // (F^T g)_j = 2^{E_j} <col_j, g>: rescale the outputs
+        const bool pos = tot > (R)0;
+        const int tj = pos ? ej + exponent_of(tot) : -(1 << 28);
+        const int top = allreduce_max<64>(tj);
+        tot = pos ? scale2(tot, ej - top) : (R)0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return (j < S) ? tot : (R)0;          // padded speakers carry no mass in either direction
+}
+
 // The walk is used at several levels (`level` argument of scan2_kernel):
 //   0  flat: every chunk operator of a recording, from the initial vector          (grid.x = recording)
 //   2  the group operators of scan_compose_kernel: boundaries at the group edges     (grid.x = recording)
@@ -237,11 +279,7 @@ __device__ __forceinline__ void scan2_body(const BatchView<R>& bt, int level, R*
         R opv[2][NI];
         int ejv[2];
         auto fetch = [&](int q, int slot) {       // LDS -> registers, issued one chain step ahead
-            const R* opl = ring + (long long)(buf * RB + q) * OPSZ;
-#pragma unroll
-            for (int ii = 0; ii < NI; ++ii)       // fwd: row j of columns h*NI..; bwd: column j, rows h*NI..
-                opv[slot][ii] = dir == 0 ? opl[(h * NI + ii) * SP + j] : opl[j * SP + h * NI + ii];
-            ejv[slot] = exps[(buf * RB + q) * SP + j];
+            walk_fetch<R, SP, dir>(opv[slot], ejv[slot], ring + (long long)(buf * RB + q) * OPSZ, exps + (buf * RB + q) * SP, j, h);
         };
         fetch(0, 0);
 #pragma unroll
@@ -249,31 +287,7 @@ __device__ __forceinline__ void scan2_body(const BatchView<R>& bt, int level, R*
             const int n = r * RB + q;
             if (n >= nops) break;
             if (q + 1 < RB) fetch(q + 1, (q + 1) & 1);
-            const int ej = ejv[q & 1];
-            R w = y;
-            if (dir == 0) {                       // weights y_i 2^{E_i}, shifted by the largest on the support
-                const bool pos = y > (R)0;
-                const int tj = pos ? ej + exponent_of(y) : -(1 << 28);
-                const int top = allreduce_max<64>(tj);
-                w = pos ? scale2(y, ej - top) : (R)0;
-            }
-            if (h == 0) wl[j] = w;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            R acc[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int ii = 0; ii < NI; ++ii) acc[ii & 3] += wl[h * NI + ii] * opv[q & 1][ii];
-            R tot = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-            tot = column_sum<HL>(tot);
-            if (dir == 1) {                       // (F^T g)_j = 2^{E_j} <col_j, g>: rescale the outputs
-                const bool pos = tot > (R)0;
-                const int tj = pos ? ej + exponent_of(tot) : -(1 << 28);
-                const int top = allreduce_max<64>(tj);
-                tot = pos ? scale2(tot, ej - top) : (R)0;
-            }
-            y = (j < rd.S) ? tot : (R)0;          // padded speakers carry no mass in either direction
-            __builtin_amdgcn_wave_barrier();
+            y = walk_step<R, SP, dir>(y, opv[q & 1], ejv[q & 1], wl, j, h, rd.S);
             if (h == 0) bound[(b0 + (long long)(n + 1) * bs) * SP + j] = y;
         }
     };

@@ -139,7 +139,7 @@ class DeviceStages:
     # The device linkage merges all reciprocal nearest-neighbour pairs per round on the whole chip (round 4: 1.2 ms at
     # T = 1025, 2.2 ms at 4000, 5.8 ms at 10 000, 19 ms at 20 000; the one-workgroup chain of rounds 2-3: 12 / 54 / 174 / 512 ms);
     # the host routine needs ~3 ns per matrix entry plus the condensed matrix over PCIe (3 ms at T = 1025): the device from ~600
-    DEVICE_LINKAGE_FROM = int(os.environ.get('VBX_AMD_DEVICE_LINKAGE_FROM', '600'))
+    DEVICE_LINKAGE_FROM = int((os.environ.get('VBX_AMD_DEVICE_LINKAGE_FROM') if os.environ.get('VBX_AMD_EXPERIMENT') == '1' else None) or '600')
 
     def ahc(self, k, threshold):
         """-> (AHC labels of recording k, calibrated threshold)."""
