@@ -5,7 +5,7 @@
 #                                (with the kernel trace of bench.py itself beside each)
 #   c2*, c3*                     BASELINE configs[1], [2] (one recording each): fp32, split, fp64
 #   c4x8*                        configs[3] as stated: 8 recordings on this GPU
-#   c5_shared*                   configs[4]: the nine-point sweep on one rho
+#   c5_shared*, c5_private_32    configs[4]: the nine-point sweep on one rho; with a private copy per point (fp32)
 #   s128*                        one recording with S = 128: the wide chunked scan (vbx_scan_wide.hpp)
 # Summaries land in gpurun_out/prof_<round>_*/ and are copied into profiles/<round>_* on the box and into
 # gpurun_out/profiles_<round>/ (what comes back: copy that directory's files into profiles/; the files bench.py reads carry the
@@ -36,6 +36,7 @@ for p in fp32 fp32-split fp64; do
   run c4x8_$s 1 --batch 8 --T 10000 --S 30 --precision $p
   run c5_shared_$s 1 --sweep shared --T 200000 --S 50 --precision $p
 done
+run c5_private_32 1 --sweep private --T 200000 --S 50 --precision fp32
 run s128_32 1 --batch 1 --T 10000 --S 128 --precision fp32
 run s128_64 1 --batch 1 --T 10000 --S 128 --precision fp64
 ls profiles | grep "^${r}_" | wc -l

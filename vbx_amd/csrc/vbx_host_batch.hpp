@@ -75,7 +75,7 @@ static int leaf_destroy(vbx_batch* b) {
     (void)hipStreamSynchronize(b->ctx->stream);               // nothing of this batch may still be running when its
     for (void* p : ptrs) ctx_free(b->ctx, p);                 // blocks go back to the spare list
     if (b->d_fetch) ctx_free(b->ctx, b->d_fetch);
-    if (b->h_args) (void)hipHostFree(b->h_args);
+    if (b->h_args) (void)vbx_host_free(b->h_args);
     if (b->ev_start) (void)hipEventDestroy(b->ev_start);
     if (b->ev_stop) (void)hipEventDestroy(b->ev_stop);
     for (auto& ep : b->ev_pool) {
@@ -276,7 +276,9 @@ static int leaf_set_option(vbx_batch* b, int option, int64_t value) {
 static int ensure_host_args(vbx_batch* b) {
     if (b->h_args) return VBX_OK;
     const size_t per = (size_t)2 * b->Dp + b->Sp + 2;         // {Phi, sqrt Phi, pi0, flags: Phi is here, pi0 is here}
-    HIPCHK(b->ctx, hipHostMalloc((void**)&b->h_args, sizeof(double) * per * b->n_rec, hipHostMallocDefault));
+    // (from the process-wide pool of pinned blocks, vbx_host_alloc: pinning and unpinning a block per batch cost a single VBx() call
+    //  of the example recording 0.25 of its 1.2 ms)
+    if (vbx_host_alloc(sizeof(double) * per * b->n_rec, (void**)&b->h_args) != VBX_OK) FAIL(b->ctx, VBX_ERR_HIP, "pinned argument block: %s", g_create_error.c_str());
     std::memset(b->h_args, 0, sizeof(double) * per * b->n_rec);
     b->gsum_pending.assign(b->n_rec, 0);
     b->args_busy.assign(b->n_rec, 0);
