@@ -18,10 +18,13 @@ for f in sys.argv[1:]:
         print('   single recording', round(d['single_recording']['ms_per_iteration'] * 1e3, 1), 'us per iteration')
     if 'cpu_baseline' in d:
         c = d['cpu_baseline']
-        print('   cpu_baseline', c['kind'], round(c['value'], 3), c['unit'], '| parity after 2 iterations', c['parity_after_2_iterations'])
+        par = c.get('parity_over_iterations') or c.get('parity_after_2_iterations')
+        print('   cpu_baseline', c['kind'], round(c['value'], 3), c['unit'], '| parity', {k: v for k, v in (par or {}).items() if k != 'note'})
+    if 'call_level' in d:
+        print('   call level', round(d['call_level']['ms_per_call'], 2), 'ms per VBx_batch call of', d['call_level']['iterations'], 'iterations,', round(d['call_level']['value']), 'rec-it/s')
     for k, v in d.get('configs', {}).items():
         if 'ms_per_call' in v:
             print(f'   {k:40s} {v["ms_per_call"]:.3f} ms per call, {v["iterations"]} iterations, gamma diff vs reference {v["gamma_max_abs_diff_vs_reference"]:.2e}')
         else:
             print(f'   {k:40s} {v["ms_per_iteration"]:.4f} ms/it {v["value"]:.0f} rec-it/s | {v["dominant_kernel"]} {v["avg_us"]:.1f} us frac {v["frac"]:.3f} '
-                  f'bound {v["bound"]} traffic {v["traffic"]}')
+                  f'bound {v.get("bound_today", v["bound"])} traffic {v["traffic"]}')
