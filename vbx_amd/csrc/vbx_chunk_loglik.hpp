@@ -27,8 +27,13 @@ template <typename R, int SP> struct ChunkLoglikCfg {
 #endif
 // SPLIT (fp32 only): the product on v_mfma_f32_16x16x32_f16 with f16 operand pairs (vbx_split.hpp) -- rho from its
 // fragment-ordered copy rho_a, alpha from the fragments fin_kernel wrote.
-template <typename R, int SP, bool SPLIT = false>
-__global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? (SPLIT && SP == 32 ? VBX_SPLIT_LOGLIK_WAVES : 8) : SP * (int)sizeof(R) <= 256 ? 4 : 2)) void chunk_loglik_kernel(BatchView<R> bt) {
+// LAT (round 6): the instance for batches that do not fill the chip.  There a launch's duration is one workgroup's life plus
+// what its bytes take at (bytes in flight) / (memory latency) -- and a workgroup that fetches its rho slab one K-block ahead has
+// a quarter of it in flight: 632 workgroups x 16 KB / 2 us = 5 TB/s whatever the memory system could deliver.  LAT requests the
+// whole slab before the first product (64 registers per lane: fine at three or four workgroups per CU) -- for Dp <= 128.
+template <typename R, int SP, bool SPLIT = false, bool LAT = false>
+__global__ __launch_bounds__(256, (LAT ? (SP * (int)sizeof(R) <= 128 ? 4 : 2)
+                                       : SP * (int)sizeof(R) <= 128 ? (SPLIT && SP == 32 ? VBX_SPLIT_LOGLIK_WAVES : 8) : SP * (int)sizeof(R) <= 256 ? 4 : 2)) void chunk_loglik_kernel(BatchView<R> bt) {
     static_assert(!SPLIT || sizeof(R) == 4, "the split GEMM is a mode of the fp32 path");
     using M = Mfma16<R>;
     using acc_t = typename M::acc_t;
@@ -98,7 +103,8 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? (SPLIT && SP == 
 #pragma unroll
             for (int n = 0; n < NT; ++n)
                 cscale[n] = scale2((R)1, -(e_rho + bt.alpha_e[(long long)par * bt.vec_stride + (long long)rec * SP + 16 * n + i]));
-            h8 a[2][2][2];                                 // [buffer][M-tile][hi | lo]
+            constexpr int NBUF = LAT ? 4 : 2;             // LAT: the whole slab (KK <= 4: the host launches LAT only then)
+            h8 a[NBUF][2][2];                              // [buffer][M-tile][hi | lo]
             auto load_a = [&](int buf, int kk) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
@@ -107,10 +113,18 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? (SPLIT && SP == 
                 }
             };
             load_a(0, 0);
+            if constexpr (LAT) {
+#pragma unroll
+                for (int kk = 1; kk < 4; ++kk)
+                    if (kk < KK) load_a(kk, kk);
+            }
             // (three terms of alpha per K-block: two K-blocks per staging round keep the slice inside the region b will take)
             constexpr int KS = 2;
-#pragma unroll 1
-            for (int kk0 = 0; kk0 < KK; kk0 += KS) {
+            // one staging round: the alpha terms of K-blocks [kk0, kk0 + KS) into LDS, then their products.  `kslot` = the A
+            // buffer of K-block kk0 (a compile-time constant in the LAT instance, whose rounds are unrolled: a register array
+            // indexed at run time would live in scratch memory)
+            auto round = [&](int kk0, auto slot0) {
+                constexpr int kSlot0 = decltype(slot0)::value;
                 const int nk = min(KS, KK - kk0);
                 if (kk0 > 0) __syncthreads();
 #pragma unroll
@@ -121,22 +135,30 @@ __global__ __launch_bounds__(256, (SP * (int)sizeof(R) <= 128 ? (SPLIT && SP == 
                 for (int kl = 0; kl < KS; ++kl) {
                     if (kl < nk) {
                         const int kk = kk0 + kl;
-                        if (kk + 1 < KK) load_a((kk + 1) & 1, kk + 1);
+                        if (!LAT && kk + 1 < KK) load_a((kl + 1) & 1, kk + 1);      // (kk0 is even: buffer = kl & 1)
+                        constexpr int kBufBase = LAT ? kSlot0 : 0;
 #pragma unroll
                         for (int n = 0; n < NT; ++n) {
                             const h8* bf = afl + (n * KS + kl) * 192 + lane;
                             const h8 bh = bf[0], bl = bf[64], bl2 = bf[128];
 #pragma unroll
                             for (int m = 0; m < 2; ++m)
-                                acc[m][n] = mfma_split3(a[kk & 1][m][0], a[kk & 1][m][1], bh, bl, bl2, acc[m][n]);
+                                acc[m][n] = mfma_split3(a[kBufBase + kl][m][0], a[kBufBase + kl][m][1], bh, bl, bl2, acc[m][n]);
                         }
                     }
                 }
+            };
+            if constexpr (LAT) {
+                round(0, std::integral_constant<int, 0>{});
+                if (KK > KS) round(KS, std::integral_constant<int, KS>{});
+            } else {
+#pragma unroll 1
+                for (int kk0 = 0; kk0 < KK; kk0 += KS) round(kk0, std::integral_constant<int, 0>{});
             }
         } else {
         // rows past the end of the recording are clamped (their results are never stored)
         const int rowA0 = min(f0 + i, rd.T - 1), rowA1 = min(f0 + 16 + i, rd.T - 1);
-        constexpr int QB = 2;                          // K blocks of 16 whose rho fragments are loaded together
+        constexpr int QB = LAT ? 4 : 2;   // K blocks of 16 whose rho fragments are loaded together (LAT: half a slice)
         // The speaker means (B operand) are staged in LDS once per workgroup, kAlphaSlice feature dims at a
         // time: every wave needs all of alpha, and fetching it per wave from L2 cost as much as streaming rho
         // (a CU sustains ~10 B/clk of global loads whether they hit L2 or HBM).

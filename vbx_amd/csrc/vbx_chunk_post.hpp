@@ -75,6 +75,11 @@ template <typename R, int SP> struct ChunkPostCfg {
 // chunk (at most kTileFrames / SP of them: the region r1 is free until the re-run starts), wave 0 walks forward from the group's
 // left edge, wave 1 backward from its right edge, with the very arithmetic of scan2 (walk_step).  One dependent launch fewer
 // per iteration where an iteration IS its launches (one recording of T = 10 000: 51.7 us in six launches).
+// The FOLD instances are the small-batch instances altogether: in split mode they also request the wave's whole rho slab of the
+// accumulation before the re-run starts (its registers exist anyway: occupancy stays at four): with a few hundred workgroups on
+// the chip a launch streams at (bytes in flight) / (latency), and one k-step of four in flight is a quarter of what the memory
+// system gives.  Measured (8 recordings): 66.2 -> 64.1 us per iteration.  NOT in exact f32 (232 registers: two workgroups per
+// CU, i.e. 512 slots for the 632 workgroups of eight recordings: 70.9 -> 79.9 us) nor in fp64.
 template <typename R, int SP, bool REPLAY, bool SPLIT = false, bool FOLD = false>
 __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post_kernel(BatchView<R> bt) {
     static_assert(!SPLIT || (sizeof(R) == 4 && !REPLAY), "the split GEMM is a mode of the fp32 iteration");
@@ -527,8 +532,21 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
                 bs[buf][h][1] = rb[((long long)(2 * slab + h) * 4 + kk) * 128 + 64];
             }
         };
+        constexpr bool kAllAhead = FOLD && SPLIT && !REPLAY;               // the small-batch split instances: the whole slab now
+        R2 bq_all[kAllAhead && !SPLIT ? 4 : 1][QK];
         if constexpr (SPLIT) {
-            if (wave * 32 < Dp) load_kstep(0, wave, 0);
+            if (wave * 32 < Dp) {
+                load_kstep(0, wave, 0);
+                if constexpr (kAllAhead) {
+#pragma unroll
+                    for (int kk = 1; kk < 4; ++kk) load_kstep(kk, wave, kk);
+                }
+            }
+        } else if constexpr (kAllAhead) {
+            if (wave * 32 < Dp) {
+#pragma unroll
+                for (int qi = 0; qi < 4; ++qi) load_quarter(bq_all[qi], wave, qi);
+            }
         } else {
             if (!REPLAY && wave * 32 < Dp) load_quarter(bq[0], wave, 0);
         }
@@ -669,7 +687,7 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
                 // pass are free: ONE exposed round trip in the accumulation instead of three (phase stamps, 64 recordings:
                 // the accumulation phase was 11.6 k of a workgroup's 41 k cycles, all of it waiting for these loads one
                 // k-step at a time)
-                if (wave * 32 < Dp) {
+                if (!kAllAhead && wave * 32 < Dp) {
 #pragma unroll
                     for (int kk = 1; kk < 4; ++kk) load_kstep(kk, wave, kk);
                 }
@@ -727,7 +745,7 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
                 acc[mu][1] = acc_t{0, 0, 0, 0};
                 nsum[mu] = 0;
             }
-            if (slab != wave) load_quarter(bq[0], slab, 0);
+            if (slab != wave || kAllAhead) { if (!(kAllAhead && slab == wave)) load_quarter(bq[0], slab, 0); }
             auto quarter = [&](const R2 (&bfr)[QK], int qi) {
 #pragma unroll
                 for (int u = 0; u < QK; ++u) {
@@ -742,12 +760,17 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
                     }
                 }
             };
+            if (kAllAhead && slab == wave) {                     // the small-batch instances: the slab has been in flight since the start
+#pragma unroll
+                for (int qi = 0; qi < 4; ++qi) quarter(bq_all[qi], qi);
+            } else {
 #pragma unroll 1
-            for (int pair = 0; pair < 2; ++pair) {               // (not unrolled: bounds how many LDS reads are hoisted)
-                load_quarter(bq[1], slab, 2 * pair + 1);         // next quarter in flight
-                quarter(bq[0], 2 * pair);
-                if (pair == 0) load_quarter(bq[0], slab, 2);
-                quarter(bq[1], 2 * pair + 1);
+                for (int pair = 0; pair < 2; ++pair) {           // (not unrolled: bounds how many LDS reads are hoisted)
+                    load_quarter(bq[1], slab, 2 * pair + 1);     // next quarter in flight
+                    quarter(bq[0], 2 * pair);
+                    if (pair == 0) load_quarter(bq[0], slab, 2);
+                    quarter(bq[1], 2 * pair + 1);
+                }
             }
             R* __restrict__ part = bt.mpart + (long long)tile * SP * Dp;
 #pragma unroll

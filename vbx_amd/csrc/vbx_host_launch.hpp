@@ -117,11 +117,18 @@ static int small_kernel_threads(const vbx_batch* b, int from_tiles) {
 // Does chunk_post walk the last level of the boundary walk itself (FOLD, vbx_chunk_post.hpp)?  Where an iteration is its launches:
 // a grouped walk, the group's operators fit the free LDS region, and the batch does not fill the chip (beyond that the extra
 // mat-vecs per workgroup cost more than the launch they replace).  VBX_AMD_FOLD_WALK=0 / 1 forces it off / on (A/B runs).
+// A batch that does not fill the chip: the small-batch instances of the chunk kernels (FOLD / LAT).  VBX_AMD_FOLD_WALK /
+// VBX_AMD_SMALL_BATCH = 0 / 1 force them off / on (A/B runs, under VBX_AMD_EXPERIMENT=1).
+static bool small_batch_wanted(const vbx_batch* b) {
+    static const int forced = [] { const char* e = experiment_env("VBX_AMD_SMALL_BATCH"); return (e && *e) ? (e[0] == '0' ? 0 : 1) : -1; }();
+    if (forced >= 0) return forced == 1;
+    return b->ntiles_total <= 2048;
+}
 template <int SP> bool fold_walk_wanted(const vbx_batch* b) {
     static const int forced = [] { const char* e = experiment_env("VBX_AMD_FOLD_WALK"); return (e && *e) ? (e[0] == '0' ? 0 : 1) : -1; }();
     if (SP > 32 || b->sgroup <= 1 || b->spt != 1 || b->sgroup - 1 > kTileFrames / SP) return false;
     if (forced >= 0) return forced == 1;
-    return b->ntiles_total <= 2048;
+    return small_batch_wanted(b);
 }
 
 template <typename R, int SP, bool REPLAY> void launch_chunk_post(vbx_batch* b, const BatchView<R>& v) {
@@ -157,12 +164,23 @@ template <typename R, int SP> void launch_scan(vbx_batch* b, const BatchView<R>&
         if (fused_loglik) {      // log-likelihoods and the chunk operators in one pass over rho
             LaunchScope ls(b, VBX_K_CHUNK_LOGLIK);
             bool launched = false;
+            // LAT: the whole rho slab of a workgroup in flight before the first product (vbx_chunk_loglik.hpp): batches that do
+            // not fill the chip, feature dimensions that fit the registers
+            const bool lat = SP <= 32 && b->Dp <= 128 && small_batch_wanted(b);
             if constexpr (std::is_same<R, float>::value) {
                 if (v.rho_a && (split_debug_mask() & 1)) {   // rho alpha^T on the f16 matrix cores (vbx_split.hpp)
-                    hipLaunchKernelGGL((chunk_loglik_kernel<R, SP, true>), dim3(b->nblocks_chunk), dim3(256), 0, st, v);
+                    if constexpr (SP <= 32) {
+                        if (lat) {
+                            hipLaunchKernelGGL((chunk_loglik_kernel<R, SP, true, true>), dim3(b->nblocks_chunk), dim3(256), 0, st, v);
+                            launched = true;
+                        }
+                    }
+                    if (!launched) hipLaunchKernelGGL((chunk_loglik_kernel<R, SP, true>), dim3(b->nblocks_chunk), dim3(256), 0, st, v);
                     launched = true;
                 }
             }
+            // (exact f32 and fp64: LAT measured slower -- 8 recordings 70.9 -> 79.9 / 117.6 -> 120.8 us per iteration together
+            //  with chunk_post's counterpart: the extra registers cost the occupancy these batches need; split only)
             if (!launched) hipLaunchKernelGGL((chunk_loglik_kernel<R, SP>), dim3(b->nblocks_chunk), dim3(256), 0, st, v);
             have_op = true;
         }
