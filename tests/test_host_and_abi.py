@@ -64,6 +64,12 @@ def test_no_gpu_means_a_loud_error_not_a_fallback():
     X = np.random.default_rng(0).standard_normal((10, 16))
     with pytest.raises(_capi.VbxError):
         vbx_amd.VBx(X, np.ones(16), pi=3, gamma=np.full((10, 3), 1 / 3), maxIters=2)
+    # the batch call and the pinned result blocks of ABI 7 alike: no device, no silent stand-in
+    from vbx_amd.batch import VBx_batch
+    with pytest.raises(_capi.VbxError):
+        VBx_batch([dict(X=X, Phi=np.ones(16), pi=3, gamma=np.full((10, 3), 1 / 3))], maxIters=2)
+    with pytest.raises(_capi.VbxError):
+        _capi.pinned_arrays([(4, 4)])
 
 
 def test_product_code_never_imports_the_oracle():
