@@ -109,7 +109,11 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
 #ifndef VBX_POST_REVERSE
 #define VBX_POST_REVERSE 1
 #endif
-    const int tile = (VBX_POST_REVERSE && !REPLAY && !bt.tile_order) ? bt.ntiles_total - 1 - (int)blockIdx.x : tile_of_block(bt, blockIdx.x);
+    // (round 6: only when the launch's working set is beyond the L2s -- 80 KB per tile against 8 x 4 MB.  A smaller batch keeps the
+    //  tile -> XCD map of chunk_loglik, block b on XCD b % 8, so that b and the half-tile operators are found in the L2 that wrote
+    //  them: one recording 46.9 -> 45.8 us per iteration, fp64 69.1 -> 67.1, two recordings 49.5 -> 48.2, eight: no difference)
+    const int tile = (VBX_POST_REVERSE && !REPLAY && !bt.tile_order && bt.ntiles_total > 512) ? bt.ntiles_total - 1 - (int)blockIdx.x
+                                                                                              : tile_of_block(bt, blockIdx.x);
     if (tile < 0 || (!REPLAY && bt.tile_done[tile])) return;
     VBX_CLOCKS_DECL();
     // (the wave index as a scalar: roles, frame ranges and loop bounds of the re-run stay in SGPRs)
