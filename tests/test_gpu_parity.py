@@ -520,6 +520,30 @@ def test_integration_md_ctypes_stub_runs_as_written(synth_cases, monkeypatch):
     assert np.allclose([r[0] for r in Li], c['Li'], rtol=1e-10)
 
 
+def test_integration_md_batch_binding_runs_as_written(monkeypatch):
+    """The batch binding INTEGRATION.md section 3 shows (ABI 7: enqueued uploads, one run, vbx_batch_get_results into pinned
+    blocks) is executable as printed and gives what one VBx() call per recording gives."""
+    import re
+    import vbx_amd
+    from vbx_amd.synth import make_recording
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, 'INTEGRATION.md')).read()
+    block = [b for b in re.findall(r'```python\n(.*?)```', text, flags=re.S) if 'def VBx_many' in b][0]
+    monkeypatch.chdir(root)
+    ns = {}
+    exec(block, ns)
+    recs = []
+    for k, (T, S) in enumerate([(900, 7), (1400, 12), (300, 4)]):
+        X, Phi, _ = make_recording(T, S, D=64, seed=90 + k, kappa=0.05)
+        g = np.random.default_rng(k).gamma(1.0, size=(T, S))
+        g /= g.sum(1, keepdims=True)
+        recs.append((np.ascontiguousarray(X), np.ascontiguousarray(Phi), np.ones(S) / S, g))
+    got = ns['VBx_many'](recs, 0.9, 0.3, 17.0, 6, -1e300)
+    for (X, Phi, pi, g), (gg, gp, gL) in zip(recs, got):
+        wg, wp, wL = vbx_amd.VBx(X, Phi, loopProb=0.9, Fa=0.3, Fb=17.0, pi=pi, gamma=g, maxIters=6, epsilon=-1e300, precision='fp64')
+        assert np.array_equal(gg, wg) and np.array_equal(gp, wp) and np.array_equal(np.array(gL), np.array(wL))
+
+
 def _properties(res, precision, name):
     np.testing.assert_allclose(res['gamma'].sum(1), 1.0, atol=1e-5, err_msg=name)
     np.testing.assert_allclose(res['pi'].sum(), 1.0, atol=1e-9, err_msg=name)
