@@ -76,10 +76,11 @@ template <typename R, int SP> struct ChunkPostCfg {
 // left edge, wave 1 backward from its right edge, with the very arithmetic of scan2 (walk_step).  One dependent launch fewer
 // per iteration where an iteration IS its launches (one recording of T = 10 000: 51.7 us in six launches).
 // The FOLD instances are the small-batch instances altogether: in split mode they also request the wave's whole rho slab of the
-// accumulation before the re-run starts (its registers exist anyway: occupancy stays at four): with a few hundred workgroups on
-// the chip a launch streams at (bytes in flight) / (latency), and one k-step of four in flight is a quarter of what the memory
-// system gives.  Measured (8 recordings): 66.2 -> 64.1 us per iteration.  NOT in exact f32 (232 registers: two workgroups per
-// CU, i.e. 512 slots for the 632 workgroups of eight recordings: 70.9 -> 79.9 us) nor in fp64.
+// accumulation in one go, when the re-run is over and before the posterior pass (its registers exist anyway: occupancy stays at
+// four; round 5 requested one k-step there and the other three after the pass): with a few hundred workgroups on the chip a
+// launch streams at (bytes in flight) / (latency).  Measured (8 recordings): 66.2 -> 64.1 us per iteration.  NOT in exact f32
+// (232 registers: two workgroups per CU, i.e. 512 slots for the 632 workgroups of eight recordings: 70.9 -> 79.9 us) nor in
+// fp64.  Since the end of round 6 every split instance with SP >= 32 does the same (kAllAhead below).
 template <typename R, int SP, bool REPLAY, bool SPLIT = false, bool FOLD = false>
 __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post_kernel(BatchView<R> bt) {
     static_assert(!SPLIT || (sizeof(R) == 4 && !REPLAY), "the split GEMM is a mode of the fp32 iteration");
@@ -536,7 +537,15 @@ __global__ __launch_bounds__(256, (ChunkPostCfg<R, SP>::kPerCU)) void chunk_post
                 bs[buf][h][1] = rb[((long long)(2 * slab + h) * 4 + kk) * 128 + 64];
             }
         };
-        constexpr bool kAllAhead = FOLD && SPLIT && !REPLAY;               // the small-batch split instances: the whole slab now
+        // Split mode: the wave's whole slab of the accumulation is requested NOW, between the re-run and the posterior pass (its
+        // registers exist anyway; at SP = 16 the instance would spill).  Round 5 requested k-step 0 here and k-steps 1-3 after the
+        // pass; with the streams of a big batch side by side the earlier request measured 0.2315 / 0.2319 / 0.2340 -> 0.2249 / 0.2258 / 0.2275 ms per step (three
+        // A/B pairs in one call; on ONE stream 0.2603 -> 0.2629: the loads of a lone launch queue up behind each other), the C5
+        // sweep 1.421 -> 1.408; small batches: see FOLD above
+#ifndef VBX_POST_ALLAHEAD
+#define VBX_POST_ALLAHEAD 1
+#endif
+        constexpr bool kAllAhead = (FOLD || (VBX_POST_ALLAHEAD && SP >= 32)) && SPLIT && !REPLAY;
         R2 bq_all[kAllAhead && !SPLIT ? 4 : 1][QK];
         if constexpr (SPLIT) {
             if (wave * 32 < Dp) {
