@@ -6,7 +6,7 @@ extern "C" {
 // ---------------------------------------------------------------------------------------
 // public batch API: a plain batch (one stream) or a stream group of plain batches
 // ---------------------------------------------------------------------------------------
-static int auto_streams(int n_rec, long long tiles) {
+static int auto_streams(int n_rec, long long tiles, int max_iters) {
     const char* env = std::getenv("VBX_AMD_STREAMS");
     if (env && *env) {
         const int k = std::atoi(env);
@@ -15,7 +15,19 @@ static int auto_streams(int n_rec, long long tiles) {
     // measured on 64 recordings of T = 10 000 (NOTES.md, rounds 1-2): 1 / 2 / 3 / 4 streams = 341 / 321 / 312 / 334 us per
     // iteration (three is the robust optimum: the fourth stream brought nothing in any queue configuration tried)
     // -- and only when every stream still has several rounds of workgroups per launch (a chunk = one workgroup)
-    return (n_rec >= 24 && tiles >= 1536) ? 3 : (n_rec >= 12 && tiles >= 768) ? 2 : 1;
+    if (n_rec >= 24 && tiles >= 1536) return 3;
+    // Batches that do not fill the chip (round 6, NOTES.md): an iteration there is five dependent launches, each as long as one
+    // of its workgroups lives, and two or three sub-batches of >= 150 chunks each run theirs in each other's shadow -- 8
+    // recordings of T = 10 000: 63.9 / 60.9 / 57.4 us per iteration on 1 / 2 / 3 streams (fp64 116.8 / 108.9 / 97.8), 4: 54.2 /
+    // 50.9, 16: 95.1 / 82.2 / 76.7, 2 x T = 50 000: 91.9 / 84.0; below 150 chunks per stream nothing (8 x T = 2000: 37.9 / 39.5 /
+    // 40.5).  A group costs 0.2-0.5 ms per batch (threads, sub-batches, one more synchronize per stream): it pays from about
+    // forty iterations, so a batch created for fewer (max_iters: one VBx_batch call with the reference's default of 10)
+    // keeps the rule of rounds 1-5.
+    if (max_iters >= 40) {
+        const int k = (int)std::min<long long>(std::min(3, n_rec), tiles / 150);
+        if (k >= 2) return k;
+    }
+    return (n_rec >= 12 && tiles >= 768) ? 2 : 1;
 }
 
 static void group_stop_threads(vbx_batch* b) {
@@ -181,7 +193,7 @@ int vbx_batch_create_streams(vbx_ctx* ctx, int n_rec, const int64_t* T, const in
     if (streams < 0 || streams > 8) FAIL(ctx, VBX_ERR_INVALID, "vbx_batch_create_streams: streams takes 0 (auto) .. 8");
     long long tiles = 0;
     for (int i = 0; i < n_rec; ++i) tiles += T[i] > 0 ? (T[i] + kTileFrames - 1) / kTileFrames : 0;
-    const int K = streams == 0 ? auto_streams(n_rec, tiles) : std::min(streams, n_rec);
+    const int K = streams == 0 ? auto_streams(n_rec, tiles, max_iters) : std::min(streams, n_rec);
     if (K <= 1) return leaf_create(ctx, n_rec, T, S, D, precision, max_iters, out);
     *out = nullptr;
     vbx_batch* b = new vbx_batch();
@@ -217,7 +229,7 @@ int vbx_batch_set_option(vbx_batch* b, int option, int64_t value) {
         const bool group = !b->kids.empty();
         long long tiles = 0;
         for (int64_t t : b->all_T) tiles += (t + kTileFrames - 1) / kTileFrames;
-        const int want = value == 0 ? auto_streams(b->n_rec, tiles) : (int)std::min<int64_t>(value, b->n_rec);
+        const int want = value == 0 ? auto_streams(b->n_rec, tiles, b->max_iters) : (int)std::min<int64_t>(value, b->n_rec);
         const int have = group ? (int)b->kids.size() : 1;
         if (want == have) return VBX_OK;
         if (!group) FAIL(b->ctx, VBX_ERR_STATE, "VBX_OPT_STREAMS: this batch was created on one stream and cannot be regrouped: "
