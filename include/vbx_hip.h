@@ -63,10 +63,13 @@ extern "C" {
                                    2*mask: only the kernel classes whose bit (1 << VBX_K_*) is set in mask */
 #define VBX_OPT_CHUNK_FRAMES 4  /* frames per scan chunk for VBX_FB_CHUNKED (0 = auto)         */
 #define VBX_OPT_SCAN_GROUP 6    /* chunks per group of the two-level boundary walk: 0 auto (sqrt(chunks / 5) once a
-                                   recording has >= 160 chunks, or >= 32 in a batch of <= 16), 1 flat chain, >= 2 explicit */
+                                   recording has >= 160 chunks, or >= 32 in a batch of <= 16; at most 128 / Sp + 1 where
+                                   chunk_post walks the last level itself: up to 32 padded states in a batch of <= 2048
+                                   chunks), 1 flat chain, >= 2 explicit */
 #define VBX_OPT_SCAN_GROUP2 12   /* groups per level-2 group of the THREE-level walk: 0 auto (from 300 chunks per recording --
                                    T = 38 400 -- both group sizes become (chunks / 8)^(1/3) + 1), 1 off, >= 2 explicit (on top of
-                                   the VBX_OPT_SCAN_GROUP in effect)                                                     */
+                                   the VBX_OPT_SCAN_GROUP in effect).  Where chunk_post walks the last level itself and the
+                                   cube root is too long for it, up to 1200 chunks: 128 / Sp + 1 and sqrt(chunks / (5 group)) */
 #define VBX_OPT_THREE_LEVEL_FROM 13 /* chunk count from which VBX_OPT_SCAN_GROUP2 = 0 adds the third level            */
 #define VBX_OPT_SPLIT_TILES 11  /* fused path: tiles re-run as two halves side by side (four 64-frame chains per tile instead of two
                                    128-frame ones; chunk_loglik hands the half-tile operators over).  0 = auto (on), 1 = on,

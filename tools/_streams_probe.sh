@@ -1,10 +1,18 @@
 cd $GRAFT_REPO_ROOT
+HEAD_LIB=$GRAFT_REPO_ROOT/build/libvbx_head.so
 {
-for shape in "2 10000" "3 10000" "4 10000" "5 10000" "6 10000" "8 10000" "10 10000" "12 10000" "16 10000" "20 10000" "8 2000" "2 50000" "1 50000"; do
+for shape in "1 10000 30" "1 20000 30" "1 30000 30" "1 38000 30" "1 50000 30" "1 70000 30" "1 100000 30" "1 120000 30" "1 150000 30" "1 200000 30" "1 50000 10" "1 100000 10" "2 30000 30" "4 20000 30"; do
   set -- $shape
-  timeout 120 python tools/ab_quick.py --batch $1 --T $2 --iters 400 --reps 4 2>&1 | tail -1
+  echo "--- $shape head / new"
+  VBX_AMD_LIB=$HEAD_LIB timeout 120 python tools/ab_quick.py --batch $1 --T $2 --S $3 --iters 400 --reps 4 2>&1 | tail -1
+  timeout 120 python tools/ab_quick.py --batch $1 --T $2 --S $3 --iters 400 --reps 4 2>&1 | tail -1
 done
-for p in fp32 fp64; do for n in 4 8 16; do timeout 120 python tools/ab_quick.py --batch $n --iters 300 --reps 3 --precision $p 2>&1 | tail -1; done; done
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "stream or group or shared or batch" 2>&1 | tail -3
-} > gpurun_out/streams_probe3.txt 2>&1
-cat gpurun_out/streams_probe3.txt
+for shape in "1 30000 30" "1 100000 30"; do
+  set -- $shape
+  echo "--- fp64 $shape head / new"
+  VBX_AMD_LIB=$HEAD_LIB timeout 120 python tools/ab_quick.py --batch $1 --T $2 --S $3 --iters 300 --reps 4 --precision fp64 2>&1 | tail -1
+  timeout 120 python tools/ab_quick.py --batch $1 --T $2 --S $3 --iters 300 --reps 4 --precision fp64 2>&1 | tail -1
+done
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_trajectory.py -x -q -m gpu -k "walk or long or trajectory and c3 or level" 2>&1 | tail -3
+} > gpurun_out/walk_probe2.txt 2>&1
+cat gpurun_out/walk_probe2.txt

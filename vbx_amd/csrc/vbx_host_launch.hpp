@@ -476,6 +476,13 @@ int choose_fb_algo(vbx_batch* b, bool step_api_logs) {
         else if (b->scan_group == 0 && (maxchunks >= b->two_level_from || (b->n_rec <= 16 && maxchunks >= 32)))
             group = g_auto;
     }
+    // Round 6: where chunk_post walks the last level itself (FOLD: groups of at most kTileFrames / Sp + 1 chunks) that level
+    // costs no launch, so the automatic group size stops there: one recording of T = 20 000 / 30 000 (g = 6 / 7 before, last
+    // level a launch of its own) 57.5 -> 54.9 / 64.0 -> 62.0 us per iteration.
+    static const bool fold_off = [] { const char* e = experiment_env("VBX_AMD_FOLD_WALK"); return e && e[0] == '0'; }();
+    const int fold_max = kTileFrames / std::max(b->Sp, 1) + 1;
+    const bool may_fold = group > 1 && fused1 && spt == 1 && b->Sp <= 32 && !fold_off && small_batch_wanted(b) && b->scan_group == 0;
+    if (may_fold) group = std::min(group, fold_max);
     // Third level: with products worth ~4 walk steps the chain 4 (g - 1) + 4 (g2 - 1) + K / (g g2) + g2 + g is shortest
     // near g = g2 = (K / 8)^(1/3) rounded up: K = 1563 (T = 200 000): 7 x 7 -> 94 step equivalents against 173 on two
     // levels; K = 391 (T = 50 000): 56 against 84 -- measured walk 36.0 -> 33.7 us (fp64 47.8 -> 39.8), T = 70 000: 40.5 ->
@@ -485,6 +492,14 @@ int choose_fb_algo(vbx_batch* b, bool step_api_logs) {
         if (b->scan_group2 >= 2) group2 = b->scan_group2;
         else if (b->scan_group2 == 0 && b->scan_group == 0 && maxchunks >= b->three_level_from) {
             group = group2 = std::max(4, (int)std::ceil(std::cbrt((double)maxchunks / 8.0)) + 1);
+            // (a first level that folds, and the second as long as the chain 4 (g2 - 1) + K / (g g2) + g2 likes it: T = 100 000 /
+            //  120 000, (6, 6) -> (5, 6): 102.3 -> 100.7 / 106.6 -> 104.4 us; from 1200 chunks the cube root wins: T = 200 000,
+            //  (7, 7) 148.6 against (5, 8) 150.6.  A two-level walk with a folded first level loses from 300 chunks:
+            //  T = 50 000 81.8 against 75.5, T = 100 000 125 against 102)
+            if (may_fold && group > fold_max && maxchunks < 1200) {
+                group = fold_max;
+                group2 = std::max(5, (int)std::lround(std::sqrt((double)maxchunks / (5.0 * group))));
+            }
         }
     }
     if (group != b->sgroup || group2 != b->sgroup2 || spt != b->spt || (group > 1 && !b->d_sop) || (group2 > 1 && !b->d_sop2)) {
