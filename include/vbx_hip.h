@@ -77,7 +77,8 @@ extern "C" {
 #define VBX_OPT_STREAMS 10      /* HIP streams of a batch: its recordings are dealt to that many sub-batches, one
                                    iteration of each is launched stream after stream, so the latency-bound launches of
                                    one overlap the bandwidth-bound ones of the others.  0 = auto (3 from 24 recordings and
-                                   1536 chunks, 2 from 12 and 768, else 1; env VBX_AMD_STREAMS overrides).  Before the
+                                   1536 chunks; a batch created for max_iters >= 40: min(3, recordings, chunks / 150) if
+                                   that is >= 2; else 2 from 12 recordings and 768 chunks, else 1; env VBX_AMD_STREAMS overrides).  Before the
                                    first recording. */
 #define VBX_OPT_TWO_LEVEL_FROM 8 /* chunk count from which VBX_OPT_SCAN_GROUP = 0 picks the two-level walk           */
 #define VBX_OPT_GEMM 14         /* how the fp32 path multiplies rho alpha^T (VBx.py:97) and gamma^T rho (VBx.py:96):
@@ -131,8 +132,8 @@ int vbx_device_info(vbx_ctx* ctx, char* name, int cap, int* compute_units, int64
 int vbx_batch_create(vbx_ctx* ctx, int n_rec, const int64_t* T, const int32_t* S, int32_t D,
                      int precision, int max_iters, vbx_batch** out);
 /* The same with the number of HIP streams (sub-batches, VBX_OPT_STREAMS) chosen at creation: 0 = the library's choice as
- * vbx_batch_create makes it (three streams from 24 recordings and 1536 chunks, two from 12 and 768, else one; env
- * VBX_AMD_STREAMS overrides), 1 .. 8 = that many (at most one per recording).  A batch created on one stream by the
+ * vbx_batch_create makes it (VBX_OPT_STREAMS: three streams from 24 recordings and 1536 chunks, for max_iters >= 40 also two or
+ * three from 150 chunks per stream, else two from 12 recordings and 768 chunks, else one; env VBX_AMD_STREAMS overrides), 1 .. 8 = that many (at most one per recording).  A batch created on one stream by the
  * automatic choice cannot be regrouped later (VBX_OPT_STREAMS regroups stream groups only): a sweep over one long recording
  * -- few "recordings", many chunks -- asks for its streams here (vbx_batch_set_recording_shared).  ABI 6. */
 int vbx_batch_create_streams(vbx_ctx* ctx, int n_rec, const int64_t* T, const int32_t* S, int32_t D,

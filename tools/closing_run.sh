@@ -23,6 +23,6 @@ python tools/call_breakdown.py fp32-split 40 >> $out/${r}_call_level.jsonl 2>&1
 python tools/one_step_error.py c5 1 2 3 > $out/${r}_one_step_error.txt 2>&1
 python tools/one_step_error.py hl 0 1 2 >> $out/${r}_one_step_error.txt 2>&1
 cp $out/trajectory_parity.json $out/${r}_trajectory_parity.json 2>/dev/null
-(cd /tmp && export TMPDIR=/tmp && for nb in 1 8; do timeout 300 rocprofv3 --kernel-trace -d /tmp/gap$nb -o trace -- python $GRAFT_REPO_ROOT/tools/profile_target.py --batch $nb --precision fp32-split --iters 300 > /dev/null 2>&1; python $GRAFT_REPO_ROOT/tools/launch_gaps.py /tmp/gap$nb/trace_results.db $GRAFT_REPO_ROOT/$out/${r}_launch_gaps_b$nb.txt > /dev/null; done)
+(cd /tmp && export TMPDIR=/tmp && for nb in 1 8; do timeout 300 rocprofv3 --kernel-trace -d /tmp/gap$nb -o trace -- python $GRAFT_REPO_ROOT/tools/profile_target.py --batch $nb --precision fp32-split --iters 300 --streams 1 > /dev/null 2>&1; python $GRAFT_REPO_ROOT/tools/launch_gaps.py /tmp/gap$nb/trace_results.db $GRAFT_REPO_ROOT/$out/${r}_launch_gaps_b$nb.txt > /dev/null; done)
 python tools/bench_summary.py $out/${r}_bench_default.json $out/${r}_bench_driver_args.json | cut -c1-200
 du -sh $out | tail -1

@@ -33,7 +33,7 @@ for p in fp32 fp32-split fp64; do
   s=$(echo $p | sed -e 's/fp32-split/split/' -e 's/fp//')
   run c2_$s 1 --batch 1 --T 10000 --S 10 --precision $p
   run c3_$s 1 --batch 1 --T 50000 --S 30 --precision $p
-  run c4x8_$s 1 --batch 8 --T 10000 --S 30 --precision $p
+  run c4x8_$s 1 --batch 8 --T 10000 --S 30 --precision $p --streams 1
   run c5_shared_$s 1 --sweep shared --T 200000 --S 50 --precision $p
 done
 run c5_private_32 1 --sweep private --T 200000 --S 50 --precision fp32
