@@ -65,7 +65,7 @@ extern "C" {
 #define VBX_OPT_SCAN_GROUP 6    /* chunks per group of the two-level boundary walk: 0 auto (sqrt(chunks / 5) once a
                                    recording has >= 160 chunks, or >= 32 in a batch of <= 16; at most 128 / Sp + 1 where
                                    chunk_post walks the last level itself: up to 32 padded states in a batch of <= 2048
-                                   chunks), 1 flat chain, >= 2 explicit */
+                                   chunks; 64 < Sp <= 256: sqrt(chunks / 3.5) from 40 chunks), 1 flat chain, >= 2 explicit */
 #define VBX_OPT_SCAN_GROUP2 12   /* groups per level-2 group of the THREE-level walk: 0 auto (from 300 chunks per recording --
                                    T = 38 400 -- both group sizes become (chunks / 8)^(1/3) + 1), 1 off, >= 2 explicit (on top of
                                    the VBX_OPT_SCAN_GROUP in effect).  Where chunk_post walks the last level itself and the

@@ -1254,3 +1254,90 @@ def test_a_batch_slot_set_again_with_another_loop_probability(ctx):
         assert np.abs(a['gamma'] - gr).max() <= 2e-8, (lp, np.abs(a['gamma'] - gr).max())
         assert rel_err(a['Li'], [r[0] for r in Lr]) <= 1e-10, lp
     batch.close()
+
+
+def test_small_batches_get_stream_groups_when_created_for_long_runs(ctx):
+    """vbx_batch_create's automatic stream count (vbx_host_group.hpp, round 6): a batch that does not fill the chip runs as
+    two or three sub-batches of >= 150 chunks each when it is created for 40 iterations or more, on one stream for fewer;
+    the results are those of the single stream."""
+    from vbx_amd import _capi
+    from vbx_amd.synth import make_recording
+    n, T, S = 8, 5000, 12                                     # 8 x 40 chunks = 320: two streams of 160
+    recs = []
+    for i in range(n):
+        X, Phi, _ = make_recording(T - 17 * i, S, seed=40 + i, kappa=0.05, dtype=np.float32)
+        g = np.random.default_rng(4000 + i).gamma(1.0, size=(T - 17 * i, S))
+        recs.append((X, Phi, g / g.sum(1, keepdims=True)))
+    res = {}
+    for label, max_iters, streams in (('few', 10, None), ('many', 40, None), ('one', 40, 1)):
+        batch = _capi.Batch(ctx, [r[0].shape[0] for r in recs], [S] * n, 128, precision='fp32', max_iters=max_iters, streams=streams)
+        assert batch.streams == {'few': 1, 'many': 2, 'one': 1}[label], (label, batch.streams)
+        for i, (X, Phi, g) in enumerate(recs):
+            batch.set_recording(i, X, Phi, np.ones(S) / S, g, 0.9, 0.3, 17.0)
+        batch.run(6, -np.inf)
+        res[label] = [batch.result(i) for i in range(n)]
+        batch.close()
+    for i in range(n):
+        for key in ('gamma', 'pi', 'Li', 'alpha', 'invL'):
+            assert np.allclose(res['many'][i][key], res['one'][i][key], rtol=1e-6, atol=1e-7), (i, key)
+            assert np.allclose(res['few'][i][key], res['one'][i][key], rtol=1e-6, atol=1e-7), (i, key)
+    # three streams need 450 chunks, and at least 150 per stream whatever the number of recordings
+    for T_each, n_rec, want in ((10000, 8, 3), (10000, 3, 1), (2000, 8, 1), (50000, 2, 2), (10000, 1, 1)):
+        batch = _capi.Batch(ctx, [T_each] * n_rec, [S] * n_rec, 128, precision='fp32', max_iters=64)
+        assert batch.streams == want, (T_each, n_rec, batch.streams)
+        batch.close()
+
+
+@pytest.mark.parametrize('precision,tol', [('fp64', 1e-9), ('fp32', 2e-5)])
+def test_automatic_walk_groups_fold_and_agree_with_the_flat_chain(ctx, precision, tol):
+    """The automatic group size of the boundary walk stops where chunk_post can walk the last level itself (128 / Sp + 1
+    chunks: vbx_host_launch.hpp, round 6) -- T = 20 000 and 30 000 used to get groups of 6 and 7 -- and on three levels the
+    first level folds up to 1200 chunks (T = 70 000: (5, 5) instead of (6, 6)).  Same posteriors as the flat chain."""
+    from vbx_amd import _capi
+    from vbx_amd.synth import make_recording
+    for T in (20000, 70000):
+        S = 20
+        X, Phi, _ = make_recording(T, S, seed=7, kappa=0.05, dtype=np.float32)
+        g = np.random.default_rng(77).gamma(1.0, size=(T, S))
+        g /= g.sum(1, keepdims=True)
+        out = {}
+        for label in ('auto', 'flat'):
+            batch = _capi.Batch(ctx, [T], [S], 128, precision=precision, max_iters=3)
+            if label == 'flat':
+                batch.set_option(_capi.OPT_SCAN_GROUP, 1)
+            batch.set_recording(0, X, Phi, np.ones(S) / S, g, 0.9, 0.3, 17.0)
+            batch.run(3, -np.inf)
+            out[label] = batch.result(0)
+            batch.close()
+        assert np.abs(out['auto']['gamma'] - out['flat']['gamma']).max() <= tol, T
+        assert np.abs(out['auto']['pi'] - out['flat']['pi']).max() <= tol, T
+        assert abs(out['auto']['Li'][-1] - out['flat']['Li'][-1]) <= 1e-6 * abs(out['flat']['Li'][-1]), T
+
+
+@pytest.mark.parametrize('S', [100, 130, 256])
+@pytest.mark.parametrize('precision,tol', [('fp64', 1e-9), ('fp32', 2e-5)])
+def test_wide_two_level_walk_equals_the_flat_chain(ctx, S, precision, tol):
+    """64 < S <= 256: groups of chunk operators (compose_wide_kernel) + the walk over the groups + the walks inside them
+    (vbx_scan_wide.hpp, round 6) against the flat chain of K - 1 mat-vecs: explicit group sizes including one that leaves a
+    ragged last group and one larger than the recording, and the automatic choice (two levels from 40 chunks)."""
+    from vbx_amd import _capi
+    from vbx_amd.synth import make_recording
+    T = 7001                                                   # 55 chunks, the last one of 89 frames
+    X, Phi, _ = make_recording(T, S, seed=S, kappa=0.05, dtype=np.float32)
+    g0 = np.random.default_rng(S + 5).gamma(1.0, size=(T, S))
+    g0 /= g0.sum(1, keepdims=True)
+    out = {}
+    for group in (1, 0, 2, 7, 64):
+        batch = _capi.Batch(ctx, [T, 300], [S, S], 128, precision=precision, max_iters=3)
+        batch.set_option(_capi.OPT_SCAN_GROUP, group)
+        batch.set_recording(0, X, Phi, np.ones(S) / S, g0, 0.95, 0.3, 17.0)
+        batch.set_recording(1, X[:300], Phi, np.ones(S) / S, g0[:300], 0.95, 0.3, 17.0)      # (three chunks: groups of one recording only)
+        batch.run(3, -np.inf)
+        out[group] = [batch.result(i) for i in range(2)]
+        batch.close()
+    for group in (0, 2, 7, 64):
+        for i in range(2):
+            a, b = out[group][i], out[1][i]
+            assert np.abs(a['gamma'] - b['gamma']).max() <= tol, (group, i, np.abs(a['gamma'] - b['gamma']).max())
+            assert np.abs(a['pi'] - b['pi']).max() <= tol, (group, i)
+            assert rel_err(a['Li'], b['Li']) <= (1e-12 if precision == 'fp64' else 1e-6), (group, i)

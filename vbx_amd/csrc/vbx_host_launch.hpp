@@ -230,7 +230,13 @@ template <typename R, int SP> void launch_scan_wide(vbx_batch* b, const BatchVie
     }
     {
         LaunchScope ls(b, VBX_K_FB_AUX);
-        hipLaunchKernelGGL((scan2_wide_kernel<R, SP, 16>), dim3(b->n_rec, 2), dim3(1024), 0, st, v);
+        if (b->sgroup > 1) {     // group operators, boundaries at the group edges, then inside the groups (as launch_scan does)
+            hipLaunchKernelGGL((compose_wide_kernel<R, SP>), dim3(b->nsup_total, SP / ComposeWideCfg<R, SP>::CW), dim3(256), 0, st, v);
+            hipLaunchKernelGGL((scan2_wide_kernel<R, SP, 16>), dim3(b->n_rec, 2), dim3(1024), 0, st, v, 2);
+            hipLaunchKernelGGL((scan2_wide_kernel<R, SP, 16>), dim3(b->nsup_total, 2), dim3(1024), 0, st, v, 3);
+        } else {
+            hipLaunchKernelGGL((scan2_wide_kernel<R, SP, 16>), dim3(b->n_rec, 2), dim3(1024), 0, st, v, 0);
+        }
     }
     {
         LaunchScope ls(b, VBX_K_FB);
@@ -475,6 +481,16 @@ int choose_fb_algo(vbx_batch* b, bool step_api_logs) {
         //  25.3 -> 20.5 / 21.6 / 22.5 / 25.4 / 32.5 us, iteration 73.7 -> 69.1, 95.7 -> 90.0, then no gain: up to 16 recordings)
         else if (b->scan_group == 0 && (maxchunks >= b->two_level_from || (b->n_rec <= 16 && maxchunks >= 32)))
             group = g_auto;
+    }
+    // The wide scan (64 < Sp <= 256, round 6): a walk step there is 0.95 us (fp32) / 1.6 us (fp64) at Sp = 128 and a product of
+    // compose_wide_kernel 2.4 us, so the chain (g - 1) products + K / g + g steps is shortest near sqrt(K / 3.5) -- measured,
+    // one recording at S = 128, ms per iteration with the flat chain / groups of 4 / 5 / 6 / 8 at T = 10 000: 0.193 / 0.161 /
+    // 0.161 / 0.164 / 0.169 (fp64 0.310 / 0.246 / 0.247 / 0.253 / 0.263); flat / 6 / 8 / 10 / 14 / 20 at T = 50 000: 0.616 / 0.371
+    // / 0.359 / 0.356 / 0.354 / 0.371 (fp64 1.103 / 0.677 / 0.640 / 0.637 / 0.633 / 0.671); T = 3000 (24 chunks): 0.123 flat
+    // against 0.127 in groups of 4 -- the two extra launches are paid from about 40 chunks.
+    if (chunked && b->Sp > 64 && b->Sp <= 256) {
+        if (b->scan_group >= 2) group = b->scan_group;
+        else if (b->scan_group == 0 && maxchunks >= 40) group = std::max(4, (int)std::lround(std::sqrt((double)maxchunks / 3.5)));
     }
     // Round 6: where chunk_post walks the last level itself (FOLD: groups of at most kTileFrames / Sp + 1 chunks) that level
     // costs no launch, so the automatic group size stops there: one recording of T = 20 000 / 30 000 (g = 6 / 7 before, last

@@ -158,8 +158,11 @@ template <typename R, int SP, int NW> struct WalkWideCfg {
     static_assert(NW * 64 >= SP, "the first SP threads carry the vector");
 };
 
+// `level` as in scan2_kernel (vbx_scan.hpp): 0 the flat chain over a recording's chunk operators (grid.x = recording), 2 over
+// its GROUP operators (compose_wide_kernel below; boundaries at the group edges), 3 inside one group from the boundary level 2
+// left at its edge (grid.x = group).  Chain step n uses operator op0 + n os of `ops` and writes boundary b0 + (n + 1) bs.
 template <typename R, int SP, int NW>
-__global__ __launch_bounds__(NW * 64) void scan2_wide_kernel(BatchView<R> bt) {
+__global__ __launch_bounds__(NW * 64) void scan2_wide_kernel(BatchView<R> bt, int level) {
     using Cfg = WalkWideCfg<R, SP, NW>;
     constexpr int VEC = Cfg::VEC, EPI = Cfg::EPI, RPI = Cfg::RPI, NG = Cfg::NG, LPR = Cfg::LPR, RPW = Cfg::RPW, IPW = Cfg::IPW;
     constexpr int D = Cfg::D, CHI = Cfg::CHI;
@@ -168,25 +171,43 @@ __global__ __launch_bounds__(NW * 64) void scan2_wide_kernel(BatchView<R> bt) {
     __shared__ __attribute__((aligned(16))) R vec[SP];         // the vector being pushed through the chain (weights, forward)
     __shared__ __attribute__((aligned(16))) R part[NW * SP];   // forward: per wave and column; backward: per row
     __shared__ int wmax[SP / 64];
-    const int rec = blockIdx.x, dir = blockIdx.y;
+    const int rec = level == 3 ? bt.sup_rec[blockIdx.x] : blockIdx.x, dir = blockIdx.y;
     if (bt.state[rec].done) return;
     const RecDesc rd = bt.recs[rec];
-    const int K = rd.ntiles;
+    const int K = rd.ntiles, G = bt.sgroup;
     const long long cb0 = rd.tile0;
+    const R* __restrict__ ops = bt.op;
+    const int* __restrict__ oexp = bt.opexp;
+    int nops = K - 1, os = dir == 0 ? 1 : -1, bs = os;
+    long long op0 = dir == 0 ? cb0 : cb0 + K - 1, b0 = op0, binit = op0;
+    if (level == 2) {
+        const int ns = (K + G - 1) / G;
+        ops = bt.sop;
+        oexp = bt.sopexp;
+        nops = ns - 1;
+        op0 = dir == 0 ? rd.sup0 : rd.sup0 + ns - 1;
+        bs = dir == 0 ? G : -G;
+        b0 = dir == 0 ? cb0 : cb0 + (long long)ns * G - 1;
+    } else if (level == 3) {
+        const long long a = cb0 + (long long)bt.sup_idx[blockIdx.x] * G, b = min(a + G, cb0 + K);
+        nops = (int)(b - 1 - a);
+        op0 = b0 = binit = dir == 0 ? a : b - 1;
+        if (nops <= 0) return;
+    }
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int j = tid % SP;
     constexpr int kNone = -(1 << 28);
     const int sub = kRows ? lane / LPR : 0;                    // which of the RPI rows of an instruction this lane reads
     const int col0 = kRows ? (lane % LPR) * VEC : lane * VEC;  // its first column (within group g: + g * EPI)
-    // chain step n uses the operator of chunk cb0 + n (forward) / cb0 + K - 1 - n (backward); n is clamped so that the
-    // requests running ahead of the last step stay inside the recording (K >= 2 wherever this is called)
+    // chain step n uses operator op0 + n os; n is clamped so that the requests running ahead of the last step stay inside the
+    // chain (nops >= 1 wherever a step runs)
     auto fetch = [&](int n, RV (&dst)[CHI], int& e, int i0) {
-        const int nn = min(n, K - 2);
-        const long long k = dir == 0 ? cb0 + nn : cb0 + K - 1 - nn;
-        const RV* __restrict__ src = reinterpret_cast<const RV*>(bt.op + k * SP * SP) + (long long)(wave * IPW + i0) * 64 + lane;
+        const int nn = max(min(n, nops - 1), 0);
+        const long long k = op0 + (long long)nn * os;
+        const RV* __restrict__ src = reinterpret_cast<const RV*>(ops + k * SP * SP) + (long long)(wave * IPW + i0) * 64 + lane;
 #pragma unroll
         for (int q = 0; q < CHI; ++q) dst[q] = src[q * 64];
-        if (tid < SP) e = bt.opexp[k * SP + j];
+        if (tid < SP) e = oexp[k * SP + j];
     };
     RV ovr[D + 1][CHI];
     int ejr[D + 1];
@@ -196,8 +217,12 @@ __global__ __launch_bounds__(NW * 64) void scan2_wide_kernel(BatchView<R> bt) {
     if (dir == 0) {
         R y = 0;
         if (tid < SP) {
-            y = (j < rd.S) ? (R)(bt.ip[(long long)rec * SP + j] + 1e-8) : (R)0;
-            bt.fbound[cb0 * SP + j] = y;
+            if (level == 3) {
+                y = bt.fbound[binit * SP + j];
+            } else {
+                y = (j < rd.S) ? (R)(bt.ip[(long long)rec * SP + j] + 1e-8) : (R)0;
+                bt.fbound[binit * SP + j] = y;
+            }
         }
         auto step = [&](int n, RV (&ov)[CHI], int ej) {
             if constexpr (D == 0) fetch(n, ov, ej, 0);
@@ -242,39 +267,42 @@ __global__ __launch_bounds__(NW * 64) void scan2_wide_kernel(BatchView<R> bt) {
 #pragma unroll
                 for (int w = 0; w < NW; ++w) tot += part[w * SP + j];
                 y = (j < rd.S) ? tot : (R)0;                   // padded speakers carry no mass
-                bt.fbound[(cb0 + n + 1) * SP + j] = y;
+                bt.fbound[(b0 + (long long)(n + 1) * bs) * SP + j] = y;
             }
             lds_barrier();
         };
         if constexpr (D > 0) {
-            if (K > 1) {
+            if (nops > 0) {
 #pragma unroll
                 for (int d = 0; d < D; ++d) fetch(d, ovr[d], ejr[d], 0);
             }
-            for (int n = 0; n + 1 < K; n += D + 1) {
+            for (int n = 0; n < nops; n += D + 1) {
 #pragma unroll
                 for (int u = 0; u <= D; ++u) {
-                    if (n + u + 1 < K) {                       // (uniform)
+                    if (n + u < nops) {                        // (uniform)
                         fetch(n + u + D, ovr[(u + D) % (D + 1)], ejr[(u + D) % (D + 1)], 0);
                         step(n + u, ovr[u], ejr[u]);
                     }
                 }
             }
         } else {
-            for (int n = 0; n + 1 < K; ++n) step(n, ovr[0], 0);
+            for (int n = 0; n < nops; ++n) step(n, ovr[0], 0);
         }
     } else {
         R g = 0;
         if (tid < SP) {
-            g = (j < rd.S) ? (R)1 : (R)0;
-            bt.gbound[(cb0 + K - 1) * SP + j] = g;
+            if (level == 3) {
+                g = bt.gbound[binit * SP + j];
+            } else {
+                g = (j < rd.S) ? (R)1 : (R)0;
+                bt.gbound[binit * SP + j] = g;
+            }
             vec[j] = g;
         }
         lds_barrier();
         // (F^T g)_c = 2^{E_c} <row c of the stored operator, g>: the lanes of a row multiply their VEC elements with
         // their VEC elements of g and the products meet in a butterfly over the row's lanes
         auto step = [&](int n, RV (&ov)[CHI], int ecur) {
-            const long long k = cb0 + K - 1 - n;
             if constexpr (D == 0) fetch(n, ov, ecur, 0);
             RV gl[NG];
 #pragma unroll
@@ -343,28 +371,164 @@ __global__ __launch_bounds__(NW * 64) void scan2_wide_kernel(BatchView<R> bt) {
             if (tid < SP) {
                 g = (tot > (R)0 && j < rd.S) ? scale2(tot, ecur - top) : (R)0;
                 vec[j] = g;
-                bt.gbound[(k - 1) * SP + j] = g;
+                bt.gbound[(b0 + (long long)(n + 1) * bs) * SP + j] = g;
             }
             lds_barrier();
         };
         if constexpr (D > 0) {
-            if (K > 1) {
+            if (nops > 0) {
 #pragma unroll
                 for (int d = 0; d < D; ++d) fetch(d, ovr[d], ejr[d], 0);
             }
-            for (int n = 0; n + 1 < K; n += D + 1) {
+            for (int n = 0; n < nops; n += D + 1) {
 #pragma unroll
                 for (int u = 0; u <= D; ++u) {
-                    if (n + u + 1 < K) {                       // (uniform)
+                    if (n + u < nops) {                        // (uniform)
                         fetch(n + u + D, ovr[(u + D) % (D + 1)], ejr[(u + D) % (D + 1)], 0);
                         step(n + u, ovr[u], ejr[u]);
                     }
                 }
             }
         } else {
-            for (int n = 0; n + 1 < K; ++n) step(n, ovr[0], 0);
+            for (int n = 0; n < nops; ++n) step(n, ovr[0], 0);
         }
     }
+}
+
+// compose_wide: the operator of a group of bt.sgroup consecutive chunks, P = F_(b-1) ... F_a -- what scan_compose_kernel is to
+// the fused path (same arithmetic per product: weights 2^E shifted by the largest exponent on a column's support, the column's
+// scale kept as an integer exponent; oracle/chunked_scan.py::compose), for operators that do not fit the LDS twice (round 6:
+// until then the wide scan walked the flat chain of K - 1 mat-vecs of 0.95 / 1.6 us each, 74 / 128 us of an iteration of
+// T = 10 000 at S = 128 and five times that at T = 50 000).  A column of P depends on that column only, so the grid is
+// (group, block of 16 columns): the four waves of a workgroup share the block's columns, wave w keeps the row tiles w, w + 4, ...
+// of them in the accumulator layout through the whole chain (a product is SP / 4 x SP / 64 MFMAs per wave: the f32 16x16x4
+// instruction runs at the vector rate, so the rows are what gets spread), the scaled columns W go through LDS (SP x 16), F in
+// slabs of KH of its columns, fetched into registers a slab ahead.  Slab rows are padded by 16 elements: the four 16-lane rows
+// of a fragment read hit different banks.
+template <typename R, int SP> struct ComposeWideCfg {
+    static constexpr int CW = 16;                                  // columns of P per workgroup
+    static constexpr int KH = 32768 / (SP * (int)sizeof(R));       // columns of F per slab (32 KB + padding)
+    static constexpr int FLD = SP + 16;
+    static constexpr int VPT = KH * SP * (int)sizeof(R) / 16 / 256;    // 16-byte vectors of a slab per thread
+};
+
+template <typename R, int SP>
+__global__ __launch_bounds__(256) void compose_wide_kernel(BatchView<R> bt) {
+    using Cfg = ComposeWideCfg<R, SP>;
+    using M = Mfma16<R>;
+    using acc_t = typename M::acc_t;
+    typedef R RV __attribute__((ext_vector_type(16 / sizeof(R))));
+    constexpr int NT = SP / 16, MT = NT / 4, KH = Cfg::KH, FLD = Cfg::FLD, VPT = Cfg::VPT, VEC = 16 / (int)sizeof(R), NSLAB = SP / KH;
+    constexpr int kNoMass = -(1 << 24), kNever = -(1 << 28);
+    static_assert(NT % 4 == 0 && VPT >= 1 && (KH * SP / VEC) % 256 == 0, "compose_wide shapes");
+    __shared__ __attribute__((aligned(16))) R Fs[KH * FLD];
+    __shared__ __attribute__((aligned(16))) R Wt[SP * 16];
+    __shared__ int eF[SP];
+    __shared__ int topw[4][16];
+    __shared__ R sigw[4][16];
+    const int sup = blockIdx.x;
+    const int rec = bt.sup_rec[sup];
+    if (bt.state[rec].done) return;
+    const RecDesc rd = bt.recs[rec];
+    const int G = bt.sgroup;
+    const long long cb0 = rd.tile0;
+    const long long a = cb0 + (long long)bt.sup_idx[sup] * G, b = min(a + G, cb0 + rd.ntiles);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l16 = lane & 15, g = lane >> 4;
+    const int i = Cfg::CW * blockIdx.y + l16;          // my column of P
+    R pv[MT][4];                                       // rows 16 (wave + 4 q) + M::row(lane, r)
+    int eP = bt.opexp[a * SP + i];
+#pragma unroll
+    for (int q = 0; q < MT; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pv[q][r] = bt.op[(a * SP + i) * SP + 16 * (wave + 4 * q) + M::row(lane, r)];
+    // slab s of operator k: columns [s KH, (s + 1) KH) of F_k = KH SP contiguous elements; thread t moves the vectors t, t + 256, ...
+    RV fr[VPT];
+    auto fetch = [&](long long k, int sl) {
+        const RV* __restrict__ src = reinterpret_cast<const RV*>(bt.op + k * SP * SP + (long long)sl * KH * SP);
+#pragma unroll
+        for (int u = 0; u < VPT; ++u) fr[u] = src[u * 256 + tid];
+    };
+    auto stash = [&]() {                               // registers -> Fs (column kc of the slab at kc FLD)
+#pragma unroll
+        for (int u = 0; u < VPT; ++u) {
+            const int v = u * 256 + tid, kc = v / (SP / VEC), m = (v % (SP / VEC)) * VEC;
+            *reinterpret_cast<RV*>(Fs + kc * FLD + m) = fr[u];
+        }
+    };
+    if (a + 1 < b) fetch(a + 1, 0);
+    for (long long k = a + 1; k < b; ++k) {
+        for (int t = tid; t < SP; t += 256) eF[t] = bt.opexp[k * SP + t];
+        __syncthreads();
+        // weights of my column, shifted by the largest exponent on its support (over the rows of all four waves)
+        int tj[MT][4], top = kNever;
+#pragma unroll
+        for (int q = 0; q < MT; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int e = eF[16 * (wave + 4 * q) + M::row(lane, r)];
+                tj[q][r] = (pv[q][r] > (R)0 && e > kNoMass / 2) ? e + exponent_of(pv[q][r]) : kNever;
+                top = max(top, tj[q][r]);
+            }
+        top = max_xor<16>(top);
+        top = max_xor<32>(top);
+        if (g == 0) topw[wave][l16] = top;
+        __syncthreads();
+        top = max(max(topw[0][l16], topw[1][l16]), max(topw[2][l16], topw[3][l16]));
+        const bool alive = top > -(1 << 27) && eP > kNoMass / 2;
+#pragma unroll
+        for (int q = 0; q < MT; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * (wave + 4 * q) + M::row(lane, r);
+                Wt[row * 16 + l16] = (alive && tj[q][r] > -(1 << 27)) ? scale2(pv[q][r], eF[row] - top) : (R)0;
+            }
+        acc_t acc[MT];
+#pragma unroll
+        for (int q = 0; q < MT; ++q) acc[q] = acc_t{0, 0, 0, 0};
+#pragma unroll 1
+        for (int sl = 0; sl < NSLAB; ++sl) {
+            stash();
+            __syncthreads();                           // the slab (and, first pass, W) is in LDS
+            if (sl + 1 < NSLAB) fetch(k, sl + 1);      // the next slab -- or the next operator's first one -- during the MFMAs
+            else if (k + 1 < b) fetch(k + 1, 0);
+#pragma unroll 4
+            for (int kk = 0; kk < KH / 4; ++kk) {
+                const R bv = Wt[(sl * KH + 4 * kk + g) * 16 + l16];
+#pragma unroll
+                for (int q = 0; q < MT; ++q) acc[q] = M::mma(Fs[(4 * kk + g) * FLD + 16 * (wave + 4 * q) + l16], bv, acc[q]);
+            }
+            __syncthreads();                           // before the slab is overwritten
+        }
+        R sig = 0;
+#pragma unroll
+        for (int q = 0; q < MT; ++q) sig += (acc[q][0] + acc[q][1]) + (acc[q][2] + acc[q][3]);
+        sig = add_xor<16>(sig);
+        sig = add_xor<32>(sig);
+        if (g == 0) sigw[wave][l16] = sig;
+        __syncthreads();
+        sig = (sigw[0][l16] + sigw[1][l16]) + (sigw[2][l16] + sigw[3][l16]);
+        if (alive && sig > (R)0) {
+            const int e = rescale_exponent(sig);
+#pragma unroll
+            for (int q = 0; q < MT; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pv[q][r] = scale2(acc[q][r], -e);
+            eP += top + e;
+        } else {
+#pragma unroll
+            for (int q = 0; q < MT; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pv[q][r] = 0;
+            eP = kNoMass;
+        }
+        // (eF, W, topw and sigw are rewritten only behind the next product's first barrier resp. after its second one)
+    }
+    R* __restrict__ dst = bt.sop + ((long long)sup * SP + i) * SP;
+#pragma unroll
+    for (int q = 0; q < MT; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[16 * (wave + 4 * q) + M::row(lane, r)] = pv[q][r];
+    if (wave == 0 && g == 0) bt.sopexp[(long long)sup * SP + i] = eP;
 }
 
 // Re-run of one chunk in one direction by one wavefront, lane = state (NREG = SP / 64 states per lane); the
