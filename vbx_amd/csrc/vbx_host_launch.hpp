@@ -102,15 +102,21 @@ template <typename R> void launch_loglik(vbx_batch* b, double eps, bool raw) {
         hipLaunchKernelGGL((rownorm_kernel<R>), dim3(b->ntiles_total), dim3(256), 0, b->ctx->stream, v);
 }
 
-// Block size of the per-recording reductions over tiles (mstep_fin, iter_fin): 1024 threads once a recording has more
-// partials than the smaller block fetches in a few rounds (one recording of T = 200 000: mstep_fin 42 -> 30 us, iter_fin
-// 33 -> 23 us; at T = 50 000 mstep_fin is no faster with 1024 threads, iter_fin 9 -> 8 us).
+// Block size of the per-recording reductions over tiles (fin_kernel): more threads once a recording has more partials than
+// the smaller block fetches in a few rounds (one recording of T = 200 000, rounds 2-3: mstep_fin 42 -> 30 us, iter_fin 33 -> 23 us
+// with 1024 threads instead of 256).
 static int small_kernel_threads(const vbx_batch* b, int from_tiles) {
-    static const int forced = [] { const char* e = experiment_env("VBX_AMD_FIN_THREADS"); const int v = e ? atoi(e) : 0; return (v == 256 || v == 1024) ? v : 0; }();
+    static const int forced = [] { const char* e = experiment_env("VBX_AMD_FIN_THREADS"); const int v = e ? atoi(e) : 0; return (v == 256 || v == 512 || v == 1024) ? v : 0; }();
     if (forced && b->Sp <= 256) return forced;
     int maxtiles = 0;
     for (auto& rd : b->recs) maxtiles = std::max(maxtiles, rd.ntiles);
-    return (maxtiles > from_tiles || b->Sp > 256) ? 1024 : 256;        // (iter_fin: a thread per speaker)
+    // (round 6, one recording, split, us per iteration with 256 / 512 / 1024 threads: T = 12 000 48.7 / 48.0 / 51.3, 20 000 52.9 /
+    //  53.6 / 56.1, 50 000 74.0 / 73.4 / 75.9, 100 000 102.8 / 98.0 / 100.2; four of T = 20 000: 65.5 / 65.0 / 68.8 -- the barriers
+    //  of a block of sixteen waves cost more than its shorter rounds save until a recording has about a thousand partials)
+    if (b->Sp > 256) return 1024;                                      // (iter_fin: a thread per speaker)
+    // (T = 150 000 / 200 000 alone: 126.1 / 149.7 with 512 against 125.0 / 148.6 with 1024; the nine-point sweep over T = 200 000
+    //  on three streams: 1.390 against 1.407 ms -- the lighter block fits beside the other streams' kernels)
+    return (maxtiles > 1200 && b->n_rec == 1) ? 1024 : maxtiles > from_tiles ? 512 : 256;
 }
 
 // chunk_post over the tiles of the batch; REPLAY: the instance that only writes the responsibilities
