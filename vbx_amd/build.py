@@ -42,7 +42,7 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-Wno
 # the sources that decide what the kernels of an EM iteration do and move: profiles/*_pmc_traffic.json carries their
 # hash, and bench.py only quotes a PMC figure whose hash matches the tree it runs from
 ITERATION_SOURCES = ['vbx_host_state.hpp', 'vbx_host_launch.hpp', 'vbx_host_batch.hpp', 'vbx_host_group.hpp', 'vbx_device.hpp', 'vbx_kernels.hpp', 'vbx_scan.hpp', 'vbx_operator.hpp',
-                     'vbx_split.hpp', 'vbx_chunk_loglik.hpp', 'vbx_chunk_post.hpp']
+                     'vbx_split.hpp', 'vbx_chunk_loglik.hpp', 'vbx_chunk_post.hpp', 'vbx_scan_wide.hpp']
 
 
 def iteration_source_hash() -> str:
