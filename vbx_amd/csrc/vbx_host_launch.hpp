@@ -232,7 +232,15 @@ template <typename R, int SP> void launch_scan_wide(vbx_batch* b, const BatchVie
     hipStream_t st = b->ctx->stream;
     {
         LaunchScope ls(b, VBX_K_FB);
-        hipLaunchKernelGGL((scan1_wide_kernel<R, SP>), dim3(b->ntiles_total, SP / ScanWideCfg<R, SP>::CB), dim3(256), 0, st, v);
+        bool launched = false;
+        if constexpr (Scan1WideLdsCfg<R, SP>::kFits) {
+            static const bool off = [] { const char* e = experiment_env("VBX_AMD_SCAN1_WIDE_LDS"); return e && e[0] == '0'; }();
+            if (b->d_lppow && !off) {
+                hipLaunchKernelGGL((scan1_wide_lds_kernel<R, SP>), dim3(b->ntiles_total, SP / Scan1WideLdsCfg<R, SP>::COLS), dim3(1024), 0, st, v);
+                launched = true;
+            }
+        }
+        if (!launched) hipLaunchKernelGGL((scan1_wide_kernel<R, SP>), dim3(b->ntiles_total, SP / ScanWideCfg<R, SP>::CB), dim3(256), 0, st, v);
     }
     {
         LaunchScope ls(b, VBX_K_FB_AUX);
@@ -459,6 +467,11 @@ int choose_fb_algo(vbx_batch* b, bool step_api_logs) {
         if (rc == VBX_OK) rc = dmalloc(b->ctx, &b->d_lppow, (size_t)b->n_rec * (kTileFrames + 1));
         if (rc != VBX_OK) return rc;
         b->recs_dirty = true;                    // (the lp^n tables go up with the recording descriptors)
+    }
+    if (!fused1 && chunked && b->Sp > 64 && b->Sp <= 256 && !b->d_lppow) {      // the wide scan's operator build (scan1_wide_lds_kernel)
+        int rc = dmalloc(b->ctx, &b->d_lppow, (size_t)b->n_rec * (kTileFrames + 1));
+        if (rc != VBX_OK) return rc;
+        b->recs_dirty = true;
     }
     if (!fused1 && !b->d_ahat) {
         const size_t cells = (size_t)b->sum_T * b->Sp;

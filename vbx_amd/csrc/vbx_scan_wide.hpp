@@ -14,6 +14,7 @@
 // (fb_seq_kernel: one wavefront over all T frames) 2 ms.
 #pragma once
 #include "vbx_scan.hpp"
+#include "vbx_operator.hpp"
 
 namespace vbx {
 
@@ -92,6 +93,51 @@ __global__ __launch_bounds__(256) void scan1_wide_kernel(BatchView<R> bt) {
 #pragma unroll
     for (int r = 0; r < NR; ++r) dst[r] = x[r];
     if ((tid % PH) == 0) bt.opexp[(long long)tile * SP + col] = expo;
+}
+
+// scan1_wide with the recursion of the fused path (round 6): b of the WHOLE chunk in LDS (64 KB at S = 128 in f32: it fits since
+// gfx950), 64 columns per workgroup of 1024 threads, and the column recursion of vbx_operator.hpp -- the form scaled by lp^t
+// (one FMA and one product per state), written on pairs of states (v_pk_*_f32), rescaled every fourth frame -- instead of
+// three operations per state, scalar, and a rescale per frame: 48 -> about 22 vector instructions per wave and frame.  The c
+// of the scaled form is computed here from the priors exactly as fin_kernel computes it for chunk_loglik (f64, rounded once),
+// so the kernel also serves forward_backward() calls that never run an M-step.  S > 128 keeps scan1_wide_kernel.
+template <typename R, int SP> struct Scan1WideLdsCfg {
+    static constexpr int COLS = 64;                                // columns per workgroup (16 lanes each)
+    static constexpr int kBytes = (kTileFrames * SP + SP) * (int)sizeof(R);
+    // (S = 256: sixteen states per lane spill at the 128 registers of a 1024-thread block; fp64 has no packed instructions to
+    //  gain from and pays for one workgroup per CU: S = 128, T = 10 000 / 50 000 0.247 / 0.704 -> 0.251 / 0.736 ms per iteration;
+    //  f32: 0.161 / 0.381 -> 0.146 / 0.327, eight recordings of S = 100: 0.405 -> 0.311)
+    static constexpr bool kFits = kBytes <= 144 * 1024 && SP == 128 && sizeof(R) == 4;
+};
+
+template <typename R, int SP>
+__global__ __launch_bounds__(1024) void scan1_wide_lds_kernel(BatchView<R> bt) {
+    using R4 = typename Vec<R>::v4;
+    constexpr int PH = 16, NR = SP / PH;
+    constexpr int NV = (kTileFrames * SP / 4 + 1023) / 1024;
+    __shared__ __attribute__((aligned(16))) R btile[kTileFrames * SP];
+    __shared__ __attribute__((aligned(16))) R cl[SP];
+    const int tile = blockIdx.x;
+    const int rec = bt.tile_rec[tile];
+    if (bt.state[rec].done) return;
+    const RecDesc rd = bt.recs[rec];
+    const int t0 = bt.tile_t0[tile];
+    const int len = min(kTileFrames, rd.T - t0);
+    const int tid = threadIdx.x;
+    stage_to_lds<NV>(reinterpret_cast<R4*>(btile), reinterpret_cast<const R4*>(bt.bmat + (rd.row0 + t0) * SP), len * SP / 4, tid, 1024);
+    if (tid < SP) {
+        const double cj = tid < rd.S ? (1.0 - rd.lp) * bt.pi[(long long)rec * SP + tid] + 1e-8 : 0.0;
+        cl[tid] = (R)(rd.lp >= 0x1p-20 ? cj / rd.lp : cj);
+    }
+    __syncthreads();
+    const int col = blockIdx.y * Scan1WideLdsCfg<R, SP>::COLS + tid / PH, part = tid % PH;
+    R x[1][NR];
+    int expo[1];
+    operator_columns<R, SP, PH, 1>(btile, 0, len, t0 == 0, col, part, rd.lp, cl, bt.lppow + (long long)rec * (kTileFrames + 1), x, expo);
+    R* __restrict__ dst = bt.op + ((long long)tile * SP + col) * SP + part * NR;
+#pragma unroll
+    for (int q = 0; q < NR / 4; ++q) *reinterpret_cast<R4*>(dst + 4 * q) = R4{x[0][4 * q], x[0][4 * q + 1], x[0][4 * q + 2], x[0][4 * q + 3]};
+    if (part == 0) bt.opexp[(long long)tile * SP + col] = expo[0];
 }
 
 // Two values (a, b) in every lane -> ONE per lane, summed over the lane pair (l, l ^ STAGE), STAGE = 16 or 32: lanes with
