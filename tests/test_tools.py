@@ -121,3 +121,20 @@ def test_device_code_holds_no_packed_f32_instruction_that_selects_src1_from_the_
     found = hipbuild.audit_isa(sample)
     assert len(found) == 3 and all(f.startswith('kernel_a: ') for f in found), found
 
+
+
+def test_committed_round_profiles_belong_to_the_committed_kernels():
+    """bench.py quotes a PMC figure only from a profile stamped with the hash of the iteration sources it runs from
+    (vbx_amd/build.py: ITERATION_SOURCES): the profiles committed for the latest round must carry the hash of the tree they
+    are committed with, or the driver's bench line would say `traffic: null` for kernels whose counters are in profiles/."""
+    import glob
+    import json
+    from vbx_amd.build import iteration_source_hash
+    rounds = sorted({os.path.basename(p).split('_')[0] for p in glob.glob(os.path.join(REPO, 'profiles', 'r[0-9][0-9]_*_pmc_traffic.json'))})
+    assert rounds, 'no PMC profiles committed'
+    latest = rounds[-1]
+    now = iteration_source_hash()
+    files = sorted(glob.glob(os.path.join(REPO, 'profiles', f'{latest}_*_pmc_traffic.json')))
+    assert len(files) >= 10, files
+    stale = [os.path.basename(p) for p in files if json.load(open(p)).get('iteration_source_sha16') != now]
+    assert not stale, f'{len(stale)} of {len(files)} {latest} profiles were taken on other kernel sources than {now}: {stale[:3]} ... (tools/closing_run.sh {latest})'
