@@ -1341,3 +1341,30 @@ def test_wide_two_level_walk_equals_the_flat_chain(ctx, S, precision, tol):
             assert np.abs(a['gamma'] - b['gamma']).max() <= tol, (group, i, np.abs(a['gamma'] - b['gamma']).max())
             assert np.abs(a['pi'] - b['pi']).max() <= tol, (group, i)
             assert rel_err(a['Li'], b['Li']) <= (1e-12 if precision == 'fp64' else 1e-6), (group, i)
+
+
+def test_pipelined_batch_call_equals_the_plain_one(monkeypatch):
+    """vbx_amd.batch.run_shard_hip runs a large batch call as two halves on two contexts of the device (uploads of one behind
+    the iterations of the other, round 6): forced on a small batch here (VBX_AMD_BATCH_PIPELINE=1) -- same results in input
+    order as the plain call, an error in one half surfaces in the caller."""
+    from vbx_amd.batch import VBx_batch
+    from vbx_amd.synth import make_recording
+    recs = []
+    for k, (T, S) in enumerate([(700, 6), (1500, 20), (300, 4), (1300, 30), (2100, 11), (129, 3), (900, 17)]):
+        X, Phi, _ = make_recording(T, S, seed=170 + k, kappa=0.05, dtype=np.float32)
+        g = np.random.default_rng(1700 + k).gamma(1.0, size=(T, S))
+        recs.append(dict(X=X, Phi=Phi, pi=S, gamma=g / g.sum(1, keepdims=True), loopProb=0.9, Fa=0.3 + 0.05 * k, Fb=17.0))
+    monkeypatch.setenv('VBX_AMD_BATCH_PIPELINE', '0')
+    plain = VBx_batch(recs, maxIters=5, epsilon=-np.inf, return_model=True)
+    monkeypatch.setenv('VBX_AMD_BATCH_PIPELINE', '1')
+    piped = VBx_batch(recs, maxIters=5, epsilon=-np.inf, return_model=True)
+    for a, b in zip(piped, plain):
+        assert len(a) == 5 and a[0].shape == b[0].shape
+        np.testing.assert_allclose(a[0], b[0], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(a[1], b[1], rtol=0, atol=2e-6)
+        np.testing.assert_allclose([r[0] for r in a[2]], [r[0] for r in b[2]], rtol=1e-6)
+        np.testing.assert_allclose(a[3], b[3], rtol=0, atol=2e-5 * max(1.0, np.abs(b[3]).max()))
+    bad = [dict(r) for r in recs]
+    bad[-1]['Phi'] = np.ones(7)                                # (the second half's last recording)
+    with pytest.raises((ValueError, AssertionError, Exception)):
+        VBx_batch(bad, maxIters=2, epsilon=-np.inf)

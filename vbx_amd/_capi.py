@@ -710,9 +710,12 @@ def fcluster_distance(Z, t):
     return labels
 
 
-def default_context(device: int | None = None) -> Context:
+def default_context(device: int | None = None, slot: int = 0) -> Context:
+    """The process-wide context of a device; ``slot`` > 0: a further one of the same device (its own streams and device
+    arena: vbx_amd.batch pipelines a large batch call over two of them)."""
     if device is None:
         device = int(os.environ.get('VBX_AMD_DEVICE', os.environ.get('LOCAL_RANK', '0')))
-    if device not in _default_ctx:
-        _default_ctx[device] = Context(device)
-    return _default_ctx[device]
+    key = device if slot == 0 else (device, slot)
+    if key not in _default_ctx:
+        _default_ctx[key] = Context(device)
+    return _default_ctx[key]
