@@ -104,15 +104,14 @@ def _padded_states(n_states):
 
 
 def _pipeline_halves(n_rec, n_bytes):
-    """A batch call large enough to be worth running as two halves on two contexts, the second half's uploads behind the
-    first half's iterations and the first half's results behind the second half's iterations (VBX_AMD_BATCH_PIPELINE=0 / 1
-    forces it off / on)."""
-    env = os.environ.get('VBX_AMD_BATCH_PIPELINE')
-    if env in ('0', '1'):
-        return env == '1' and n_rec >= 2
-    # measured (64 recordings of T = 10 000, 40 iterations): 27.4 -> 24.6 ms per call, fp64 45.6 -> 39.9, 128 recordings 42.1 ->
-    # 37.4; 32 recordings 14.7 -> 15.5, 16: 8.6 -> 10.3 -- the second context's threads and synchronisation cost a millisecond
-    return n_rec >= 48 and n_bytes >= (256 << 20)
+    """Run a batch call as two halves on two contexts, the second half's uploads behind the first half's iterations and the
+    first half's results behind the second half's iterations?  Only on request (VBX_AMD_BATCH_PIPELINE=1)."""
+    # Measured (64 recordings of T = 10 000, 40 iterations): 27.4 -> 24.6 ms per call, fp64 45.6 -> 39.9, 128 recordings 42.1 ->
+    # 37.4; 32 recordings 14.7 -> 15.5, 16: 8.6 -> 10.3 (the second context's threads and synchronisation cost a millisecond)
+    # -- in a process that holds no other streams.  Inside bench.py (a ctx of its own, the default ctx and the second one: a
+    # dozen streams on eight hardware queues, two busy streams to a queue) the same call takes 30.1 ms against 28.0 plain, so
+    # the pipeline is NOT the default: VBX_AMD_BATCH_PIPELINE=1 asks for it (it pays from 48 recordings and 256 MB).
+    return os.environ.get('VBX_AMD_BATCH_PIPELINE') == '1' and n_rec >= 2
 
 
 def _run_one_batch(ctx, items, idx, D, prec, maxIters, epsilon, results, gates=None):
@@ -162,9 +161,9 @@ def run_shard_hip(items, maxIters, epsilon, precision=None, device=None):
     """Run normalised recordings on the local GPU, one vbx_batch per (feature dimension, padded state count): every
     recording of a batch runs with the widest one's padding, and one recording with more than 64 speakers would push the
     others from the fused kernels onto the wide scan.  ``precision=None`` is VBx()'s rule (VBX_AMD_PRECISION, else fp32
-    only when every X of the batch is float32).  A large batch (48 recordings and 256 MB of arrays or more) runs as two
-    halves on two contexts of the device: the second half uploads while the first iterates, the first half's results come
-    back while the second iterates."""
+    only when every X of the batch is float32).  With VBX_AMD_BATCH_PIPELINE=1 a batch runs as two halves on two contexts of
+    the device: the second half uploads while the first iterates, the first half's results come back while the second
+    iterates (_pipeline_halves)."""
     from . import _capi
     from .VBx import _pick_precision
     ctx = _capi.default_context(device)
