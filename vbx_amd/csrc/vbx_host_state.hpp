@@ -172,6 +172,7 @@ struct vbx_batch {
     // chunked scan
     void *d_op = nullptr, *d_fbound = nullptr, *d_gbound = nullptr;
     int* d_opexp = nullptr;
+    RecState* h_poll = nullptr;                   // pinned host copy of the states for the stop test (run_all_done)
     void* d_cop = nullptr;                        // c of the operator recursion per recording (mstep_fin -> chunk_loglik)
     vbx::LpPow* d_lppow = nullptr;                // lp^n tables of the recordings (host-computed)
     void* d_oph = nullptr;                        // half-tile operators of the fused path (chunk_loglik -> chunk_post)
