@@ -1368,3 +1368,27 @@ def test_pipelined_batch_call_equals_the_plain_one(monkeypatch):
     bad[-1]['Phi'] = np.ones(7)                                # (the second half's last recording)
     with pytest.raises((ValueError, AssertionError, Exception)):
         VBx_batch(bad, maxIters=2, epsilon=-np.inf)
+
+
+@pytest.mark.parametrize('T,S', [(30000, 100), (30000, 200), (160000, 70)])
+def test_wide_scan_on_long_recordings_equals_the_sequential_walk(ctx, T, S):
+    """64 < S <= 256 on long recordings: the automatic two-level walk (groups of sqrt(K / 3.5) chunks: 8, 8 and 19 here), the
+    LDS-resident f32 operator build at S <= 128 and fin_kernel on 512 / 1024 threads against the sequential walk, which
+    shares none of it."""
+    from vbx_amd import _capi
+    from vbx_amd.synth import make_recording
+    X, Phi, _ = make_recording(T, S, seed=S, kappa=0.05, dtype=np.float32)
+    g0 = np.random.default_rng(S + 5).gamma(1.0, size=(T, S))
+    g0 /= g0.sum(1, keepdims=True)
+    for precision, tol in (('fp64', 1e-10), ('fp32', 5e-5)):
+        out = {}
+        for algo in (_capi.FB_CHUNKED, _capi.FB_SEQUENTIAL):
+            batch = _capi.Batch(ctx, [T], [S], 128, precision=precision, max_iters=3)
+            batch.set_option(_capi.OPT_FB_ALGO, algo)
+            batch.set_recording(0, X, Phi, np.ones(S) / S, g0, 0.95, 0.3, 17.0)
+            batch.run(3, -np.inf)
+            out[algo] = batch.result(0, want_model=False)
+            batch.close()
+        a, b = out[_capi.FB_CHUNKED], out[_capi.FB_SEQUENTIAL]
+        assert np.abs(a['gamma'] - b['gamma']).max() <= tol, (precision, np.abs(a['gamma'] - b['gamma']).max())
+        assert np.abs(a['pi'] - b['pi']).max() <= tol and rel_err(a['Li'], b['Li']) <= 1e-8, precision
